@@ -1,0 +1,294 @@
+/*
+ * webdgs.h -- C ABI of libwebdgs_hip.so: the MI355X (gfx950) hot path of krispy-kenay/WebDGS.
+ *
+ * The reference has no FFI: its boundary is the set of TypeScript operator classes that
+ * src/trainer.ts and src/viewer.ts construct.  Every entry point below names the
+ * reference interface it replaces (paths relative to the reference's src/).  Conventions:
+ *
+ *   - every function returns int: 0 = WDGS_OK, <0 = WDGS_E_*; wdgs_last_error() gives the text
+ *     (the reference throws `Error`, e.g. renderers/tiled-rasterizer.ts:308-330);
+ *   - `void*` arguments named *_dev are DEVICE pointers (hipMalloc / torch / wdgs_buffer_ptr); no torch or
+ *     HIP types appear in signatures;
+ *   - ops own the buffers they create and free them in *_destroy (idempotent on NULL), as the reference's
+ *     destroy() methods do (renderers/tiled-forward-pass.ts:518-533); borrowed pointers are never freed;
+ *   - "encode" = the reference's encode(encoder, ...): work is queued on the device's HIP stream in call
+ *     order and runs asynchronously; wdgs_device_synchronize() = queue.onSubmittedWorkDone()
+ *     (trainer.ts:639-645).  wdgs_buffer_write() is stream-ordered (queue.writeBuffer, camera/camera.ts:194);
+ *   - sizes that the reference derives on the GPU (total tile entries) stay on the GPU: no host read-back
+ *     inside a step.  Capacity overflow is a hard error reported by *_check / wdgs_device_synchronize
+ *     (the reference silently overruns: SURVEY Q1, Q2);
+ *   - handles are not thread-safe; use one host thread per wdgs_device.
+ *
+ * Data layouts (byte-exact with the reference unless marked INTERNAL):
+ *   Gaussian        6 x u32 = 12 fp16: x y z opacity_raw | rot w x y z | log-sigma x y z, pad   shaders/common.wgsl:20-24
+ *   SH              24 x u32 = 48 fp16, [k][rgb], 16 coefficient slots                          shaders/tiled-forward.wgsl:64-86
+ *   Splat           6 x u32 fp16 pairs: ndc.xy | extent.xy px | conic.xy | conic.z,0 | r,g | b,opacity   shaders/common.wgsl:26-33
+ *   CameraUniforms  68 f32: view, view_inv, proj, proj_inv (column-major), viewport.xy, focal.xy  shaders/common.wgsl:1-8
+ *   GaussianGradient 8 x u32 = 16 fp16: dpos.xyz dopacity | drot.wxyz | dlogsigma.xyz 0 | drgb 0  shaders/tiled-backward.wgsl:18-23
+ *   OptVec4 {param,m,v: vec4f} 48 B; OptFloat {param,m,v} 12 B; param_sh 48 f32; state_sh 48 x (m,v)   renderers/optimizer.ts:7-11
+ *   images          rgba8unorm, row-major, W*H*4 bytes (textures in the reference)
+ *   grad accumulators INTERNAL: i32 x 12 per Gaussian {mean.x, mean.y, conic.x, conic.y, conic.z, opacity, r, g, b, 0, 0, 0}
+ *                   (the reference keeps four arrays, renderers/tiled-backward-pass.ts:249-252; same fixed-point x1e6 values)
+ */
+#ifndef WEBDGS_H
+#define WEBDGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WDGS_OK 0
+#define WDGS_E_INVALID (-1)  /* bad argument / API misuse */
+#define WDGS_E_HIP (-2)      /* HIP runtime error */
+#define WDGS_E_CAPACITY (-3) /* a device-side capacity was exceeded (tile entries, densify output) */
+#define WDGS_E_STATE (-4)    /* getter before first encode, mismatched sizes, ... */
+
+typedef struct wdgs_device wdgs_device;
+typedef struct wdgs_buffer wdgs_buffer;
+typedef struct wdgs_prefix_scanner wdgs_prefix_scanner;
+typedef struct wdgs_sorter wdgs_sorter;
+typedef struct wdgs_tiled_forward wdgs_tiled_forward;
+typedef struct wdgs_tiled_rasterizer wdgs_tiled_rasterizer;
+typedef struct wdgs_tiled_backward wdgs_tiled_backward;
+typedef struct wdgs_optimizer wdgs_optimizer;
+typedef struct wdgs_densify_prune wdgs_densify_prune;
+
+const char* wdgs_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int wdgs_abi_version(void);
+
+/* ---------------------------------------------------------------- device / queue
+ * Replaces GPUDevice + GPUQueue (main.ts:186-201).  external_hip_stream may be NULL (the device creates its own
+ * stream) or a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream). */
+int wdgs_device_create(int hip_ordinal, void* external_hip_stream, wdgs_device** out);
+int wdgs_device_destroy(wdgs_device* dev);
+/* queue.onSubmittedWorkDone(): waits for the stream, then reports deferred device-side errors. */
+int wdgs_device_synchronize(wdgs_device* dev);
+/* Per-kernel hipEvent timing (the reference only has a wall-clock meter, trainer.ts:570,647-651). */
+int wdgs_device_set_profiling(wdgs_device* dev, int enabled);
+/* After a synchronize: copies up to `cap` records; returns the number of distinct kernels through *count. */
+typedef struct wdgs_kernel_time {
+    char name[48];
+    uint32_t launches;
+    float total_ms;
+} wdgs_kernel_time;
+int wdgs_device_get_kernel_times(wdgs_device* dev, wdgs_kernel_time* out, uint32_t cap, uint32_t* count);
+int wdgs_device_reset_kernel_times(wdgs_device* dev);
+
+/* Raw device<->host copies on the device's stream (copy_to_host synchronises): mapAsync/getMappedRange
+ * (trainer.ts:455-458) and queue.writeBuffer. */
+int wdgs_copy_to_host(wdgs_device* dev, void* dst_host, const void* src_dev, size_t bytes);
+int wdgs_copy_to_device(wdgs_device* dev, void* dst_dev, const void* src_host, size_t bytes);
+int wdgs_memset(wdgs_device* dev, void* dst_dev, int value, size_t bytes); /* encoder.clearBuffer */
+
+/* ---------------------------------------------------------------- buffers (for hosts without their own allocator)
+ * Replaces device.createBuffer / GPUBuffer.destroy; contents are zero-filled like WebGPU buffers. */
+int wdgs_buffer_create(wdgs_device* dev, size_t bytes, wdgs_buffer** out);
+int wdgs_buffer_destroy(wdgs_buffer* buf);
+void* wdgs_buffer_ptr(const wdgs_buffer* buf);
+size_t wdgs_buffer_size(const wdgs_buffer* buf);
+int wdgs_buffer_write(wdgs_device* dev, wdgs_buffer* buf, size_t offset, const void* src_host, size_t bytes);
+int wdgs_buffer_read(wdgs_device* dev, const wdgs_buffer* buf, size_t offset, void* dst_host, size_t bytes);
+
+/* ---------------------------------------------------------------- prefix scanner
+ * Replaces get_prefix_scanner(maxElements, device): PrefixScanner (prefix/prefix.ts:140, interface 26-43).
+ * Exclusive u32 scan.  No 2 097 152-element cap. */
+int wdgs_prefix_scanner_create(wdgs_device* dev, uint32_t max_elements, wdgs_prefix_scanner** out);
+int wdgs_prefix_scanner_destroy(wdgs_prefix_scanner* s);
+void* wdgs_prefix_scanner_input(wdgs_prefix_scanner* s);  /* input_buffer  (u32[max_elements]) */
+void* wdgs_prefix_scanner_output(wdgs_prefix_scanner* s); /* output_buffer (u32[max_elements]) */
+int wdgs_prefix_scanner_set_count(wdgs_prefix_scanner* s, uint32_t count);
+int wdgs_prefix_scanner_scan(wdgs_prefix_scanner* s);
+/* Scan arbitrary device arrays with this scanner's scratch (count <= max_elements). */
+int wdgs_prefix_scanner_scan_ptr(wdgs_prefix_scanner* s, const void* in_dev, void* out_dev, uint32_t count);
+
+/* ---------------------------------------------------------------- dynamic sorter
+ * Replaces get_dynamic_sorter(maxCapacity, device, statsBuffer): DynamicSortStuff (sort/sort_dynamic.ts:252,
+ * interface 9-24).  Stable ascending LSD radix sort of (key u32, value u32) pairs; the element count is read on
+ * the device from stats_dev[0] (TilePipelineStats.total_tile_entries).  Results land in
+ * ping_pong[final_out_index] (sort_dynamic.ts:24, 386).  key_bits limits the passes to the significant digits
+ * (the reference always runs 4). */
+int wdgs_sorter_create(wdgs_device* dev, uint32_t max_capacity, const void* stats_dev, wdgs_sorter** out);
+int wdgs_sorter_destroy(wdgs_sorter* s);
+void* wdgs_sorter_keys(wdgs_sorter* s, int ping_pong_index);   /* sort_depths_buffer  */
+void* wdgs_sorter_values(wdgs_sorter* s, int ping_pong_index); /* sort_indices_buffer */
+int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits);
+int wdgs_sorter_final_out_index(wdgs_sorter* s);  /* DynamicSortStuff.final_out_index */
+uint32_t wdgs_sorter_capacity(wdgs_sorter* s);
+
+/* ---------------------------------------------------------------- TiledForwardPass
+ * Replaces `new TiledForwardPass(device, pointCloud, cameraBuffer, config)` (renderers/tiled-forward-pass.ts:120-125,
+ * config 24-31), .encode (341-387), setters (389-425), .getResources (428-443), getters (445-459), .destroy (518). */
+typedef struct wdgs_tiled_forward_config {
+    uint32_t num_points;         /* pointCloud.num_points */
+    uint32_t sh_deg;             /* pointCloud.sh_deg */
+    uint32_t viewport_width;
+    uint32_t viewport_height;
+    float gaussian_scale;        /* default 1.0 (declared, unused by the tiled path: SURVEY A3) */
+    float point_size_px;         /* default 3.0 */
+    float max_splat_radius_px;   /* default 128.0 */
+    uint32_t render_mode;        /* 1 = 'gaussian', 0 = 'pointcloud' */
+    uint32_t max_tile_entries;   /* 0 = auto: max(30*N, 1<<20) rounded up to 4096 */
+    uint32_t compat_caps;        /* 1 = reproduce the reference's capacity caps (min(30N, 32Mi, 2097152) -> x3840) */
+} wdgs_tiled_forward_config;
+
+typedef struct wdgs_tiled_forward_resources { /* TiledForwardResources (tiled-forward-pass.ts:33-46) */
+    void* splat_buffer;        /* Splat[num_points] */
+    void* depths_buffer;       /* u32[num_points] ordered-uint view z */
+    void* tile_keys_buffer;    /* u32[max_tile_entries]  (sorted after encode) */
+    void* tile_indices_buffer; /* u32[max_tile_entries]  (sorted after encode) */
+    void* tile_offsets_buffer; /* u32[num_points] per-GAUSSIAN exclusive scan */
+    void* tile_counts_buffer;  /* u32[num_points] */
+    void* stats_buffer;        /* u32[4] {total_tile_entries, visible_gaussians, overflow_flag, pad} */
+    uint32_t num_tiles_x, num_tiles_y, total_tiles, max_tile_entries;
+    float settings[7];         /* RenderSettings (shaders/common.wgsl:10-18) */
+} wdgs_tiled_forward_resources;
+
+int wdgs_tiled_forward_create(wdgs_device* dev, const wdgs_tiled_forward_config* cfg, wdgs_tiled_forward** out);
+int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op);
+/* encode(encoder, {skipSort}): K1 project+count, scan, stats, K6 emit, sort. gaussians/sh/camera are device pointers. */
+int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians_dev, const void* sh_dev, const void* camera_dev, int skip_sort);
+int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t width, uint32_t height);
+int wdgs_tiled_forward_set_render_mode(wdgs_tiled_forward* op, uint32_t render_mode);
+int wdgs_tiled_forward_set_point_size(wdgs_tiled_forward* op, float point_size_px);
+int wdgs_tiled_forward_set_gaussian_scale(wdgs_tiled_forward* op, float scale);
+int wdgs_tiled_forward_get_resources(wdgs_tiled_forward* op, wdgs_tiled_forward_resources* out);
+/* Synchronises and returns WDGS_E_CAPACITY if the last encode overflowed max_tile_entries; stats_out (4 x u32) optional. */
+int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out);
+
+/* ---------------------------------------------------------------- TiledRasterizer
+ * Replaces `new TiledRasterizer({device, forwardPass, format})` (renderers/tiled-rasterizer.ts:57), .encode(encoder,w,h)
+ * (180-242: tile ranges K12-K13 + composite K14), texture getters (308-330), .destroy (359).  The tile grid follows
+ * the forward pass's CURRENT viewport (fixes the stale-grid host bug). */
+int wdgs_tiled_rasterizer_create(wdgs_device* dev, wdgs_tiled_forward* forward, uint32_t compat_caps, wdgs_tiled_rasterizer** out);
+int wdgs_tiled_rasterizer_destroy(wdgs_tiled_rasterizer* op);
+int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint32_t height);
+/* Getters fail with WDGS_E_STATE before the first encode, as the reference throws. */
+int wdgs_tiled_rasterizer_get_output(wdgs_tiled_rasterizer* op, void** rgba8_dev);        /* getOutputTextureView   */
+int wdgs_tiled_rasterizer_get_alpha(wdgs_tiled_rasterizer* op, void** final_t_dev);       /* getAlphaTextureView  f32[W*H] */
+int wdgs_tiled_rasterizer_get_n_contrib(wdgs_tiled_rasterizer* op, void** n_contrib_dev); /* getNContribTextureView u32[W*H] */
+int wdgs_tiled_rasterizer_get_tile_offsets(wdgs_tiled_rasterizer* op, void** ranges_dev); /* getTileOffsetsBuffer: per-TILE table u32[T+1] */
+
+/* ---------------------------------------------------------------- TiledBackwardPass
+ * Replaces `new TiledBackwardPass(device, pointCloud, config)` (renderers/tiled-backward-pass.ts:136-140, config 27-34,
+ * TrainingConfig 19-25), .encode (592-740), .computeLossOnly (383), .computeMetricMap (425), .computeMetricCounts (514),
+ * .normalizeMetricCounts (565), getters (409-421, 832), .setViewport (742), .setTrainingConfig (812), .destroy (836). */
+typedef struct wdgs_training_config {
+    float lambda_l1, lambda_l2, lambda_dssim, c1, c2; /* defaults 0.8, 0.0, 0.2, 1e-4, 9e-4 (trainer.ts:100-104) */
+} wdgs_training_config;
+typedef struct wdgs_tiled_backward_config {
+    uint32_t num_points;
+    uint32_t sh_deg;
+    uint32_t viewport_width, viewport_height;
+    wdgs_training_config training;
+    float gaussian_scale, point_size_px, max_splat_radius_px;
+} wdgs_tiled_backward_config;
+typedef struct wdgs_tiled_backward_resources { /* TiledBackwardResources (tiled-backward-pass.ts:40-50) */
+    const void* splat_buffer;
+    const void* tile_offsets_buffer; /* the RASTERIZER's per-tile table (trainer.ts:621) */
+    const void* tile_indices_buffer; /* sorted indices */
+    const void* camera_buffer;
+    const void* alpha_texture;       /* f32[W*H] final T */
+    const void* n_contrib_texture;   /* u32[W*H] */
+} wdgs_tiled_backward_resources;
+
+int wdgs_tiled_backward_create(wdgs_device* dev, const wdgs_tiled_backward_config* cfg, wdgs_tiled_backward** out);
+int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op);
+/* encode: K15 loss gradient, clear accumulators, K16 backward raster, K17 geometry backward -> GaussianGradient[N]. */
+int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev,
+                               const wdgs_tiled_backward_resources* res, const void* gaussians_dev);
+int wdgs_tiled_backward_compute_loss_only(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev);
+int wdgs_tiled_backward_compute_metric_map(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev, float threshold);
+int wdgs_tiled_backward_compute_metric_counts(wdgs_tiled_backward* op, const wdgs_tiled_backward_resources* res, uint32_t num_instances, int clear);
+int wdgs_tiled_backward_normalize_metric_counts(wdgs_tiled_backward* op, uint32_t divisor);
+int wdgs_tiled_backward_set_viewport(wdgs_tiled_backward* op, uint32_t width, uint32_t height);
+int wdgs_tiled_backward_set_training_config(wdgs_tiled_backward* op, const wdgs_training_config* cfg);
+void* wdgs_tiled_backward_gradients(wdgs_tiled_backward* op);     /* getGradientsBuffer: GaussianGradient[N] */
+void* wdgs_tiled_backward_metric_counts(wdgs_tiled_backward* op); /* getMetricCountsBuffer: u32[N] */
+void* wdgs_tiled_backward_loss_image(wdgs_tiled_backward* op);    /* getLossTextureView: rgba32float W*H */
+void* wdgs_tiled_backward_metric_map(wdgs_tiled_backward* op);    /* getMetricMapTextureView: u32[W*H] */
+void* wdgs_tiled_backward_accumulators(wdgs_tiled_backward* op);  /* INTERNAL i32[N*12] (for parity tests) */
+void* wdgs_tiled_backward_metric_minmax(wdgs_tiled_backward* op); /* u32[2] global (min,max) of the last metric map */
+/* Bilinear down-sample of an rgba8 image (the blit render pass of trainer.ts:303-328, shaders/blit.wgsl fs_main). */
+int wdgs_downsample_rgba8(wdgs_device* dev, const void* src_dev, uint32_t src_w, uint32_t src_h, void* dst_dev, uint32_t dst_w, uint32_t dst_h);
+
+/* ---------------------------------------------------------------- Optimizer
+ * Replaces allocateOptimizerStateBuffers (renderers/optimizer.ts:27-38), `new Optimizer(device, pointCloud, params?,
+ * initialState?)` (71-88), .step (295-350), hyperparameter accessors (256-278), .destroy (352). */
+typedef struct wdgs_adam_hyperparameters { /* AdamHyperparameters (renderers/adam-config.ts:1-21) */
+    float lr_pos, lr_color, lr_opacity, lr_scale, lr_rot, beta1, beta2, epsilon;
+} wdgs_adam_hyperparameters;
+typedef struct wdgs_optimizer_state { /* OptimizerStateBuffers (optimizer.ts:13-20); device pointers */
+    void* opt_pos;     /* OptVec4[N]   48 B */
+    void* opt_rot;     /* OptVec4[N]   48 B */
+    void* opt_scale;   /* OptVec4[N]   48 B */
+    void* opt_opacity; /* OptFloat[N]  12 B */
+    void* param_sh;    /* f32[N*48] */
+    void* state_sh;    /* (m,v)[N*48] */
+} wdgs_optimizer_state;
+/* Byte sizes of the six state arrays for n points, in the struct's field order. */
+int wdgs_optimizer_state_sizes(uint32_t num_points, size_t sizes_out[6]);
+/* initial_state == NULL: the optimizer allocates zeroed state and initialises the fp32 masters from the fp16 point
+ * cloud (K20, optimizer.ts:166-253).  Otherwise the given buffers are ADOPTED as-is (optimizer.ts:81-88) and `owns_state`
+ * says whether destroy frees them. */
+int wdgs_optimizer_create(wdgs_device* dev, uint32_t num_points, const wdgs_adam_hyperparameters* params,
+                          const void* gaussians_dev, const void* sh_dev,
+                          const wdgs_optimizer_state* initial_state, int owns_state, uint32_t initial_iteration, wdgs_optimizer** out);
+int wdgs_optimizer_destroy(wdgs_optimizer* op);
+/* K20 (optimizer.ts:145-253 initBuffers): fp16 point cloud -> fp32 master parameters of this optimizer's state; m, v untouched. */
+int wdgs_optimizer_init_from_point_cloud(wdgs_optimizer* op, const void* gaussians_dev, const void* sh_dev);
+/* step(encoder, pointCloud, gradientsBuffer, tileCountsBuffer): iteration++, K18 Adam, K19 re-pack into gaussians/sh. */
+int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, const void* gradients_dev, const void* tile_counts_dev);
+/* Data-parallel variant: gradients are fp32 sums over views, 14 f32 per Gaussian in GaussianGradient
+ * component order {pos3, opacity, rot4, logsigma3, rgb3}, plus u32 visibility counts (Adam runs where count > 0). */
+int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, const void* grad_f32_dev, const void* visible_counts_dev);
+/* acc_f32[N*14] += unpack(GaussianGradient[N]) where tile_counts > 0; visible[N] += (tile_counts > 0). */
+int wdgs_accumulate_gradients(wdgs_device* dev, uint32_t num_points, const void* gradients_dev, const void* tile_counts_dev,
+                              void* acc_f32_dev, void* visible_counts_dev);
+uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op);
+int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out);
+int wdgs_optimizer_set_hyperparameters(wdgs_optimizer* op, const wdgs_adam_hyperparameters* params);
+int wdgs_optimizer_get_state(wdgs_optimizer* op, wdgs_optimizer_state* out); /* getStateBuffers */
+/* Detaches the state so destroy does not free it (hand-over across a densify swap, trainer.ts:492-495). */
+int wdgs_optimizer_release_state(wdgs_optimizer* op, wdgs_optimizer_state* out);
+
+/* ---------------------------------------------------------------- DensifyPrunePass
+ * Replaces `new DensifyPrunePass(device, config)` (renderers/densify-prune.ts:108, config 17-30), .setConfig/.ensureSize
+ * (279-312), .encodePrepare (458-468: decide K26, scan, cap K27, scan, total K28), .encodeScatter (470-678: K29 + K30). */
+typedef struct wdgs_densify_config {
+    uint32_t num_views;              /* numViews */
+    uint32_t clone_threshold;        /* cloneThreshold (metric count) */
+    float split_threshold;           /* splitThreshold (max scale) */
+    float prune_threshold;           /* pruneThreshold (opacity) */
+    uint32_t max_new_points_per_step;/* 0 = unlimited */
+    uint64_t max_buffer_bytes;       /* 128 MiB in the reference; 0 = unlimited */
+} wdgs_densify_config;
+typedef struct wdgs_densify_prepared { /* DensifyPrunePrepared (densify-prune.ts:42-48) */
+    void* action_buffer;     /* u32[N] 0 keep, 1 clone, 2 split, 3 prune */
+    void* out_count_buffer;  /* u32[N] */
+    void* out_offset_buffer; /* u32[N] exclusive scan */
+    void* out_total_buffer;  /* u32[1] */
+    uint32_t max_out_points;
+} wdgs_densify_prepared;
+
+int wdgs_densify_prune_create(wdgs_device* dev, const wdgs_densify_config* cfg, wdgs_densify_prune** out);
+int wdgs_densify_prune_destroy(wdgs_densify_prune* op);
+int wdgs_densify_prune_set_config(wdgs_densify_prune* op, const wdgs_densify_config* cfg);
+int wdgs_densify_prune_ensure_size(wdgs_densify_prune* op, uint32_t num_points);
+int wdgs_densify_prune_encode_prepare(wdgs_densify_prune* op, uint32_t num_points, const void* gaussians_dev,
+                                      const void* metric_counts_dev, wdgs_densify_prepared* out);
+/* Reads the 4-byte total back (the one device->host crossing of the densify path, trainer.ts:440-458). */
+int wdgs_densify_prune_read_total(wdgs_densify_prune* op, uint32_t* total_out);
+/* encodeScatter: out_num_points must equal the size of the output buffers (the reference throws otherwise,
+ * densify-prune.ts:478-480).  in_state/out_state may both be NULL (point cloud only). */
+int wdgs_densify_prune_encode_scatter(wdgs_densify_prune* op, uint32_t in_points, const void* in_gaussians_dev, const void* in_sh_dev,
+                                      const wdgs_optimizer_state* in_state, uint32_t out_num_points, int reset_new_optimizer_state,
+                                      void* out_gaussians_dev, void* out_sh_dev, const wdgs_optimizer_state* out_state);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEBDGS_H */

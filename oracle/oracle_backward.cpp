@@ -35,6 +35,12 @@ static Cov3D covariance3D(vec4 quaternion, vec3 scale) {  // common.wgsl:44-68
 
 static const f32 GRAD_SCALE = 1000000.0f;  // common.wgsl:111
 static inline i32 to_fixed(f32 value) { return to_i32(value * GRAD_SCALE); }              // common.wgsl:113-116
+// atomicAdd on atomic<i32> wraps (two's complement); accumulate through u32 so the host addition wraps too.
+static inline void acc_add(i32* p, i32 v) {
+    u32* up = reinterpret_cast<u32*>(p);
+#pragma omp atomic
+    *up += (u32)v;
+}
 static inline f32 from_fixed(i32 fixed_val) { return (f32)fixed_val / GRAD_SCALE; }       // common.wgsl:118-121
 
 static inline vec3 texel_rgb(const uint8_t* img, u32 W, u32 H, i32 x, i32 y) {  // clamp-to-edge textureLoad of rgba8unorm
@@ -163,9 +169,7 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
                     const f32 grad_pix = dL_dpixel[ch];
                     const f32 dchannel_dcolor = alpha * T;
                     const f32 dL_dc = dchannel_dcolor * grad_pix;
-                    const i32 fx = to_fixed(dL_dc);
-#pragma omp atomic
-                    grad_colors[(size_t)g * 3u + ch] += fx;
+                    acc_add(&grad_colors[(size_t)g * 3u + ch], to_fixed(dL_dc));
                     dL_dalpha += (color[ch] - accum_rec[ch]) * grad_pix;
                 }
                 dL_dalpha *= T;
@@ -182,20 +186,12 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
                 const f32 dL_dconic_x = dL_dG * (-0.5f * G * delta.x * delta.x);
                 const f32 dL_dconic_y = dL_dG * (-0.5f * G * 2.0f * delta.x * delta.y);
                 const f32 dL_dconic_z = dL_dG * (-0.5f * G * delta.y * delta.y);
-                const i32 f_op = to_fixed(dL_dopacity), f_mx = to_fixed(dL_dmean_x), f_my = to_fixed(dL_dmean_y);
-                const i32 f_cx = to_fixed(dL_dconic_x), f_cy = to_fixed(dL_dconic_y), f_cz = to_fixed(dL_dconic_z);
-#pragma omp atomic
-                grad_opacity[g] += f_op;
-#pragma omp atomic
-                grad_means_2d[(size_t)g * 2u + 0u] += f_mx;
-#pragma omp atomic
-                grad_means_2d[(size_t)g * 2u + 1u] += f_my;
-#pragma omp atomic
-                grad_conics[(size_t)g * 4u + 0u] += f_cx;
-#pragma omp atomic
-                grad_conics[(size_t)g * 4u + 1u] += f_cy;
-#pragma omp atomic
-                grad_conics[(size_t)g * 4u + 3u] += f_cz;
+                acc_add(&grad_opacity[g], to_fixed(dL_dopacity));
+                acc_add(&grad_means_2d[(size_t)g * 2u + 0u], to_fixed(dL_dmean_x));
+                acc_add(&grad_means_2d[(size_t)g * 2u + 1u], to_fixed(dL_dmean_y));
+                acc_add(&grad_conics[(size_t)g * 4u + 0u], to_fixed(dL_dconic_x));
+                acc_add(&grad_conics[(size_t)g * 4u + 1u], to_fixed(dL_dconic_y));
+                acc_add(&grad_conics[(size_t)g * 4u + 3u], to_fixed(dL_dconic_z));
             }
         }
     }

@@ -34,7 +34,7 @@ static inline f32 bits2f(u32 u) { f32 f; std::memcpy(&f, &u, 4); return f; }
 // ---------------------------------------------------------------- dmath: exp
 // exp(x) = 2^n * P(r), n = rint(x*log2e), r = x - n*ln2 (two-step, FMA),
 // P(r) = 1 + r*(1 + r*(c2 + r*(c3 + r*(c4 + r*(c5 + r*c6))))) by FMA Horner.
-// x < -86 -> +0 (keeps every result normal);  x > 88.5 -> +inf;  NaN -> NaN.
+// x < -86 -> +0 and x > 88 -> +inf, so n is in [-124, 127] and the single multiply by 2^n is exact;  NaN -> NaN.
 static inline f32 wd_exp(f32 x) {
     const f32 LOG2E  = bits2f(0x3FB8AA3Bu);   // 1.44269502
     const f32 LN2_HI = bits2f(0x3F318000u);   // 0.693359375
@@ -43,7 +43,7 @@ static inline f32 wd_exp(f32 x) {
               C5 = bits2f(1007230415u), C6 = bits2f(984890875u);
     if (x != x) return x;
     if (x < -86.0f) return 0.0f;
-    if (x > 88.5f) return INFINITY;
+    if (x > 88.0f) return INFINITY;
     f32 n = std::nearbyintf(x * LOG2E);
     f32 r = std::fmaf(-n, LN2_HI, x);
     r = std::fmaf(-n, LN2_LO, r);
@@ -53,11 +53,8 @@ static inline f32 wd_exp(f32 x) {
     p = std::fmaf(p, r, C2);
     p = std::fmaf(p, r, 1.0f);
     p = std::fmaf(p, r, 1.0f);
-    i32 ni = (i32)n;                       // |n| <= 128
-    // 2^n split in two exact factors so n = 128 does not overflow the exponent field
-    i32 n1 = ni >> 1, n2 = ni - n1;
-    f32 s1 = bits2f((u32)(n1 + 127) << 23), s2 = bits2f((u32)(n2 + 127) << 23);
-    return (p * s1) * s2;
+    i32 ni = (i32)n;                       // -124 <= n <= 127
+    return p * bits2f((u32)(ni + 127) << 23);
 }
 
 // ---------------------------------------------------------------- dmath: log
@@ -177,8 +174,9 @@ static inline f32 length(vec3 a) { return wd_sqrt(dot(a, a)); }
 static inline f32 length(vec4 a) { return wd_sqrt(dot(a, a)); }
 static inline vec3 normalize(vec3 a) { return a / length(a); }
 static inline vec4 normalize(vec4 a) { return a / length(a); }
-static inline f32 wmin(f32 a, f32 b) { return std::fmin(a, b); }
-static inline f32 wmax(f32 a, f32 b) { return std::fmax(a, b); }
+// WGSL spec 17.5: min(e1,e2) = e2 if e2 < e1 else e1;  max(e1,e2) = e2 if e1 < e2 else e1 (pins +-0 ties and NaN).
+static inline f32 wmin(f32 a, f32 b) { return (b < a) ? b : a; }
+static inline f32 wmax(f32 a, f32 b) { return (a < b) ? b : a; }
 static inline f32 clamp(f32 v, f32 lo, f32 hi) { return wmin(wmax(v, lo), hi); }
 static inline vec2 min(vec2 a, vec2 b) { return vec2{wmin(a.x, b.x), wmin(a.y, b.y)}; }
 static inline vec2 max(vec2 a, vec2 b) { return vec2{wmax(a.x, b.x), wmax(a.y, b.y)}; }

@@ -1,0 +1,715 @@
+// C ABI of libwebdgs_hip.so (include/webdgs.h): handle types, ownership, launch sequencing.
+#include <cstdarg>
+#include <cstring>
+#include <algorithm>
+
+#include "common.h"
+
+// ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
+int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*);
+int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*);
+int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
+int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
+int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
+                     void*, void*);
+int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdgs_training_config&, void*);
+int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
+                              void*);
+int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*);
+int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*);
+int launch_adam_repack_f32(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*);
+int launch_accumulate_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
+int launch_unpack(wdgs_device*, u32, const void*, const void*, const wdgs_optimizer_state&);
+int launch_metric_map(wdgs_device*, u32, u32, const void*, const void*, float, float, void*, void*, void*, void*);
+int launch_metric_count(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, u32, const void*, u32, const void*, const void*, void*, u32);
+int launch_metric_normalize(wdgs_device*, u32, u32, void*);
+int launch_downsample(wdgs_device*, const void*, u32, u32, void*, u32, u32);
+
+extern "C" int wdgs_sorter_final_out_index(wdgs_sorter* s);
+extern "C" uint32_t wdgs_sorter_capacity(wdgs_sorter* s);
+
+static thread_local char g_last_error[512] = "";
+
+void wdgs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    WDGS_CHECK_HIP(hipMalloc(p, bytes));
+    if (zero) WDGS_CHECK_HIP(hipMemsetAsync(*p, 0, bytes, stream));
+    return WDGS_OK;
+}
+
+static void free_dev(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+struct wdgs_buffer {
+    void* ptr;
+    size_t size;
+};
+
+struct wdgs_prefix_scanner {
+    wdgs_device* dev;
+    u32 max_elements, count;
+    u32 *input, *output;
+    ScanScratch scratch;
+};
+
+struct wdgs_tiled_forward {
+    wdgs_device* dev;
+    wdgs_tiled_forward_config cfg;
+    RenderSettings settings;
+    TileInfo tile_info;
+    u32* stats;   // {total_tile_entries, visible_gaussians, overflow (0 or requested total), pad}
+    u32* splats;
+    u32* depths;
+    wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
+    wdgs_sorter* sorter;
+    bool encoded;
+};
+
+struct wdgs_tiled_rasterizer {
+    wdgs_device* dev;
+    wdgs_tiled_forward* fwd;
+    u32 compat_caps;
+    u32 width, height;       // allocated image size
+    u32 ranges_capacity;     // tiles + 1
+    u32* ranges;
+    u32* rgba8;
+    float* alpha;
+    u32* n_contrib;
+    bool encoded;
+};
+
+struct wdgs_tiled_backward {
+    wdgs_device* dev;
+    wdgs_tiled_backward_config cfg;
+    RenderSettings settings;
+    int* acc;            // i32[N*12]
+    u32* gradients;      // GaussianGradient[N]
+    float* loss_image;   // rgba32f
+    u32* metric_counts;  // u32[N]
+    u32* metric_err;     // u32[W*H]
+    u32* metric_flags;   // u32[W*H]
+    u32* metric_minmax;  // u32[2] + scratch
+    u32 img_capacity;    // pixels allocated
+};
+
+struct wdgs_optimizer {
+    wdgs_device* dev;
+    u32 num_points;
+    wdgs_adam_hyperparameters params;
+    wdgs_optimizer_state state;
+    bool owns_state;
+    u32 iteration;
+};
+
+extern "C" {
+
+const char* wdgs_last_error(void) { return g_last_error; }
+int wdgs_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------- device
+int wdgs_device_create(int ordinal, void* external_stream, wdgs_device** out) {
+    WDGS_REQUIRE(out, WDGS_E_INVALID, "wdgs_device_create: out is null");
+    int count = 0;
+    WDGS_CHECK_HIP(hipGetDeviceCount(&count));
+    WDGS_REQUIRE(ordinal >= 0 && ordinal < count, WDGS_E_INVALID, "wdgs_device_create: ordinal %d out of range (%d devices)", ordinal, count);
+    WDGS_CHECK_HIP(hipSetDevice(ordinal));
+    wdgs_device* d = new wdgs_device();
+    d->ordinal = ordinal;
+    if (external_stream) {
+        d->stream = (hipStream_t)external_stream;
+        d->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete d; wdgs_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return WDGS_E_HIP; }
+        d->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess) d->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = d;
+    return WDGS_OK;
+}
+
+static int collect_profile(wdgs_device* d) {
+    for (auto& p : d->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto& t = d->totals[p.name];
+            t.launches += 1;
+            t.ms += ms;
+        }
+        d->event_pool.push_back(p.a);
+        d->event_pool.push_back(p.b);
+    }
+    d->pending.clear();
+    return WDGS_OK;
+}
+
+int wdgs_device_synchronize(wdgs_device* d) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_synchronize: null device");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    WDGS_CHECK_HIP(hipStreamSynchronize(d->stream));
+    collect_profile(d);
+    for (wdgs_tiled_forward* f : d->forwards) {
+        if (!f->encoded) continue;
+        u32 st[4];
+        WDGS_CHECK_HIP(hipMemcpy(st, f->stats, sizeof(st), hipMemcpyDeviceToHost));
+        WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)",
+                     st[2], f->tile_info.max_tile_entries);
+    }
+    return WDGS_OK;
+}
+
+int wdgs_device_destroy(wdgs_device* d) {
+    if (!d) return WDGS_OK;
+    (void)hipSetDevice(d->ordinal);
+    (void)hipStreamSynchronize(d->stream);
+    collect_profile(d);
+    for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
+    if (d->own_stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+    return WDGS_OK;
+}
+
+int wdgs_device_set_profiling(wdgs_device* d, int enabled) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
+    d->profiling = enabled != 0;
+    return WDGS_OK;
+}
+
+int wdgs_device_get_kernel_times(wdgs_device* d, wdgs_kernel_time* out, uint32_t cap, uint32_t* count) {
+    WDGS_REQUIRE(d && count, WDGS_E_INVALID, "null argument");
+    u32 i = 0;
+    for (auto& kv : d->totals) {
+        if (out && i < cap) {
+            std::memset(&out[i], 0, sizeof(out[i]));
+            std::strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+            out[i].launches = kv.second.launches;
+            out[i].total_ms = kv.second.ms;
+        }
+        i++;
+    }
+    *count = i;
+    return WDGS_OK;
+}
+
+int wdgs_device_reset_kernel_times(wdgs_device* d) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
+    d->totals.clear();
+    return WDGS_OK;
+}
+
+int wdgs_copy_to_host(wdgs_device* d, void* dst, const void* src, size_t bytes) {
+    WDGS_REQUIRE(d && (bytes == 0 || (dst && src)), WDGS_E_INVALID, "wdgs_copy_to_host: null argument");
+    if (bytes == 0) return WDGS_OK;
+    WDGS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
+    WDGS_CHECK_HIP(hipStreamSynchronize(d->stream));
+    return WDGS_OK;
+}
+
+int wdgs_copy_to_device(wdgs_device* d, void* dst, const void* src, size_t bytes) {
+    WDGS_REQUIRE(d && (bytes == 0 || (dst && src)), WDGS_E_INVALID, "wdgs_copy_to_device: null argument");
+    if (bytes == 0) return WDGS_OK;
+    // pageable source: hipMemcpyAsync stages the copy before returning, so `src` may be reused immediately
+    WDGS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
+    return WDGS_OK;
+}
+
+int wdgs_memset(wdgs_device* d, void* dst, int value, size_t bytes) {
+    WDGS_REQUIRE(d && (bytes == 0 || dst), WDGS_E_INVALID, "wdgs_memset: null argument");
+    if (bytes == 0) return WDGS_OK;
+    WDGS_CHECK_HIP(hipMemsetAsync(dst, value, bytes, d->stream));
+    return WDGS_OK;
+}
+
+// ---------------------------------------------------------------- buffers
+int wdgs_buffer_create(wdgs_device* d, size_t bytes, wdgs_buffer** out) {
+    WDGS_REQUIRE(d && out, WDGS_E_INVALID, "wdgs_buffer_create: null argument");
+    wdgs_buffer* b = new wdgs_buffer{nullptr, bytes};
+    int r = wdgs_alloc(&b->ptr, bytes, true, d->stream);
+    if (r != WDGS_OK) { delete b; return r; }
+    *out = b;
+    return WDGS_OK;
+}
+int wdgs_buffer_destroy(wdgs_buffer* b) {
+    if (!b) return WDGS_OK;
+    free_dev(b->ptr);
+    delete b;
+    return WDGS_OK;
+}
+void* wdgs_buffer_ptr(const wdgs_buffer* b) { return b ? b->ptr : nullptr; }
+size_t wdgs_buffer_size(const wdgs_buffer* b) { return b ? b->size : 0; }
+int wdgs_buffer_write(wdgs_device* d, wdgs_buffer* b, size_t off, const void* src, size_t bytes) {
+    WDGS_REQUIRE(d && b, WDGS_E_INVALID, "wdgs_buffer_write: null argument");
+    WDGS_REQUIRE(off + bytes <= b->size, WDGS_E_INVALID, "wdgs_buffer_write: range [%zu, %zu) exceeds buffer size %zu", off, off + bytes, b->size);
+    return wdgs_copy_to_device(d, (char*)b->ptr + off, src, bytes);
+}
+int wdgs_buffer_read(wdgs_device* d, const wdgs_buffer* b, size_t off, void* dst, size_t bytes) {
+    WDGS_REQUIRE(d && b, WDGS_E_INVALID, "wdgs_buffer_read: null argument");
+    WDGS_REQUIRE(off + bytes <= b->size, WDGS_E_INVALID, "wdgs_buffer_read: range [%zu, %zu) exceeds buffer size %zu", off, off + bytes, b->size);
+    return wdgs_copy_to_host(d, dst, (const char*)b->ptr + off, bytes);
+}
+
+// ---------------------------------------------------------------- prefix scanner
+int wdgs_prefix_scanner_create(wdgs_device* d, uint32_t max_elements, wdgs_prefix_scanner** out) {
+    WDGS_REQUIRE(d && out, WDGS_E_INVALID, "wdgs_prefix_scanner_create: null argument");
+    wdgs_prefix_scanner* s = new wdgs_prefix_scanner();
+    s->dev = d;
+    s->max_elements = max_elements > 0 ? max_elements : 1;
+    s->count = s->max_elements;
+    s->input = s->output = nullptr;
+    int r = wdgs_alloc((void**)&s->input, sizeof(u32) * (size_t)s->max_elements, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&s->output, sizeof(u32) * (size_t)s->max_elements, true, d->stream);
+    if (r == WDGS_OK) r = scan_scratch_create(&s->scratch, s->max_elements);
+    if (r != WDGS_OK) { wdgs_prefix_scanner_destroy(s); return r; }
+    *out = s;
+    return WDGS_OK;
+}
+int wdgs_prefix_scanner_destroy(wdgs_prefix_scanner* s) {
+    if (!s) return WDGS_OK;
+    free_dev(s->input);
+    free_dev(s->output);
+    scan_scratch_destroy(&s->scratch);
+    delete s;
+    return WDGS_OK;
+}
+void* wdgs_prefix_scanner_input(wdgs_prefix_scanner* s) { return s ? s->input : nullptr; }
+void* wdgs_prefix_scanner_output(wdgs_prefix_scanner* s) { return s ? s->output : nullptr; }
+int wdgs_prefix_scanner_set_count(wdgs_prefix_scanner* s, uint32_t count) {
+    WDGS_REQUIRE(s, WDGS_E_INVALID, "null scanner");
+    WDGS_REQUIRE(count <= s->max_elements, WDGS_E_CAPACITY, "scan count %u exceeds max_elements %u", count, s->max_elements);
+    s->count = count;
+    return WDGS_OK;
+}
+int wdgs_prefix_scanner_scan(wdgs_prefix_scanner* s) {
+    WDGS_REQUIRE(s, WDGS_E_INVALID, "null scanner");
+    return scan_exclusive_u32(s->dev, &s->scratch, s->input, s->output, s->count, nullptr);
+}
+int wdgs_prefix_scanner_scan_ptr(wdgs_prefix_scanner* s, const void* in, void* out, uint32_t count) {
+    WDGS_REQUIRE(s && in && out, WDGS_E_INVALID, "null argument");
+    WDGS_REQUIRE(count <= s->max_elements, WDGS_E_CAPACITY, "scan count %u exceeds max_elements %u", count, s->max_elements);
+    return scan_exclusive_u32(s->dev, &s->scratch, (const u32*)in, (u32*)out, count, nullptr);
+}
+
+// ---------------------------------------------------------------- TiledForwardPass
+static void forward_set_viewport(wdgs_tiled_forward* op, u32 w, u32 h) {
+    op->cfg.viewport_width = w;
+    op->cfg.viewport_height = h;
+    op->settings.viewport_x = (float)w;
+    op->settings.viewport_y = (float)h;
+    op->tile_info.num_tiles_x = ceil_div(w, 16);
+    op->tile_info.num_tiles_y = ceil_div(h, 16);
+    op->tile_info.total_tiles = op->tile_info.num_tiles_x * op->tile_info.num_tiles_y;
+}
+
+int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* cfg, wdgs_tiled_forward** out) {
+    WDGS_REQUIRE(d && cfg && out, WDGS_E_INVALID, "wdgs_tiled_forward_create: null argument");
+    WDGS_REQUIRE(cfg->viewport_width > 0 && cfg->viewport_height > 0, WDGS_E_INVALID, "viewport must be non-empty");
+    WDGS_REQUIRE(cfg->sh_deg <= 3, WDGS_E_INVALID, "sh_deg %u > 3", cfg->sh_deg);
+    // the sort key keeps tile_id + 1 in 16 bits (tiled-forward.wgsl:121-136)
+    const uint64_t tiles = (uint64_t)ceil_div(cfg->viewport_width, 16) * ceil_div(cfg->viewport_height, 16);
+    WDGS_REQUIRE(tiles + 1 <= 0xFFFFu, WDGS_E_CAPACITY, "%llu tiles do not fit the 16-bit tile field of the sort key", (unsigned long long)tiles);
+    wdgs_tiled_forward* op = new wdgs_tiled_forward();
+    op->dev = d;
+    op->cfg = *cfg;
+    op->stats = op->splats = op->depths = nullptr;
+    op->scanner = nullptr;
+    op->sorter = nullptr;
+    op->encoded = false;
+    const u32 n = cfg->num_points;
+    uint64_t cap;
+    if (cfg->compat_caps) {  // tiled-forward-pass.ts:137-154
+        uint64_t base = std::min<uint64_t>((uint64_t)n * 30, (uint64_t)n * 2048);
+        cap = std::min<uint64_t>(std::min<uint64_t>(base, 32ull * 1024 * 1024), 2097152ull);
+        cap = (cap + 3839) / 3840 * 3840;
+    } else if (cfg->max_tile_entries) {
+        cap = cfg->max_tile_entries;
+    } else {
+        cap = std::max<uint64_t>((uint64_t)n * 30, 1ull << 20);
+    }
+    cap = std::min<uint64_t>(align_up(cap, 4096), 0xFFFFF000ull);
+    op->settings = RenderSettings{cfg->gaussian_scale != 0.f ? cfg->gaussian_scale : 1.0f, (float)cfg->sh_deg, 0.f, 0.f,
+                                  cfg->point_size_px != 0.f ? cfg->point_size_px : 3.0f, cfg->render_mode ? 1.0f : 0.0f,
+                                  cfg->max_splat_radius_px != 0.f ? cfg->max_splat_radius_px : 128.0f};
+    op->tile_info.max_tile_entries = (u32)cap;
+    forward_set_viewport(op, cfg->viewport_width, cfg->viewport_height);
+    int r = wdgs_alloc((void**)&op->stats, 16, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->splats, (size_t)24 * std::max(n, 1u), true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * std::max(n, 1u), true, d->stream);
+    if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, std::max(n, 1u), &op->scanner);
+    if (r == WDGS_OK) r = wdgs_sorter_create(d, (u32)cap, op->stats, &op->sorter);
+    if (r != WDGS_OK) { wdgs_tiled_forward_destroy(op); return r; }
+    d->forwards.push_back(op);
+    *out = op;
+    return WDGS_OK;
+}
+
+int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
+    if (!op) return WDGS_OK;
+    auto& v = op->dev->forwards;
+    v.erase(std::remove(v.begin(), v.end(), op), v.end());
+    (void)hipStreamSynchronize(op->dev->stream);
+    free_dev(op->stats);
+    free_dev(op->splats);
+    free_dev(op->depths);
+    wdgs_prefix_scanner_destroy(op->scanner);
+    wdgs_sorter_destroy(op->sorter);
+    delete op;
+    return WDGS_OK;
+}
+
+static u32 bits_for(u32 v) {  // number of bits needed to represent v
+    u32 b = 0;
+    while (v) { b++; v >>= 1; }
+    return b;
+}
+
+int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, const void* sh, const void* camera, int skip_sort) {
+    WDGS_REQUIRE(op && gaussians && sh && camera, WDGS_E_INVALID, "wdgs_tiled_forward_encode: null argument");
+    wdgs_device* d = op->dev;
+    const u32 n = op->cfg.num_points;
+    WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16, d->stream));  // clearBuffer(pipelineStatsBuffer), tiled-forward-pass.ts:345
+    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats));
+    WDGS_TRY(scan_exclusive_u32(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr));
+    WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats));
+    WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->settings, op->tile_info, wdgs_sorter_keys(op->sorter, 0),
+                         wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
+    if (!skip_sort) {
+        // key = (tile_id + 1) << 16 | depth16: only 16 + bits(total_tiles) bits are ever set
+        WDGS_TRY(wdgs_sorter_sort(op->sorter, op->cfg.compat_caps ? 32u : 16u + bits_for(op->tile_info.total_tiles)));
+    }
+    op->encoded = true;
+    return WDGS_OK;
+}
+
+int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t h) {
+    WDGS_REQUIRE(op && w > 0 && h > 0, WDGS_E_INVALID, "wdgs_tiled_forward_set_viewport: invalid argument");
+    WDGS_REQUIRE((uint64_t)ceil_div(w, 16) * ceil_div(h, 16) + 1 <= 0xFFFFu, WDGS_E_CAPACITY, "viewport %ux%u has too many tiles for the 16-bit tile field", w, h);
+    forward_set_viewport(op, w, h);
+    return WDGS_OK;
+}
+int wdgs_tiled_forward_set_render_mode(wdgs_tiled_forward* op, uint32_t mode) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    op->cfg.render_mode = mode;
+    op->settings.gaussian_mode = mode ? 1.0f : 0.0f;
+    return WDGS_OK;
+}
+int wdgs_tiled_forward_set_point_size(wdgs_tiled_forward* op, float v) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    op->settings.point_size_px = v;
+    return WDGS_OK;
+}
+int wdgs_tiled_forward_set_gaussian_scale(wdgs_tiled_forward* op, float v) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    op->settings.gaussian_scaling = v;
+    return WDGS_OK;
+}
+
+int wdgs_tiled_forward_get_resources(wdgs_tiled_forward* op, wdgs_tiled_forward_resources* out) {
+    WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    const int fo = wdgs_sorter_final_out_index(op->sorter);
+    out->splat_buffer = op->splats;
+    out->depths_buffer = op->depths;
+    out->tile_keys_buffer = wdgs_sorter_keys(op->sorter, fo);
+    out->tile_indices_buffer = wdgs_sorter_values(op->sorter, fo);
+    out->tile_offsets_buffer = op->scanner->output;
+    out->tile_counts_buffer = op->scanner->input;
+    out->stats_buffer = op->stats;
+    out->num_tiles_x = op->tile_info.num_tiles_x;
+    out->num_tiles_y = op->tile_info.num_tiles_y;
+    out->total_tiles = op->tile_info.total_tiles;
+    out->max_tile_entries = op->tile_info.max_tile_entries;
+    std::memcpy(out->settings, &op->settings, sizeof(float) * 7);
+    return WDGS_OK;
+}
+
+int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    u32 st[4];
+    WDGS_TRY(wdgs_copy_to_host(op->dev, st, op->stats, sizeof(st)));
+    if (stats_out) std::memcpy(stats_out, st, sizeof(st));
+    WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u", st[2], op->tile_info.max_tile_entries);
+    return WDGS_OK;
+}
+
+// ---------------------------------------------------------------- TiledRasterizer
+int wdgs_tiled_rasterizer_create(wdgs_device* d, wdgs_tiled_forward* fwd, uint32_t compat_caps, wdgs_tiled_rasterizer** out) {
+    WDGS_REQUIRE(d && fwd && out, WDGS_E_INVALID, "wdgs_tiled_rasterizer_create: null argument");
+    wdgs_tiled_rasterizer* op = new wdgs_tiled_rasterizer();
+    std::memset(op, 0, sizeof(*op));
+    op->dev = d;
+    op->fwd = fwd;
+    op->compat_caps = compat_caps;
+    *out = op;
+    return WDGS_OK;
+}
+int wdgs_tiled_rasterizer_destroy(wdgs_tiled_rasterizer* op) {
+    if (!op) return WDGS_OK;
+    (void)hipStreamSynchronize(op->dev->stream);
+    free_dev(op->ranges);
+    free_dev(op->rgba8);
+    free_dev(op->alpha);
+    free_dev(op->n_contrib);
+    delete op;
+    return WDGS_OK;
+}
+int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint32_t height) {
+    WDGS_REQUIRE(op && width > 0 && height > 0, WDGS_E_INVALID, "wdgs_tiled_rasterizer_encode: invalid argument");
+    wdgs_tiled_forward* f = op->fwd;
+    WDGS_REQUIRE(f->encoded, WDGS_E_STATE, "rasterizer encode before the forward pass was encoded");
+    WDGS_REQUIRE(width == f->cfg.viewport_width && height == f->cfg.viewport_height, WDGS_E_STATE,
+                 "rasterizer size %ux%u differs from the forward pass viewport %ux%u", width, height, f->cfg.viewport_width, f->cfg.viewport_height);
+    wdgs_device* d = op->dev;
+    const TileInfo& ti = f->tile_info;
+    if (width != op->width || height != op->height) {  // ensureTextures (tiled-rasterizer.ts:244-306)
+        (void)hipStreamSynchronize(d->stream);
+        free_dev(op->rgba8); free_dev(op->alpha); free_dev(op->n_contrib);
+        op->rgba8 = nullptr; op->alpha = nullptr; op->n_contrib = nullptr;
+        const size_t px = (size_t)width * height;
+        WDGS_TRY(wdgs_alloc((void**)&op->rgba8, px * 4, true, d->stream));
+        WDGS_TRY(wdgs_alloc((void**)&op->alpha, px * 4, true, d->stream));
+        WDGS_TRY(wdgs_alloc((void**)&op->n_contrib, px * 4, true, d->stream));
+        op->width = width;
+        op->height = height;
+    }
+    if (ti.total_tiles + 1 > op->ranges_capacity) {
+        (void)hipStreamSynchronize(d->stream);
+        free_dev(op->ranges);
+        op->ranges = nullptr;
+        WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(ti.total_tiles + 1), true, d->stream));
+        op->ranges_capacity = ti.total_tiles + 1;
+    }
+    const int fo = wdgs_sorter_final_out_index(f->sorter);
+    const void* keys = wdgs_sorter_keys(f->sorter, fo);
+    const void* vals = wdgs_sorter_values(f->sorter, fo);
+    WDGS_TRY(launch_tile_ranges(d, keys, f->stats, ti.total_tiles, op->ranges));
+    WDGS_TRY(launch_rasterize(d, f->settings, ti, f->splats, f->cfg.num_points, op->ranges, keys, vals, f->stats, op->compat_caps ? 32u : 0u, op->rgba8,
+                              op->alpha, op->n_contrib));
+    op->encoded = true;
+    return WDGS_OK;
+}
+#define RASTER_GETTER(fn, field, what)                                                                            \
+    int fn(wdgs_tiled_rasterizer* op, void** out) {                                                               \
+        WDGS_REQUIRE(op && out, WDGS_E_INVALID, #fn ": null argument");                                           \
+        WDGS_REQUIRE(op->encoded && op->field, WDGS_E_STATE, "TiledRasterizer: " what " not created yet (call encode first)"); \
+        *out = op->field;                                                                                         \
+        return WDGS_OK;                                                                                           \
+    }
+RASTER_GETTER(wdgs_tiled_rasterizer_get_output, rgba8, "output texture")
+RASTER_GETTER(wdgs_tiled_rasterizer_get_alpha, alpha, "alpha texture")
+RASTER_GETTER(wdgs_tiled_rasterizer_get_n_contrib, n_contrib, "n_contrib texture")
+RASTER_GETTER(wdgs_tiled_rasterizer_get_tile_offsets, ranges, "tile offsets")
+#undef RASTER_GETTER
+
+// ---------------------------------------------------------------- TiledBackwardPass
+static int backward_alloc_images(wdgs_tiled_backward* op, u32 w, u32 h) {
+    const u32 px = w * h;
+    if (px <= op->img_capacity) return WDGS_OK;
+    (void)hipStreamSynchronize(op->dev->stream);
+    free_dev(op->loss_image); free_dev(op->metric_err); free_dev(op->metric_flags);
+    op->loss_image = nullptr; op->metric_err = nullptr; op->metric_flags = nullptr;
+    WDGS_TRY(wdgs_alloc((void**)&op->loss_image, (size_t)px * 16, true, op->dev->stream));
+    WDGS_TRY(wdgs_alloc((void**)&op->metric_err, (size_t)px * 4, true, op->dev->stream));
+    WDGS_TRY(wdgs_alloc((void**)&op->metric_flags, (size_t)px * 4, true, op->dev->stream));
+    op->img_capacity = px;
+    return WDGS_OK;
+}
+
+int wdgs_tiled_backward_create(wdgs_device* d, const wdgs_tiled_backward_config* cfg, wdgs_tiled_backward** out) {
+    WDGS_REQUIRE(d && cfg && out, WDGS_E_INVALID, "wdgs_tiled_backward_create: null argument");
+    WDGS_REQUIRE(cfg->viewport_width > 0 && cfg->viewport_height > 0, WDGS_E_INVALID, "viewport must be non-empty");
+    wdgs_tiled_backward* op = new wdgs_tiled_backward();
+    std::memset(op, 0, sizeof(*op));
+    op->dev = d;
+    op->cfg = *cfg;
+    if (op->cfg.training.c1 == 0.f) op->cfg.training.c1 = 0.01f * 0.01f;  // tiled-backward-pass.ts:172-173
+    if (op->cfg.training.c2 == 0.f) op->cfg.training.c2 = 0.03f * 0.03f;
+    op->settings = RenderSettings{cfg->gaussian_scale != 0.f ? cfg->gaussian_scale : 1.0f, (float)cfg->sh_deg, (float)cfg->viewport_width,
+                                  (float)cfg->viewport_height, cfg->point_size_px != 0.f ? cfg->point_size_px : 3.0f, 0.0f,
+                                  cfg->max_splat_radius_px != 0.f ? cfg->max_splat_radius_px : 128.0f};
+    const size_t n = std::max(cfg->num_points, 1u);
+    int r = wdgs_alloc((void**)&op->acc, n * 48, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->gradients, n * 32, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->metric_counts, n * 4, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->metric_minmax, 4096, true, d->stream);
+    if (r == WDGS_OK) r = backward_alloc_images(op, cfg->viewport_width, cfg->viewport_height);
+    if (r != WDGS_OK) { wdgs_tiled_backward_destroy(op); return r; }
+    *out = op;
+    return WDGS_OK;
+}
+int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op) {
+    if (!op) return WDGS_OK;
+    (void)hipStreamSynchronize(op->dev->stream);
+    free_dev(op->acc); free_dev(op->gradients); free_dev(op->loss_image); free_dev(op->metric_counts);
+    free_dev(op->metric_err); free_dev(op->metric_flags); free_dev(op->metric_minmax);
+    delete op;
+    return WDGS_OK;
+}
+int wdgs_tiled_backward_compute_loss_only(wdgs_tiled_backward* op, const void* pred, const void* targ) {
+    WDGS_REQUIRE(op && pred && targ, WDGS_E_INVALID, "wdgs_tiled_backward_compute_loss_only: null argument");
+    return launch_loss_grad(op->dev, op->cfg.viewport_width, op->cfg.viewport_height, pred, targ, op->cfg.training, op->loss_image);
+}
+int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res,
+                               const void* gaussians) {
+    WDGS_REQUIRE(op && pred && targ && res && gaussians, WDGS_E_INVALID, "wdgs_tiled_backward_encode: null argument");
+    WDGS_REQUIRE(res->splat_buffer && res->tile_offsets_buffer && res->tile_indices_buffer && res->camera_buffer && res->alpha_texture && res->n_contrib_texture,
+                 WDGS_E_INVALID, "wdgs_tiled_backward_encode: incomplete resources");
+    wdgs_device* d = op->dev;
+    const u32 w = op->cfg.viewport_width, h = op->cfg.viewport_height, n = op->cfg.num_points;
+    WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image));
+    WDGS_CHECK_HIP(hipMemsetAsync(op->acc, 0, (size_t)std::max(n, 1u) * 48, d->stream));  // clearBuffer x4, tiled-backward-pass.ts:624-627
+    WDGS_TRY(launch_backward_rasterize(d, op->settings, ceil_div(w, 16), ceil_div(h, 16), res->tile_offsets_buffer, res->tile_indices_buffer, res->splat_buffer,
+                                       res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc));
+    WDGS_TRY(launch_geometry_backward(d, n, res->camera_buffer, op->settings, gaussians, op->acc, op->gradients));
+    return WDGS_OK;
+}
+int wdgs_tiled_backward_compute_metric_map(wdgs_tiled_backward* op, const void* pred, const void* targ, float threshold) {
+    WDGS_REQUIRE(op && pred && targ, WDGS_E_INVALID, "wdgs_tiled_backward_compute_metric_map: null argument");
+    return launch_metric_map(op->dev, op->cfg.viewport_width, op->cfg.viewport_height, pred, targ, 1000000.0f, threshold, op->metric_err, op->metric_minmax,
+                             op->metric_minmax + 2, op->metric_flags);
+}
+int wdgs_tiled_backward_compute_metric_counts(wdgs_tiled_backward* op, const wdgs_tiled_backward_resources* res, uint32_t num_instances, int clear) {
+    WDGS_REQUIRE(op && res && res->splat_buffer && res->tile_offsets_buffer && res->tile_indices_buffer && res->n_contrib_texture, WDGS_E_INVALID,
+                 "wdgs_tiled_backward_compute_metric_counts: incomplete resources");
+    const u32 n = op->cfg.num_points;
+    if (clear) WDGS_CHECK_HIP(hipMemsetAsync(op->metric_counts, 0, (size_t)std::max(n, 1u) * 4, op->dev->stream));
+    return launch_metric_count(op->dev, op->settings, ceil_div(op->cfg.viewport_width, 16), ceil_div(op->cfg.viewport_height, 16), res->tile_offsets_buffer,
+                               res->tile_indices_buffer, num_instances, res->splat_buffer, n, op->metric_flags, res->n_contrib_texture, op->metric_counts, n);
+}
+int wdgs_tiled_backward_normalize_metric_counts(wdgs_tiled_backward* op, uint32_t divisor) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    return launch_metric_normalize(op->dev, op->cfg.num_points, divisor, op->metric_counts);
+}
+int wdgs_tiled_backward_set_viewport(wdgs_tiled_backward* op, uint32_t w, uint32_t h) {
+    WDGS_REQUIRE(op && w > 0 && h > 0, WDGS_E_INVALID, "wdgs_tiled_backward_set_viewport: invalid argument");
+    op->cfg.viewport_width = w;
+    op->cfg.viewport_height = h;
+    op->settings.viewport_x = (float)w;
+    op->settings.viewport_y = (float)h;
+    return backward_alloc_images(op, w, h);
+}
+int wdgs_tiled_backward_set_training_config(wdgs_tiled_backward* op, const wdgs_training_config* cfg) {
+    WDGS_REQUIRE(op && cfg, WDGS_E_INVALID, "null argument");
+    op->cfg.training = *cfg;
+    if (op->cfg.training.c1 == 0.f) op->cfg.training.c1 = 0.01f * 0.01f;
+    if (op->cfg.training.c2 == 0.f) op->cfg.training.c2 = 0.03f * 0.03f;
+    return WDGS_OK;
+}
+void* wdgs_tiled_backward_gradients(wdgs_tiled_backward* op) { return op ? op->gradients : nullptr; }
+void* wdgs_tiled_backward_metric_counts(wdgs_tiled_backward* op) { return op ? op->metric_counts : nullptr; }
+void* wdgs_tiled_backward_loss_image(wdgs_tiled_backward* op) { return op ? op->loss_image : nullptr; }
+void* wdgs_tiled_backward_metric_map(wdgs_tiled_backward* op) { return op ? op->metric_flags : nullptr; }
+void* wdgs_tiled_backward_accumulators(wdgs_tiled_backward* op) { return op ? op->acc : nullptr; }
+void* wdgs_tiled_backward_metric_minmax(wdgs_tiled_backward* op) { return op ? op->metric_minmax : nullptr; }
+
+int wdgs_downsample_rgba8(wdgs_device* d, const void* src, uint32_t sw, uint32_t sh, void* dst, uint32_t dw, uint32_t dh) {
+    WDGS_REQUIRE(d && src && dst && sw && sh && dw && dh, WDGS_E_INVALID, "wdgs_downsample_rgba8: invalid argument");
+    return launch_downsample(d, src, sw, sh, dst, dw, dh);
+}
+
+// ---------------------------------------------------------------- Optimizer
+int wdgs_optimizer_state_sizes(uint32_t n, size_t sizes[6]) {
+    WDGS_REQUIRE(sizes, WDGS_E_INVALID, "null argument");
+    const size_t N = std::max(n, 1u);  // allocateOptimizerStateBuffers: Math.max(1, ...) (optimizer.ts:28)
+    sizes[0] = sizes[1] = sizes[2] = N * 48;
+    sizes[3] = N * 12;
+    sizes[4] = N * 48 * 4;
+    sizes[5] = N * 48 * 2 * 4;
+    return WDGS_OK;
+}
+
+static void optimizer_free_state(wdgs_optimizer* op) {
+    free_dev(op->state.opt_pos); free_dev(op->state.opt_rot); free_dev(op->state.opt_scale);
+    free_dev(op->state.opt_opacity); free_dev(op->state.param_sh); free_dev(op->state.state_sh);
+    std::memset(&op->state, 0, sizeof(op->state));
+}
+
+int wdgs_optimizer_create(wdgs_device* d, uint32_t n, const wdgs_adam_hyperparameters* params, const void* gaussians, const void* sh,
+                          const wdgs_optimizer_state* initial, int owns_state, uint32_t initial_iteration, wdgs_optimizer** out) {
+    WDGS_REQUIRE(d && out, WDGS_E_INVALID, "wdgs_optimizer_create: null argument");
+    wdgs_optimizer* op = new wdgs_optimizer();
+    std::memset(op, 0, sizeof(*op));
+    op->dev = d;
+    op->num_points = n;
+    const wdgs_adam_hyperparameters defaults = {0.00016f, 0.0025f, 0.05f, 0.005f, 0.001f, 0.9f, 0.999f, 1e-8f};  // adam-config.ts:12-21
+    op->params = params ? *params : defaults;
+    if (initial) {
+        WDGS_REQUIRE(initial->opt_pos && initial->opt_rot && initial->opt_scale && initial->opt_opacity && initial->param_sh && initial->state_sh,
+                     WDGS_E_INVALID, "wdgs_optimizer_create: incomplete initial state");
+        op->state = *initial;
+        op->owns_state = owns_state != 0;
+        op->iteration = initial_iteration;
+    } else {
+        if (!(gaussians && sh)) { delete op; wdgs_set_error("wdgs_optimizer_create: point cloud required when no initial state is given"); return WDGS_E_INVALID; }
+        size_t sz[6];
+        wdgs_optimizer_state_sizes(n, sz);
+        void** fields[6] = {&op->state.opt_pos, &op->state.opt_rot, &op->state.opt_scale, &op->state.opt_opacity, &op->state.param_sh, &op->state.state_sh};
+        op->owns_state = true;
+        for (int i = 0; i < 6; i++) {
+            int r = wdgs_alloc(fields[i], sz[i], true, d->stream);
+            if (r != WDGS_OK) { optimizer_free_state(op); delete op; return r; }
+        }
+        int r = launch_unpack(d, n, gaussians, sh, op->state);
+        if (r != WDGS_OK) { optimizer_free_state(op); delete op; return r; }
+        op->iteration = 0;
+    }
+    *out = op;
+    return WDGS_OK;
+}
+int wdgs_optimizer_destroy(wdgs_optimizer* op) {
+    if (!op) return WDGS_OK;
+    (void)hipStreamSynchronize(op->dev->stream);
+    if (op->owns_state) optimizer_free_state(op);
+    delete op;
+    return WDGS_OK;
+}
+int wdgs_optimizer_init_from_point_cloud(wdgs_optimizer* op, const void* gaussians, const void* sh) {
+    WDGS_REQUIRE(op && gaussians && sh, WDGS_E_INVALID, "wdgs_optimizer_init_from_point_cloud: null argument");
+    return launch_unpack(op->dev, op->num_points, gaussians, sh, op->state);
+}
+int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const void* gradients, const void* tile_counts) {
+    WDGS_REQUIRE(op && gaussians && sh && gradients && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step: null argument");
+    op->iteration++;  // optimizer.ts:301
+    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, gaussians, sh);
+}
+int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
+    WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");
+    op->iteration++;
+    return launch_adam_repack_f32(op->dev, op->num_points, op->params, visible, grad_f32, op->state, gaussians, sh);
+}
+int wdgs_accumulate_gradients(wdgs_device* d, uint32_t n, const void* gradients, const void* tile_counts, void* acc, void* visible) {
+    WDGS_REQUIRE(d && gradients && tile_counts && acc && visible, WDGS_E_INVALID, "wdgs_accumulate_gradients: null argument");
+    return launch_accumulate_gradients(d, n, gradients, tile_counts, acc, visible);
+}
+uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op) { return op ? op->iteration : 0; }
+int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out) {
+    WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    *out = op->params;
+    return WDGS_OK;
+}
+int wdgs_optimizer_set_hyperparameters(wdgs_optimizer* op, const wdgs_adam_hyperparameters* p) {
+    WDGS_REQUIRE(op && p, WDGS_E_INVALID, "null argument");
+    op->params = *p;
+    return WDGS_OK;
+}
+int wdgs_optimizer_get_state(wdgs_optimizer* op, wdgs_optimizer_state* out) {
+    WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    *out = op->state;
+    return WDGS_OK;
+}
+int wdgs_optimizer_release_state(wdgs_optimizer* op, wdgs_optimizer_state* out) {
+    WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    *out = op->state;
+    op->owns_state = false;
+    return WDGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+// Backward rasterization (K16) and per-Gaussian geometry backward (K17).
+//
+// K16 replaces backward_rasterize_main (src/shaders/tiled-backward-rasterize.wgsl:34-172): per pixel, back to front
+// over its first n_contrib tile entries, with every lane re-loading the splat from global memory and issuing 9 global
+// fixed-point atomics per contributing (pixel, splat) pair -- the reference's dominant cost.  Here one workgroup
+// walks a tile: splats are staged in LDS once per 256-entry batch, each wave owns an 8x8 pixel block and skips
+// splats none of its pixels touches, and the 9 per-pixel contributions are summed across the wave in registers
+// (DPP row reduce + readlane) before ONE 36-byte atomic per (wave, splat).  The contributions keep the reference's
+// semantics exactly: each is truncated to i32 at x1e6 per pixel (common.wgsl:113-116), and integer addition is
+// order-free, so the result is bit-reproducible and equal to the oracle's.
+// Bound: fp32 VALU issue (exp, one IEEE division, about 45 further lane-ops per contributing pair).
+//
+// K17 replaces main_geometry_backward (src/shaders/tiled-backward.wgsl:41-298): N-wide, HBM-bound
+// (24 B Gaussian + 48 B accumulators in, 32 B packed gradient out).
+#include "common.h"
+#include "wgslm.h"
+
+namespace {
+
+constexpr u32 BATCH = 256;
+constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity, rgb, 3 pad
+
+WD_DEV int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }       // quad_perm [1,0,3,2]
+WD_DEV int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }       // quad_perm [2,3,0,1]
+WD_DEV int dpp_half_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); }
+WD_DEV int dpp_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); }
+
+// Sum of v over the 64 lanes, returned wave-uniform (wrapping i32 arithmetic).
+WD_DEV int wave_sum(int v) {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);  // every lane of a 16-lane row now holds the row sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+WD_DEV int to_fixed(float v) {
+    // i32(v * 1e6): truncate toward zero, saturate, NaN -> 0 -- exactly v_cvt_i32_f32.
+    const float s = v * 1000000.0f;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(s));
+    return r;
+}
+WD_DEV float from_fixed(int v) { return wd_div((float)v, 1000000.0f); }
+
+__global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
+                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
+                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
+                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc) {
+    __shared__ float4 s_geo[BATCH];  // centre.x, centre.y, extent.x, extent.y
+    __shared__ float4 s_con[BATCH];  // conic.x, conic.y, conic.z, opacity
+    __shared__ float4 s_col[BATCH];  // r, g, b, gaussian index (bits)
+    __shared__ u32 s_max[4];
+
+    const u32 tile_id = blockIdx.x;
+    const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    const u32 pixel_x = tile_x * 16u + lx, pixel_y = tile_y * 16u + ly;
+    const float vx = settings.viewport_x, vy = settings.viewport_y;
+    const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
+    const bool in_bounds = pixel_x < W && pixel_y < H;
+    const size_t p = (size_t)pixel_y * W + pixel_x;
+    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+
+    const u32 range_start = ranges[tile_id];
+    const u32 range_end = ranges[tile_id + 1u];
+    const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
+    const u32 n_val = in_bounds ? n_contrib[p] : 0u;
+    const u32 pix_n = min(n_val, tile_entries);
+
+    // wave / block maxima of pix_n (uniform)
+    u32 wmax = pix_n;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
+    if (lane == 0) s_max[wave] = wmax;
+    __syncthreads();
+    const u32 block_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (block_max == 0u) return;
+
+    float T = 0.0f;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix_n > 0u) { T = final_T[p]; g = loss_grad[p]; }
+    const float pxf = (float)pixel_x + 0.5f, pyf = (float)pixel_y + 0.5f;
+    float ar_r = 0.f, ar_g = 0.f, ar_b = 0.f, lc_r = 0.f, lc_g = 0.f, lc_b = 0.f, la = 0.f;
+
+    for (u32 hi = block_max; hi > 0u;) {
+        const u32 lo = (hi > BATCH) ? hi - BATCH : 0u;
+        const u32 cnt = hi - lo;
+        if (threadIdx.x < cnt) {
+            const u32 gidx = instances[range_start + lo + threadIdx.x];
+            const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)gidx * 6);
+            const uint2 w01 = sp[0], w23 = sp[1], w45 = sp[2];
+            const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
+            const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
+            s_geo[threadIdx.x] = make_float4(cx, cy, fminf(wd_unpack_lo(w01.y), cap), fminf(wd_unpack_hi(w01.y), cap));
+            s_con[threadIdx.x] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+            s_col[threadIdx.x] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx));
+        }
+        __syncthreads();
+        if (wmax > lo) {
+            const u32 top = min(cnt, wmax - lo);
+            for (u32 i = top; i-- > 0u;) {
+                const float4 geo = s_geo[i];
+                const float dx = pxf - geo.x, dy = pyf - geo.y;
+                const bool cand = (lo + i < pix_n) && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
+                if (!__any(cand)) continue;
+                const float4 con = s_con[i];
+                const float t1 = __builtin_fmaf(con.x, dx, (2.0f * con.y) * dy);
+                const float power = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
+                const float G = wd_exp(-0.5f * power);
+                const float og = con.w * G;
+                const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
+                const bool act = cand && !(alpha < (1.0f / 255.0f));
+                if (!__any(act)) continue;
+                const float4 col = s_col[i];
+                int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
+                if (act) {
+                    T = wd_div(T, 1.0f - alpha);
+                    ar_r = la * lc_r + (1.0f - la) * ar_r;
+                    ar_g = la * lc_g + (1.0f - la) * ar_g;
+                    ar_b = la * lc_b + (1.0f - la) * ar_b;
+                    const float aT = alpha * T;
+                    f_r = to_fixed(aT * g.x);
+                    f_g = to_fixed(aT * g.y);
+                    f_b = to_fixed(aT * g.z);
+                    float dL_dalpha = 0.0f;
+                    dL_dalpha += (col.x - ar_r) * g.x;
+                    dL_dalpha += (col.y - ar_g) * g.y;
+                    dL_dalpha += (col.z - ar_b) * g.z;
+                    dL_dalpha *= T;
+                    la = alpha; lc_r = col.x; lc_g = col.y; lc_b = col.z;
+                    const float dL_dG = con.w * dL_dalpha;
+                    f_op = to_fixed(G * dL_dalpha);
+                    const float dpow_dx = 2.0f * con.x * dx + 2.0f * con.y * dy;
+                    const float dpow_dy = 2.0f * con.z * dy + 2.0f * con.y * dx;
+                    const float mhG = -0.5f * G;
+                    const float dG_ddx = mhG * dpow_dx, dG_ddy = mhG * dpow_dy;
+                    f_mx = to_fixed(dL_dG * (-dG_ddx));
+                    f_my = to_fixed(dL_dG * (-dG_ddy));
+                    f_cx = to_fixed(dL_dG * (mhG * dx * dx));
+                    f_cy = to_fixed(dL_dG * (mhG * 2.0f * dx * dy));
+                    f_cz = to_fixed(dL_dG * (mhG * dy * dy));
+                }
+                const int s0 = wave_sum(f_mx), s1 = wave_sum(f_my), s2 = wave_sum(f_cx), s3 = wave_sum(f_cy), s4 = wave_sum(f_cz);
+                const int s5 = wave_sum(f_op), s6 = wave_sum(f_r), s7 = wave_sum(f_g), s8 = wave_sum(f_b);
+                if (lane < 9u) {
+                    int v = s0;
+                    v = lane == 1u ? s1 : v; v = lane == 2u ? s2 : v; v = lane == 3u ? s3 : v; v = lane == 4u ? s4 : v;
+                    v = lane == 5u ? s5 : v; v = lane == 6u ? s6 : v; v = lane == 7u ? s7 : v; v = lane == 8u ? s8 : v;
+                    const u32 gidx = __float_as_uint(col.w);
+                    if (v != 0) atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + lane], v);
+                }
+            }
+        }
+        __syncthreads();
+        hi = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
+                                                                 const u32* __restrict__ gaussians, const int* __restrict__ acc,
+                                                                 u32* __restrict__ gradients) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int4* ap = reinterpret_cast<const int4*>(acc + (size_t)idx * ACC_STRIDE);
+    const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    const vec2 dL_dmean2D_px = V2(from_fixed(a0.x), from_fixed(a0.y));
+    const vec3 dL_dconic = V3(from_fixed(a0.z), from_fixed(a0.w), from_fixed(a1.x));
+    const float dL_dopac = from_fixed(a1.y);
+
+    const u32* gp = gaussians + (size_t)idx * 6;
+    const uint2 w01 = *reinterpret_cast<const uint2*>(gp), w23 = *reinterpret_cast<const uint2*>(gp + 2), w45 = *reinterpret_cast<const uint2*>(gp + 4);
+    const vec3 mean3D = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
+    const float opacity_raw = wd_unpack_hi(w01.y);
+    const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
+    const vec4 rot = V4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w23.y));
+    const vec3 log_scale = V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y));
+    const vec3 scale = vexp(log_scale);
+
+    const Cov3D c3 = covariance3D(rot, scale);
+    const CameraUniforms& cam = *reinterpret_cast<const CameraUniforms*>(camera_f);
+    const mat4 view = cam.view;
+    const vec3 t = xyz(view * V4(mean3D, 1.0f));
+
+    const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+    const vec2 dL_dmean2D_ndc = dL_dmean2D_px * 0.5f * viewport;
+    const mat4 view_proj = cam.proj * cam.view;
+    const vec4 p_hom = view_proj * V4(mean3D, 1.0f);
+    const float rw = wd_div(1.0f, p_hom.w + 0.0000001f);
+    const float rw2 = rw * rw;
+    const vec4 dL_dphom = V4(dL_dmean2D_ndc.x * rw, dL_dmean2D_ndc.y * rw, 0.0f, -(dL_dmean2D_ndc.x * p_hom.x + dL_dmean2D_ndc.y * p_hom.y) * rw2);
+    const vec3 dL_dmean3D_proj = xyz(transpose(view_proj) * dL_dphom);
+
+    const float focal_x = cam.focal.x, focal_y = cam.focal.y;
+    const float limx = wd_div(1.3f * viewport.x * 0.5f, focal_x);
+    const float limy = wd_div(1.3f * viewport.y * 0.5f, focal_y);
+    const float txtz = wd_div(t.x, t.z), tytz = wd_div(t.y, t.z);
+    const float tcx = wd_min(limx, wd_max(-limx, txtz)) * t.z;
+    const float tcy = wd_min(limy, wd_max(-limy, tytz)) * t.z;
+    const float x_grad_mul = (txtz >= -limx && txtz <= limx) ? 1.0f : 0.0f;
+    const float y_grad_mul = (tytz >= -limy && tytz <= limy) ? 1.0f : 0.0f;
+
+    const mat3 J = M3(V3(wd_div(focal_x, t.z), 0.0f, wd_div(-(focal_x * tcx), t.z * t.z)),
+                      V3(0.0f, wd_div(focal_y, t.z), wd_div(-(focal_y * tcy), t.z * t.z)), V3(0.0f, 0.0f, 0.0f));
+    const mat3 Wm = M3(xyz(view.c[0]), xyz(view.c[1]), xyz(view.c[2]));
+    const mat3 Tm = Wm * J;
+    const mat3 Vrk = M3(V3(c3.v[0], c3.v[1], c3.v[2]), V3(c3.v[1], c3.v[3], c3.v[4]), V3(c3.v[2], c3.v[4], c3.v[5]));
+    const mat3 cov2D = transpose(Tm) * Vrk * Tm;
+    const float a = cov2D.c[0].x + 0.3f, b = cov2D.c[0].y, c = cov2D.c[1].y + 0.3f;
+
+    const float denom = a * c - b * b;
+    const float denom2inv = wd_div(1.0f, (denom * denom) + 0.0000001f);
+    float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
+    if (denom2inv != 0.0f) {
+        dL_da = denom2inv * (-c * c * dL_dconic.x + 2.0f * b * c * dL_dconic.y + (denom - a * c) * dL_dconic.z);
+        dL_dc = denom2inv * (-a * a * dL_dconic.z + 2.0f * a * b * dL_dconic.y + (denom - a * c) * dL_dconic.x);
+        dL_db = denom2inv * 2.0f * (b * c * dL_dconic.x - (denom + 2.0f * b * b) * dL_dconic.y + a * b * dL_dconic.z);
+    }
+#define TM(c_, r_) el(Tm, c_, r_)
+#define VR(c_, r_) el(Vrk, c_, r_)
+#define WW(c_, r_) el(Wm, c_, r_)
+    float d3[6];
+    d3[0] = (TM(0, 0) * TM(0, 0) * dL_da + TM(0, 0) * TM(1, 0) * dL_db + TM(1, 0) * TM(1, 0) * dL_dc);
+    d3[3] = (TM(0, 1) * TM(0, 1) * dL_da + TM(0, 1) * TM(1, 1) * dL_db + TM(1, 1) * TM(1, 1) * dL_dc);
+    d3[5] = (TM(0, 2) * TM(0, 2) * dL_da + TM(0, 2) * TM(1, 2) * dL_db + TM(1, 2) * TM(1, 2) * dL_dc);
+    d3[1] = 2.0f * TM(0, 0) * TM(0, 1) * dL_da + (TM(0, 0) * TM(1, 1) + TM(0, 1) * TM(1, 0)) * dL_db + 2.0f * TM(1, 0) * TM(1, 1) * dL_dc;
+    d3[2] = 2.0f * TM(0, 0) * TM(0, 2) * dL_da + (TM(0, 0) * TM(1, 2) + TM(0, 2) * TM(1, 0)) * dL_db + 2.0f * TM(1, 0) * TM(1, 2) * dL_dc;
+    d3[4] = 2.0f * TM(0, 2) * TM(0, 1) * dL_da + (TM(0, 1) * TM(1, 2) + TM(0, 2) * TM(1, 1)) * dL_db + 2.0f * TM(1, 1) * TM(1, 2) * dL_dc;
+
+    const float dL_dT00 = 2.0f * (TM(0, 0) * VR(0, 0) + TM(0, 1) * VR(0, 1) + TM(0, 2) * VR(0, 2)) * dL_da + (TM(1, 0) * VR(0, 0) + TM(1, 1) * VR(0, 1) + TM(1, 2) * VR(0, 2)) * dL_db;
+    const float dL_dT01 = 2.0f * (TM(0, 0) * VR(1, 0) + TM(0, 1) * VR(1, 1) + TM(0, 2) * VR(1, 2)) * dL_da + (TM(1, 0) * VR(1, 0) + TM(1, 1) * VR(1, 1) + TM(1, 2) * VR(1, 2)) * dL_db;
+    const float dL_dT02 = 2.0f * (TM(0, 0) * VR(2, 0) + TM(0, 1) * VR(2, 1) + TM(0, 2) * VR(2, 2)) * dL_da + (TM(1, 0) * VR(2, 0) + TM(1, 1) * VR(2, 1) + TM(1, 2) * VR(2, 2)) * dL_db;
+    const float dL_dT10 = 2.0f * (TM(1, 0) * VR(0, 0) + TM(1, 1) * VR(0, 1) + TM(1, 2) * VR(0, 2)) * dL_dc + (TM(0, 0) * VR(0, 0) + TM(0, 1) * VR(0, 1) + TM(0, 2) * VR(0, 2)) * dL_db;
+    const float dL_dT11 = 2.0f * (TM(1, 0) * VR(1, 0) + TM(1, 1) * VR(1, 1) + TM(1, 2) * VR(1, 2)) * dL_dc + (TM(0, 0) * VR(1, 0) + TM(0, 1) * VR(1, 1) + TM(0, 2) * VR(1, 2)) * dL_db;
+    const float dL_dT12 = 2.0f * (TM(1, 0) * VR(2, 0) + TM(1, 1) * VR(2, 1) + TM(1, 2) * VR(2, 2)) * dL_dc + (TM(0, 0) * VR(2, 0) + TM(0, 1) * VR(2, 1) + TM(0, 2) * VR(2, 2)) * dL_db;
+
+    const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+    const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+    const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+    const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+#undef TM
+#undef VR
+#undef WW
+    const float tz = wd_div(1.0f, t.z);
+    const float tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -focal_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
+    const float dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2.0f * focal_x * tcx) * tz3 * dL_dJ02 + (2.0f * focal_y * tcy) * tz3 * dL_dJ12;
+    const vec3 dL_dmean3D_cov = xyz(transpose(view) * V4(dL_dtx, dL_dty, dL_dtz, 0.0f));
+
+    const float x = rot.y, y = rot.z, z = rot.w, r = rot.x;
+    const mat3 R = quat_to_R(rot);
+    const mat3 M = diag3(scale) * R;
+    const mat3 dL_dSigma = M3(V3(d3[0], 0.5f * d3[1], 0.5f * d3[2]), V3(0.5f * d3[1], d3[3], 0.5f * d3[4]), V3(0.5f * d3[2], 0.5f * d3[4], d3[5]));
+    const mat3 dL_dM = (2.0f * M) * dL_dSigma;
+    const mat3 dL_dMt = transpose(dL_dM);
+    const mat3 Rt = transpose(R);
+    const vec3 dL_dscale = V3(dot(Rt.c[0], dL_dMt.c[0]), dot(Rt.c[1], dL_dMt.c[1]), dot(Rt.c[2], dL_dMt.c[2]));
+    mat3 D = dL_dMt;
+    D.c[0] = dL_dMt.c[0] * scale.x;
+    D.c[1] = dL_dMt.c[1] * scale.y;
+    D.c[2] = dL_dMt.c[2] * scale.z;
+#define DD(c_, r_) el(D, c_, r_)
+    const float dL_drot_x = 2.0f * z * (DD(0, 1) - DD(1, 0)) + 2.0f * y * (DD(2, 0) - DD(0, 2)) + 2.0f * x * (DD(1, 2) - DD(2, 1));
+    const float dL_drot_y = 2.0f * y * (DD(1, 0) + DD(0, 1)) + 2.0f * z * (DD(2, 0) + DD(0, 2)) + 2.0f * r * (DD(1, 2) - DD(2, 1)) - 4.0f * x * (DD(2, 2) + DD(1, 1));
+    const float dL_drot_z = 2.0f * x * (DD(1, 0) + DD(0, 1)) + 2.0f * r * (DD(2, 0) - DD(0, 2)) + 2.0f * z * (DD(1, 2) + DD(2, 1)) - 4.0f * y * (DD(2, 2) + DD(0, 0));
+    const float dL_drot_w = 2.0f * r * (DD(0, 1) - DD(1, 0)) + 2.0f * x * (DD(2, 0) + DD(0, 2)) + 2.0f * y * (DD(1, 2) + DD(2, 1)) - 4.0f * z * (DD(1, 1) + DD(0, 0));
+#undef DD
+    const vec3 final_dL_dmean3D = dL_dmean3D_proj + dL_dmean3D_cov;
+    const float dL_dopacity_raw = dL_dopac * opacity_sigmoid * (1.0f - opacity_sigmoid);
+    vec3 dL_dlog_scale = dL_dscale * scale;
+    {
+        const float cap_px = settings.max_splat_radius_px;
+        if (cap_px > 0.0f) {
+            const float denom_cap = a * c - b * b;
+            if (denom_cap > 0.0f) {
+                const float conic_x = wd_div(c, denom_cap), conic_y = wd_div(-b, denom_cap), conic_z = wd_div(a, denom_cap);
+                const float disc = conic_y * conic_y - conic_x * conic_z;
+                const float t_cap = 2.0f * wd_log(opacity_sigmoid * 128.0f);
+                if (t_cap > 0.0f && disc < 0.0f) {
+                    const float x_extent = wd_sqrt(wd_div(t_cap * conic_z, -disc));
+                    const float y_extent = wd_sqrt(wd_div(t_cap * conic_x, -disc));
+                    if (wd_max(x_extent, y_extent) >= cap_px) dL_dlog_scale = vmax(dL_dlog_scale, V3(0.0f));
+                }
+            }
+        }
+    }
+    uint4 o0, o1;
+    o0.x = wd_pack2(final_dL_dmean3D.x, final_dL_dmean3D.y);
+    o0.y = wd_pack2(final_dL_dmean3D.z, dL_dopacity_raw);
+    o0.z = wd_pack2(dL_drot_x, dL_drot_y);
+    o0.w = wd_pack2(dL_drot_z, dL_drot_w);
+    o1.x = wd_pack2(dL_dlog_scale.x, dL_dlog_scale.y);
+    o1.y = wd_pack2(dL_dlog_scale.z, 0.0f);
+    o1.z = wd_pack2(from_fixed(a1.z), from_fixed(a1.w));
+    o1.w = wd_pack2(from_fixed(a2.x), 0.0f);
+    uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
+    op[0] = o0;
+    op[1] = o1;
+}
+
+}  // namespace
+
+int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 num_tiles_x, u32 num_tiles_y, const void* ranges, const void* instances,
+                              const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc) {
+    const u32 tiles = num_tiles_x * num_tiles_y;
+    if (tiles == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel, dim3(tiles), dim3(256), 0, st, num_tiles_x, (const u32*)ranges, (const u32*)instances,
+                (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc, void* gradients) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st, (const u32*)gaussians,
+                (const int*)acc, (u32*)gradients);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}

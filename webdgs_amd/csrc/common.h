@@ -1,0 +1,97 @@
+// Internal definitions shared by the HIP translation units of libwebdgs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/webdgs.h"
+
+typedef uint32_t u32;
+typedef int32_t i32;
+
+void wdgs_set_error(const char* fmt, ...);
+
+#define WDGS_CHECK_HIP(expr)                                                                      \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            wdgs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return WDGS_E_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define WDGS_REQUIRE(cond, code, ...)  \
+    do {                               \
+        if (!(cond)) {                 \
+            wdgs_set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+#define WDGS_TRY(expr)                 \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != WDGS_OK) return _r;  \
+    } while (0)
+
+struct wdgs_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    struct Pending { const char* name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    struct Total { u32 launches = 0; float ms = 0.f; };
+    std::map<std::string, Total> totals;
+    std::vector<wdgs_tiled_forward*> forwards;  // live forward passes, for deferred overflow checks
+    int num_cus = 256;
+};
+
+// Brackets one kernel launch with events when profiling is on (hipEvents on the launch stream).
+struct KernelScope {
+    wdgs_device* d;
+    const char* name;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelScope(wdgs_device* dev, const char* n) : d(dev), name(n) {
+        if (d->profiling) {
+            a = take(); b = take();
+            (void)hipEventRecord(a, d->stream);
+        }
+    }
+    ~KernelScope() {
+        if (d->profiling) {
+            (void)hipEventRecord(b, d->stream);
+            d->pending.push_back({name, a, b});
+        }
+    }
+    hipEvent_t take() {
+        if (!d->event_pool.empty()) { hipEvent_t e = d->event_pool.back(); d->event_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+};
+
+#define WDGS_LAUNCH(dev, kname, kernel, grid, block, shmem, ...)                           \
+    do {                                                                                   \
+        KernelScope _ks((dev), (kname));                                                   \
+        hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (dev)->stream, __VA_ARGS__);  \
+    } while (0)
+
+static inline u32 ceil_div(u32 a, u32 b) { return (a + b - 1u) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream);
+
+// ---- primitives implemented in scan.hip / sort.hip, used by the ops
+struct ScanScratch { u32* block_sums = nullptr; u32 capacity_blocks = 0; };
+int scan_scratch_create(ScanScratch* s, u32 max_elements);
+void scan_scratch_destroy(ScanScratch* s);
+// Exclusive u32 scan of `count` (host-known) elements.  If total_out != nullptr, writes the grand total there.
+int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out);
+
+struct RenderSettings { float gaussian_scaling, sh_deg, viewport_x, viewport_y, point_size_px, gaussian_mode, max_splat_radius_px; };
+struct TileInfo { u32 num_tiles_x, num_tiles_y, total_tiles, max_tile_entries; };

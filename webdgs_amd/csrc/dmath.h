@@ -1,0 +1,96 @@
+// Deterministic device math ("dmath"): every step is an IEEE-754 binary32 operation with a fixed
+// order, so results are bit-identical to any host that performs the same steps (the parity oracle does, in its
+// own independent implementation).  Compiled with -ffp-contract=off; FMA only where written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+
+#define WD_DEV __device__ __forceinline__
+
+WD_DEV float wd_bits2f(uint32_t u) { return __uint_as_float(u); }
+WD_DEV uint32_t wd_f2bits(float f) { return __float_as_uint(f); }
+
+// exp(x) = 2^n * P(r); n = rint(x*log2e); r = x - n*ln2 (hi/lo FMA); P degree 6 (FMA Horner).
+// x < -86 -> 0 and x > 88 -> inf, so n is in [-124, 127] and the multiply by 2^n is exact; NaN propagates through r.
+WD_DEV float wd_exp(float x) {
+    const float LOG2E = wd_bits2f(0x3FB8AA3Bu);
+    const float LN2_HI = wd_bits2f(0x3F318000u);
+    const float LN2_LO = wd_bits2f(0xB95E8083u);
+    const float C2 = wd_bits2f(1056964604u), C3 = wd_bits2f(1042983495u), C4 = wd_bits2f(1026207148u),
+                C5 = wd_bits2f(1007230415u), C6 = wd_bits2f(984890875u);
+    float n = __builtin_rintf(x * LOG2E);
+    float r = __builtin_fmaf(-n, LN2_HI, x);
+    r = __builtin_fmaf(-n, LN2_LO, r);
+    float p = __builtin_fmaf(C6, r, C5);
+    p = __builtin_fmaf(p, r, C4);
+    p = __builtin_fmaf(p, r, C3);
+    p = __builtin_fmaf(p, r, C2);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    // clamp the exponent so out-of-range x cannot build an invalid bit pattern before the select below
+    float nc = fminf(fmaxf(n, -126.0f), 127.0f);
+    float res = p * wd_bits2f((uint32_t)((int)nc + 127) << 23);
+    res = (x < -86.0f) ? 0.0f : res;
+    res = (x > 88.0f) ? __builtin_inff() : res;
+    return res;
+}
+
+WD_DEV float wd_log(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return x;
+    int eadj = 0;
+    if (x < wd_bits2f(0x00800000u)) { x = x * 8388608.0f; eadj = -23; }
+    uint32_t b = wd_f2bits(x);
+    int e = (int)((b >> 23) & 0xFFu) - 126 + eadj;
+    float m = wd_bits2f((b & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) { e = e - 1; m = m + m; }
+    m = m - 1.0f;
+    float z = m * m;
+    float y = 7.0376836292E-2f;
+    y = __builtin_fmaf(y, m, -1.1514610310E-1f);
+    y = __builtin_fmaf(y, m, 1.1676998740E-1f);
+    y = __builtin_fmaf(y, m, -1.2420140846E-1f);
+    y = __builtin_fmaf(y, m, 1.4249322787E-1f);
+    y = __builtin_fmaf(y, m, -1.6668057665E-1f);
+    y = __builtin_fmaf(y, m, 2.0000714765E-1f);
+    y = __builtin_fmaf(y, m, -2.4999993993E-1f);
+    y = __builtin_fmaf(y, m, 3.3333331174E-1f);
+    y = (y * m) * z;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// __fsqrt_rn is the approximate v_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf and "/" are correctly
+// rounded under -fhip-fp32-correctly-rounded-divide-sqrt (set explicitly in the Makefile).
+WD_DEV float wd_sqrt(float x) { return __builtin_sqrtf(x); }
+WD_DEV float wd_div(float a, float b) { return a / b; }
+// WGSL min/max: min(e1,e2) = e2 if e2 < e1 else e1; max(e1,e2) = e2 if e1 < e2 else e1 (pins +-0 ties and NaN).
+WD_DEV float wd_min(float a, float b) { return (b < a) ? b : a; }
+WD_DEV float wd_max(float a, float b) { return (a < b) ? b : a; }
+WD_DEV float wd_clamp(float v, float lo, float hi) { return wd_min(wd_max(v, lo), hi); }
+
+// WGSL u32(f32)/i32(f32): truncate, saturate, NaN -> 0.
+WD_DEV uint32_t wd_to_u32(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+WD_DEV int32_t wd_to_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int32_t)0x80000000u;
+    return (int32_t)v;
+}
+
+// fp16 pack/unpack (round to nearest even, subnormals kept, overflow to inf).
+WD_DEV uint32_t wd_f16bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+WD_DEV uint32_t wd_pack2(float x, float y) { return wd_f16bits(x) | (wd_f16bits(y) << 16); }
+WD_DEV float wd_unpack_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))); }
+WD_DEV float wd_unpack_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }

@@ -1,0 +1,236 @@
+// Per-splat projection + tile counting (K1) and tile-entry emission (K6).
+//
+// Replaces count_main / emit_main of the reference (src/shaders/tiled-forward.wgsl:161-294, 297-354, helpers in
+// src/shaders/common.wgsl:44-108).  Both are N-wide streaming kernels bound by HBM:
+//   project: reads 24 B Gaussian + 6K B SH (K = (deg+1)^2, visible only), writes 24 B Splat + 4 B depth (visible)
+//            and 4 B tile count (all)           -> N(24+4) + V(6K+28) bytes
+//   emit:    reads 24 B Splat + 4 B depth + 8 B count/offset, writes 8 B per tile entry -> 16V + 8N + 8E bytes
+#include "common.h"
+#include "wgslm.h"
+
+namespace {
+
+__constant__ float SH_C2c[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3c[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+WD_DEV vec3 sh_coef(const uint16_t* __restrict__ sh_half, u32 c_idx) {
+    // SH is 48 fp16 per Gaussian in [k][rgb] order; element e lives in half-word e.
+    const float r = __half2float(__ushort_as_half(sh_half[c_idx * 3u + 0u]));
+    const float g = __half2float(__ushort_as_half(sh_half[c_idx * 3u + 1u]));
+    const float b = __half2float(__ushort_as_half(sh_half[c_idx * 3u + 2u]));
+    return V3(r, g, b);
+}
+
+WD_DEV vec3 color_from_sh(const uint16_t* __restrict__ sh, vec3 dir, u32 sh_deg) {
+    const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+    vec3 result = SH_C0 * sh_coef(sh, 0u);
+    if (sh_deg > 0u) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        result = result + (-SH_C1 * y * sh_coef(sh, 1u) + SH_C1 * z * sh_coef(sh, 2u) - SH_C1 * x * sh_coef(sh, 3u));
+        if (sh_deg > 1u) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            result = result + (SH_C2c[0] * xy * sh_coef(sh, 4u) + SH_C2c[1] * yz * sh_coef(sh, 5u) +
+                               SH_C2c[2] * (2.0f * zz - xx - yy) * sh_coef(sh, 6u) + SH_C2c[3] * xz * sh_coef(sh, 7u) +
+                               SH_C2c[4] * (xx - yy) * sh_coef(sh, 8u));
+            if (sh_deg > 2u) {
+                result = result + (SH_C3c[0] * y * (3.0f * xx - yy) * sh_coef(sh, 9u) + SH_C3c[1] * xy * z * sh_coef(sh, 10u) +
+                                   SH_C3c[2] * y * (4.0f * zz - xx - yy) * sh_coef(sh, 11u) +
+                                   SH_C3c[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh_coef(sh, 12u) +
+                                   SH_C3c[4] * x * (4.0f * zz - xx - yy) * sh_coef(sh, 13u) +
+                                   SH_C3c[5] * z * (xx - yy) * sh_coef(sh, 14u) + SH_C3c[6] * x * (xx - 3.0f * yy) * sh_coef(sh, 15u));
+            }
+        }
+    }
+    result = result + 0.5f;
+    return vmax(V3(0.0f), result);
+}
+
+WD_DEV vec3 covariance2D(const Cov3D& c3, vec4 mean_view, vec2 focal, vec2 viewport, const mat4& vm) {
+    vec3 t = xyz(mean_view);
+    const float fovx = wd_div(viewport.x * 0.5f, focal.x), fovy = wd_div(viewport.y * 0.5f, focal.y);
+    const float limx = 1.3f * fovx, limy = 1.3f * fovy;
+    const float txtz = wd_div(t.x, t.z), tytz = wd_div(t.y, t.z);
+    t.x = wd_min(limx, wd_max(-limx, txtz)) * t.z;
+    t.y = wd_min(limy, wd_max(-limy, tytz)) * t.z;
+    const mat3 J = M3(V3(wd_div(focal.x, t.z), 0.0f, wd_div(-(focal.x * t.x), t.z * t.z)),
+                      V3(0.0f, wd_div(focal.y, t.z), wd_div(-(focal.y * t.y), t.z * t.z)), V3(0.0f, 0.0f, 0.0f));
+    const mat3 W = M3(V3(vm.c[0].x, vm.c[1].x, vm.c[2].x), V3(vm.c[0].y, vm.c[1].y, vm.c[2].y), V3(vm.c[0].z, vm.c[1].z, vm.c[2].z));
+    const mat3 T = W * J;
+    const mat3 Vrk = M3(V3(c3.v[0], c3.v[1], c3.v[2]), V3(c3.v[1], c3.v[3], c3.v[4]), V3(c3.v[2], c3.v[4], c3.v[5]));
+    const mat3 cov = transpose(T) * transpose(Vrk) * T;
+    return V3(cov.c[0].x + 0.3f, cov.c[0].y, cov.c[1].y + 0.3f);
+}
+
+WD_DEV u32 ordered_uint(float x) {
+    const u32 bits = wd_f2bits(x);
+    return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// Tile bounding box of a stored (fp16) splat: shared by count and emit so both see the same integers.
+struct TileBox { u32 min_x, min_y, max_x, max_y; bool valid; };
+WD_DEV TileBox tile_box(vec2 ndc_f16, vec2 extents_f16, vec2 viewport, u32 ntx, u32 nty, bool check_empty) {
+    TileBox b; b.valid = false; b.min_x = b.min_y = b.max_x = b.max_y = 0u;
+    const vec2 pixel_center = (ndc_f16 * V2(0.5f, -0.5f) + 0.5f) * viewport;
+    const vec2 lo = pixel_center - extents_f16 - 2.0f;
+    const vec2 hi = pixel_center + extents_f16 + 2.0f;
+    if (hi.x < 0.0f || hi.y < 0.0f || lo.x >= viewport.x || lo.y >= viewport.y) return b;
+    const float bminx = wd_max(lo.x, 0.0f), bminy = wd_max(lo.y, 0.0f);
+    const float bmaxx = wd_min(hi.x, viewport.x - 1.0f), bmaxy = wd_min(hi.y, viewport.y - 1.0f);
+    if (check_empty && (bmaxx < bminx || bmaxy < bminy)) return b;
+    b.min_x = wd_to_u32(bminx) / 16u;
+    b.min_y = wd_to_u32(bminy) / 16u;
+    b.max_x = min(wd_to_u32(bmaxx) / 16u, ntx - 1u);
+    b.max_y = min(wd_to_u32(bmaxy) / 16u, nty - 1u);
+    b.valid = true;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer,
+                                                             const float* __restrict__ camera_f, RenderSettings settings, TileInfo ti,
+                                                             u32* __restrict__ splats, u32* __restrict__ depths,
+                                                             u32* __restrict__ tile_counts, u32* __restrict__ stats) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool visible = false;
+    if (idx < n) {
+        u32 num_tiles_out = 0u;
+        do {
+            const u32* g = gaussians + (size_t)idx * 6;
+            const uint2 w01 = *reinterpret_cast<const uint2*>(g);
+            const uint2 w23 = *reinterpret_cast<const uint2*>(g + 2);
+            const uint2 w45 = *reinterpret_cast<const uint2*>(g + 4);
+            const vec4 quaternion = V4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w23.y));
+            const vec3 gaussian_scale = vexp(V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y)));
+            const vec3 pos = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
+            const float opacity_raw = wd_unpack_hi(w01.y);
+            const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
+
+            const CameraUniforms& cam = *reinterpret_cast<const CameraUniforms*>(camera_f);
+            const mat4 view = cam.view;
+            const vec4 world_to_view = view * V4(pos, 1.0f);
+            const vec4 clip = cam.proj * world_to_view;
+            if (clip.w == 0.0f) break;
+            const vec3 ndc = xyz(clip) / clip.w;
+            if (ndc.x < -1.2f || ndc.x > 1.2f || ndc.y < -1.2f || ndc.y > 1.2f || ndc.z < 0.0f || ndc.z > 1.0f) break;
+
+            const Cov3D c3 = covariance3D(quaternion, gaussian_scale);
+            const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+            const vec3 c2 = covariance2D(c3, world_to_view, cam.focal, viewport, view);
+            const float det = (c2.x * c2.z) - (c2.y * c2.y);
+            if (det <= 0.0f) break;
+            const float det_inv = wd_div(1.0f, det);
+            const vec3 conic = V3(c2.z * det_inv, -c2.y * det_inv, c2.x * det_inv);
+            const float disc = conic.y * conic.y - conic.x * conic.z;
+            if (conic.x <= 0.0f || conic.z <= 0.0f || disc >= 0.0f) break;
+
+            const float t = 2.0f * wd_log(opacity_sigmoid * 128.0f);
+            if (t <= 0.0f) break;
+            const float x_extent = wd_sqrt(wd_div(t * conic.z, -disc));
+            const float y_extent = wd_sqrt(wd_div(t * conic.x, -disc));
+            const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+            const float xec = wd_min(x_extent, cap), yec = wd_min(y_extent, cap);
+            // Round-trip through fp16 so emit/raster/backward (which only see the Splat) agree on the bbox.
+            const u32 ndc_packed = wd_pack2(wd_clamp(ndc.x, -60000.0f, 60000.0f), wd_clamp(ndc.y, -60000.0f, 60000.0f));
+            const u32 ext_packed = wd_pack2(xec, yec);
+            const vec2 ndc_store = V2(wd_unpack_lo(ndc_packed), wd_unpack_hi(ndc_packed));
+            const vec2 ext_f16 = V2(wd_unpack_lo(ext_packed), wd_unpack_hi(ext_packed));
+            const TileBox tb = tile_box(ndc_store, ext_f16, viewport, ti.num_tiles_x, ti.num_tiles_y, true);
+            if (!tb.valid) break;
+
+            const vec3 cam_pos = xyz(cam.view_inv.c[3]);
+            const vec3 dir = normalize(pos - cam_pos);
+            const uint16_t* shp = reinterpret_cast<const uint16_t*>(sh_buffer + (size_t)idx * 24);
+            const vec3 color = color_from_sh(shp, dir, wd_to_u32(settings.sh_deg));
+
+            const u32 num_tiles = (tb.max_x - tb.min_x + 1u) * (tb.max_y - tb.min_y + 1u);
+            if (num_tiles > 2048u) break;
+
+            u32* s = splats + (size_t)idx * 6;
+            uint2 o01, o23, o45;
+            o01.x = ndc_packed;
+            o01.y = ext_packed;
+            o23.x = wd_pack2(conic.x, conic.y);
+            o23.y = wd_pack2(conic.z, 0.0f);
+            o45.x = wd_pack2(wd_clamp(color.x, 0.0f, 1.0f), wd_clamp(color.y, 0.0f, 1.0f));
+            o45.y = wd_pack2(wd_clamp(color.z, 0.0f, 1.0f), wd_clamp(opacity_sigmoid, 0.0f, 1.0f));
+            *reinterpret_cast<uint2*>(s) = o01;
+            *reinterpret_cast<uint2*>(s + 2) = o23;
+            *reinterpret_cast<uint2*>(s + 4) = o45;
+            depths[idx] = ordered_uint(world_to_view.z);
+            num_tiles_out = num_tiles;
+            visible = true;
+        } while (false);
+        tile_counts[idx] = num_tiles_out;
+    }
+    // visible_gaussians: one atomic per wave (ballot + popcount) instead of one per lane.
+    const unsigned long long mask = __ballot(visible);
+    if ((threadIdx.x & 63u) == 0u && mask != 0ull) atomicAdd(&stats[1], (u32)__popcll(mask));
+}
+
+// stats[0] = total tile entries (update_stats, src/shaders/update-stats.wgsl:19-35); stats[2] = overflow flag.
+__global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, const u32* __restrict__ counts, u32 capacity, u32* __restrict__ stats) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u32 total = (n == 0u) ? 0u : offsets[n - 1] + counts[n - 1];
+        stats[0] = min(total, capacity);  // consumers only ever touch [0, capacity)
+        stats[2] = (total > capacity) ? total : 0u;
+        // a wrapped scan (sum >= 2^32) also shows as an offset going backwards; tile counts are <= 2048 each, so
+        // N * 2048 < 2^32 for N < 2^21; beyond that the forward pass sizes its capacity from a 64-bit bound (api).
+    }
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict__ splats, const u32* __restrict__ depths,
+                                                    const u32* __restrict__ tile_counts, const u32* __restrict__ tile_offsets,
+                                                    RenderSettings settings, TileInfo ti, u32* __restrict__ keys, u32* __restrict__ values,
+                                                    u32 capacity) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const u32 num_tiles = tile_counts[idx];
+    if (num_tiles == 0u) return;
+    const u32 start = tile_offsets[idx];
+    const uint2 w01 = *reinterpret_cast<const uint2*>(splats + (size_t)idx * 6);
+    const vec2 ndc = V2(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x));
+    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+    const vec2 ext = V2(wd_min(wd_unpack_lo(w01.y), cap), wd_min(wd_unpack_hi(w01.y), cap));
+    const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+    const TileBox tb = tile_box(ndc, ext, viewport, ti.num_tiles_x, ti.num_tiles_y, false);
+    if (!tb.valid) return;
+    const u32 depth16 = depths[idx] >> 16u;
+    u32 offset = 0u;
+    for (u32 ty = tb.min_y; ty <= tb.max_y; ty++) {
+        for (u32 tx = tb.min_x; tx <= tb.max_x; tx++) {
+            const u32 tile_id = ty * ti.num_tiles_x + tx;
+            const u32 key_idx = start + offset;
+            if (key_idx < capacity) {
+                keys[key_idx] = ((tile_id + 1u) << 16u) | depth16;
+                values[key_idx] = idx;
+            }
+            offset++;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const void* sh, const void* camera, const RenderSettings& st,
+                         const TileInfo& ti, void* splats, void* depths, void* counts, void* stats) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "project_count", project_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh,
+                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)stats);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_update_stats(wdgs_device* dev, u32 n, const void* offsets, const void* counts, u32 capacity, void* stats) {
+    WDGS_LAUNCH(dev, "update_stats", update_stats_kernel, dim3(1), dim3(64), 0, n, (const u32*)offsets, (const u32*)counts, capacity, (u32*)stats);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_emit(wdgs_device* dev, u32 n, const void* splats, const void* depths, const void* counts, const void* offsets,
+                const RenderSettings& st, const TileInfo& ti, void* keys, void* values, u32 capacity) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "emit", emit_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)splats, (const u32*)depths, (const u32*)counts,
+                (const u32*)offsets, st, ti, (u32*)keys, (u32*)values, capacity);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}

@@ -1,0 +1,200 @@
+// Stable LSD radix sort of (key u32, value u32) pairs with a device-resident element count, and the per-tile range
+// table built from the sorted keys.
+//
+// Replaces src/sort/sort_dynamic.ts + radix_sort.wgsl (K7-K11: 4 x 8-bit passes, decoupled look-back, a 32-lane
+// lock-step assumption in its rank loop -- SURVEY section 5 "race detection") and src/shaders/tile-ranges.wgsl (K12-K13:
+// E atomicMins).  Here every pass is histogram -> scan -> scatter over 4096-key partitions; ranks come from wave64
+// ballots (no lock-step assumption), only the significant digits are sorted, and the range table is a boundary
+// detect with plain stores.  HBM traffic per pass: 4E (histogram) + 16E (scatter); ranges: 4E + 4(T+1).
+#include "common.h"
+
+namespace {
+
+constexpr u32 SORT_THREADS = 256;
+constexpr u32 SORT_ITEMS = 16;
+constexpr u32 SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per partition
+constexpr u32 RADIX = 256;
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 shift,
+                                                                 u32 num_parts, u32* __restrict__ hist /*[RADIX][num_parts]*/) {
+    __shared__ u32 lh[RADIX];
+    const u32 count = *count_ptr;
+    const u32 part = blockIdx.x;
+    const u32 base = part * SORT_TILE;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    if (base < count) {
+#pragma unroll 4
+        for (u32 j = 0; j < SORT_ITEMS; j++) {
+            const u32 i = base + j * SORT_THREADS + threadIdx.x;
+            if (i < count) atomicAdd(&lh[(keys[i] >> shift) & (RADIX - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * num_parts + part] = lh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                                    u32* __restrict__ keys_out, u32* __restrict__ vals_out,
+                                                                    const u32* __restrict__ count_ptr, u32 shift, u32 num_parts,
+                                                                    const u32* __restrict__ offsets /*scanned hist*/) {
+    __shared__ u32 whist[SORT_THREADS / 64][RADIX];
+    const u32 count = *count_ptr;
+    const u32 part = blockIdx.x;
+    const u32 base = part * SORT_TILE;
+    if (base >= count) return;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (u32 w = 0; w < SORT_THREADS / 64; w++) whist[w][threadIdx.x] = 0;
+    __syncthreads();
+
+    // Wave w owns keys [base + w*1024, base + (w+1)*1024) in 16 rounds of 64 consecutive keys: the order
+    // (wave, round, lane) is the input order, which is what makes the pass stable.
+    u32 k[SORT_ITEMS], v[SORT_ITEMS], rk[SORT_ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (u32 j = 0; j < SORT_ITEMS; j++) {
+        const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
+        const bool valid = i < count;
+        k[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        v[j] = valid ? vals_in[i] : 0u;
+        const u32 digit = (k[j] >> shift) & (RADIX - 1u);
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (u32 b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        // m = valid lanes of this wave holding the same digit
+        const u32 pre = whist[wave][digit];
+        const u32 below = (u32)__popcll(m & lt_mask);
+        rk[j] = pre + below;
+        if (valid && below == 0u) whist[wave][digit] = pre + (u32)__popcll(m);  // group leader bumps the wave counter
+        // wave-private LDS words: the next round's read is ordered after this write within the wave
+    }
+    __syncthreads();
+    {   // turn per-wave counts into global base addresses: digit d, waves in order
+        const u32 d = threadIdx.x;
+        u32 run = offsets[(size_t)d * num_parts + part];
+#pragma unroll
+        for (u32 w = 0; w < SORT_THREADS / 64; w++) {
+            const u32 c = whist[w][d];
+            whist[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < SORT_ITEMS; j++) {
+        const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
+        if (i < count) {
+            const u32 digit = (k[j] >> shift) & (RADIX - 1u);
+            const u32 pos = whist[wave][digit] + rk[j];
+            keys_out[pos] = k[j];
+            vals_out[pos] = v[j];
+        }
+    }
+}
+
+// ranges[t] = first index whose key>>16 == t+1, 0xFFFFFFFF for empty tiles, ranges[T] = E.
+__global__ void tile_ranges_init_kernel(u32* __restrict__ ranges, u32 total_tiles, const u32* __restrict__ count_ptr) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total_tiles) ranges[i] = 0xFFFFFFFFu;
+    if (i == total_tiles) ranges[i] = *count_ptr;
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 total_tiles,
+                                                           u32* __restrict__ ranges) {
+    const u32 count = *count_ptr;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const u32 t = keys[i] >> 16u;
+        const u32 prev = (i > 0u) ? (keys[i - 1] >> 16u) : 0u;
+        if (t != prev && t >= 1u && t - 1u < total_tiles) ranges[t - 1u] = i;
+    }
+}
+
+}  // namespace
+
+struct wdgs_sorter {
+    wdgs_device* dev;
+    u32 capacity;       // elements (multiple of SORT_TILE)
+    u32 num_parts;
+    const u32* count_ptr;
+    u32* keys[2];
+    u32* vals[2];
+    u32* hist;          // [RADIX * num_parts], scanned in place
+    ScanScratch scan;
+    int final_out_index;
+};
+
+extern "C" {
+
+int wdgs_sorter_create(wdgs_device* dev, uint32_t max_capacity, const void* stats_dev, wdgs_sorter** out) {
+    WDGS_REQUIRE(dev && out && stats_dev, WDGS_E_INVALID, "wdgs_sorter_create: null argument");
+    wdgs_sorter* s = new wdgs_sorter();
+    s->dev = dev;
+    s->capacity = (u32)align_up(max_capacity > 0 ? max_capacity : 1, SORT_TILE);
+    s->num_parts = s->capacity / SORT_TILE;
+    s->count_ptr = (const u32*)stats_dev;
+    s->final_out_index = 0;
+    for (int i = 0; i < 2; i++) { s->keys[i] = nullptr; s->vals[i] = nullptr; }
+    s->hist = nullptr;
+    int r = WDGS_OK;
+    for (int i = 0; i < 2 && r == WDGS_OK; i++) {
+        r = wdgs_alloc((void**)&s->keys[i], sizeof(u32) * (size_t)s->capacity, true, dev->stream);
+        if (r == WDGS_OK) r = wdgs_alloc((void**)&s->vals[i], sizeof(u32) * (size_t)s->capacity, true, dev->stream);
+    }
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&s->hist, sizeof(u32) * (size_t)RADIX * s->num_parts, true, dev->stream);
+    if (r == WDGS_OK) r = scan_scratch_create(&s->scan, RADIX * s->num_parts);
+    if (r != WDGS_OK) { wdgs_sorter_destroy(s); return r; }
+    *out = s;
+    return WDGS_OK;
+}
+
+int wdgs_sorter_destroy(wdgs_sorter* s) {
+    if (!s) return WDGS_OK;
+    for (int i = 0; i < 2; i++) {
+        if (s->keys[i]) (void)hipFree(s->keys[i]);
+        if (s->vals[i]) (void)hipFree(s->vals[i]);
+    }
+    if (s->hist) (void)hipFree(s->hist);
+    scan_scratch_destroy(&s->scan);
+    delete s;
+    return WDGS_OK;
+}
+
+void* wdgs_sorter_keys(wdgs_sorter* s, int i) { return s ? s->keys[i & 1] : nullptr; }
+void* wdgs_sorter_values(wdgs_sorter* s, int i) { return s ? s->vals[i & 1] : nullptr; }
+int wdgs_sorter_final_out_index(wdgs_sorter* s) { return s ? s->final_out_index : 0; }
+uint32_t wdgs_sorter_capacity(wdgs_sorter* s) { return s ? s->capacity : 0; }
+
+int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
+    WDGS_REQUIRE(s, WDGS_E_INVALID, "wdgs_sorter_sort: null sorter");
+    if (key_bits == 0 || key_bits > 32) key_bits = 32;
+    const u32 passes = (key_bits + 7u) / 8u;
+    wdgs_device* dev = s->dev;
+    int src = 0;
+    for (u32 p = 0; p < passes; p++) {
+        const u32 shift = p * 8u;
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->hist);
+        WDGS_TRY(scan_exclusive_u32(dev, &s->scan, s->hist, s->hist, RADIX * s->num_parts, nullptr));
+        WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                    s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->hist);
+        src ^= 1;
+    }
+    WDGS_CHECK_HIP(hipGetLastError());
+    s->final_out_index = src;
+    return WDGS_OK;
+}
+
+}  // extern "C"
+
+int launch_tile_ranges(wdgs_device* dev, const void* sorted_keys, const void* count_ptr, u32 total_tiles, void* ranges) {
+    WDGS_LAUNCH(dev, "tile_ranges_init", tile_ranges_init_kernel, dim3(ceil_div(total_tiles + 1, 256)), dim3(256), 0, (u32*)ranges, total_tiles,
+                (const u32*)count_ptr);
+    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(dev->num_cus * 8), dim3(256), 0, (const u32*)sorted_keys, (const u32*)count_ptr, total_tiles,
+                (u32*)ranges);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}

@@ -1,0 +1,584 @@
+"""Host-side mirror of the reference's operator classes over the C ABI (``include/webdgs.h``).
+
+Class and method names follow ``/root/reference/src/renderers/*.ts``, ``src/sort/sort_dynamic.ts``,
+``src/prefix/prefix.ts`` and ``src/utils/allocate-pointcloud.ts`` so that code shaped like
+``src/trainer.ts`` drives them unchanged; ``GPUDevice / GPUBuffer / GPUTextureView / GPUCommandEncoder`` become
+``HipDevice / HipBuffer / HipEncoder``.  PyTorch appears only as the allocator for caller-owned device memory
+(point clouds, cameras, images, optimizer state) and as the owner of the HIP stream; every kernel is in
+``libwebdgs_hip.so``.  There is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+# ----------------------------------------------------------------------------- device / buffers
+class HipBuffer:
+    """A span of device memory (``GPUBuffer``): either a view into library-owned memory or a torch-backed allocation."""
+
+    def __init__(self, device: "HipDevice", ptr: int, size: int, owner: Optional[torch.Tensor] = None, label: str = ""):
+        self.device, self.ptr, self.size, self._owner, self.label = device, int(ptr or 0), int(size), owner, label
+        self.destroyed = False
+
+    def read(self, dtype=np.uint32, count: Optional[int] = None, offset: int = 0) -> np.ndarray:
+        """mapAsync + getMappedRange: synchronous copy to host."""
+        dt = np.dtype(dtype)
+        n = (self.size - offset) // dt.itemsize if count is None else int(count)
+        out = np.empty(n, dt)
+        if n:
+            check(self.device.lib.wdgs_copy_to_host(self.device.handle, out.ctypes.data, self.ptr + offset, n * dt.itemsize))
+        return out
+
+    def write(self, data: np.ndarray, offset: int = 0) -> None:
+        """queue.writeBuffer: stream-ordered."""
+        a = np.ascontiguousarray(data)
+        if a.nbytes + offset > self.size:
+            raise _lib.WdgsError(_lib.WDGS_E_INVALID, f"write of {a.nbytes} bytes at {offset} exceeds buffer size {self.size}")
+        check(self.device.lib.wdgs_copy_to_device(self.device.handle, self.ptr + offset, a.ctypes.data, a.nbytes))
+        self.device._keepalive.append(a)
+
+    def clear(self) -> None:
+        check(self.device.lib.wdgs_memset(self.device.handle, self.ptr, 0, self.size))
+
+    def tensor(self) -> torch.Tensor:
+        if self._owner is None:
+            raise _lib.StateError(_lib.WDGS_E_STATE, "buffer is library-owned; no torch tensor behind it")
+        return self._owner
+
+    def destroy(self) -> None:
+        self.destroyed = True
+        self._owner = None
+
+
+class HipEncoder:
+    """``GPUCommandEncoder``: ops enqueue on the device stream as they are encoded; ``finish()`` is a marker."""
+
+    def __init__(self, device: "HipDevice", label: str = ""):
+        self.device, self.label = device, label
+
+    def clearBuffer(self, buf: HipBuffer) -> None:
+        buf.clear()
+
+    def copyBufferToBuffer(self, src: HipBuffer, src_off: int, dst: HipBuffer, dst_off: int, size: int) -> None:
+        dst.tensor().view(torch.uint8)[dst_off:dst_off + size].copy_(src.tensor().view(torch.uint8)[src_off:src_off + size])
+
+    def finish(self) -> "HipEncoder":
+        return self
+
+
+class _Queue:
+    def __init__(self, device: "HipDevice"):
+        self.device = device
+
+    def submit(self, _cmds) -> None:  # work is already on the stream
+        return None
+
+    def onSubmittedWorkDone(self) -> None:
+        self.device.synchronize()
+
+    def writeBuffer(self, buf: HipBuffer, offset: int, data: np.ndarray) -> None:
+        buf.write(data, offset)
+
+
+class HipDevice:
+    """``GPUDevice`` + ``GPUQueue`` on one MI355X: a HIP ordinal and torch's current stream on it."""
+
+    def __init__(self, ordinal: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("webdgs_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = _lib.load()
+        self.ordinal = ordinal
+        self.torch_device = torch.device("cuda", ordinal)
+        torch.cuda.set_device(ordinal)
+        # One explicit stream shared by torch (allocations' fills, H2D copies, RCCL hand-off) and the library's kernels.
+        # torch's default stream has a NULL handle, which wdgs_device_create reads as "create your own stream" -- that
+        # would leave torch.zeros() fills unordered against our kernels -- so make a real stream current instead.
+        self.torch_stream = torch.cuda.Stream(self.torch_device)
+        torch.cuda.set_stream(self.torch_stream)
+        stream = self.torch_stream.cuda_stream
+        assert stream, "torch returned a NULL stream handle"
+        h = C.c_void_p()
+        check(self.lib.wdgs_device_create(ordinal, C.c_void_p(stream), C.byref(h)))
+        self.handle = h
+        self.queue = _Queue(self)
+        self._keepalive: list = []
+
+    def createCommandEncoder(self, label: str = "") -> HipEncoder:
+        return HipEncoder(self, label)
+
+    def createBuffer(self, size: int, label: str = "") -> HipBuffer:
+        """Zero-filled like a WebGPU buffer."""
+        t = torch.zeros(max(1, (int(size) + 3) // 4), dtype=torch.int32, device=self.torch_device)
+        return HipBuffer(self, t.data_ptr(), int(size), t, label)
+
+    def bufferFrom(self, array: np.ndarray, label: str = "") -> HipBuffer:
+        a = np.ascontiguousarray(array)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self.torch_device)
+        return HipBuffer(self, t.data_ptr(), a.nbytes, t, label)
+
+    def view(self, ptr: int, size: int, label: str = "") -> HipBuffer:
+        return HipBuffer(self, ptr, size, None, label)
+
+    def synchronize(self) -> None:
+        check(self.lib.wdgs_device_synchronize(self.handle))
+        self._keepalive.clear()
+
+    def setProfiling(self, enabled: bool) -> None:
+        check(self.lib.wdgs_device_set_profiling(self.handle, 1 if enabled else 0))
+
+    def kernelTimes(self, reset: bool = False) -> dict:
+        n = C.c_uint32(0)
+        arr = (_lib.KernelTime * 128)()
+        check(self.lib.wdgs_device_get_kernel_times(self.handle, arr, 128, C.byref(n)))
+        out = {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(min(n.value, 128))}
+        if reset:
+            check(self.lib.wdgs_device_reset_kernel_times(self.handle))
+        return out
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.lib.wdgs_device_destroy(self.handle)
+            self.handle = None
+
+
+@dataclasses.dataclass
+class PointCloud:
+    """``PointCloud`` of ``src/utils/load-pointcloud.ts:16-23``."""
+
+    type: str
+    num_points: int
+    sh_deg: int
+    gaussian_3d_buffer: HipBuffer
+    sh_buffer: HipBuffer
+
+
+def createPointCloud(device: HipDevice, gaussians: np.ndarray, sh: np.ndarray, sh_deg: int) -> PointCloud:
+    n = int(gaussians.shape[0])
+    return PointCloud("full", n, int(sh_deg), device.bufferFrom(gaussians.astype(np.uint32, copy=False), "gaussian_3d_buffer"),
+                      device.bufferFrom(sh.astype(np.uint32, copy=False), "sh_buffer"))
+
+
+def allocatePointCloudLike(device: HipDevice, template: PointCloud, options: dict) -> PointCloud:
+    """``allocatePointCloudLike`` (``src/utils/allocate-pointcloud.ts:8-44``)."""
+    n = max(1, int(options["numPoints"]))
+    tp = max(1, int(template.num_points))
+    bpg = max(1, template.gaussian_3d_buffer.size // tp)
+    bps = max(1, template.sh_buffer.size // tp)
+    return PointCloud(template.type or "normal", n, template.sh_deg or 0, device.createBuffer(n * bpg, "resized gaussian_3d_buffer"),
+                      device.createBuffer(n * bps, "resized sh_buffer"))
+
+
+# ----------------------------------------------------------------------------- scanner / sorter
+class PrefixScanner:
+    """``PrefixScanner`` (``src/prefix/prefix.ts:26-43``)."""
+
+    def __init__(self, max_elements: int, device: HipDevice):
+        self.device, self.max_elements = device, int(max_elements)
+        h = C.c_void_p()
+        check(device.lib.wdgs_prefix_scanner_create(device.handle, self.max_elements, C.byref(h)))
+        self.handle = h
+        self.input_buffer = device.view(device.lib.wdgs_prefix_scanner_input(h), 4 * self.max_elements, "prefix-input")
+        self.output_buffer = device.view(device.lib.wdgs_prefix_scanner_output(h), 4 * self.max_elements, "prefix-output")
+
+    def set_count(self, count: int) -> dict:
+        check(self.device.lib.wdgs_prefix_scanner_set_count(self.handle, int(count)))
+        return {"num_workgroups": (int(count) + 4095) // 4096}
+
+    def scan(self, encoder: Optional[HipEncoder] = None) -> None:
+        check(self.device.lib.wdgs_prefix_scanner_scan(self.handle))
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.device.lib.wdgs_prefix_scanner_destroy(self.handle)
+            self.handle = None
+
+
+def get_prefix_scanner(max_elements: int, device: HipDevice) -> PrefixScanner:
+    return PrefixScanner(max_elements, device)
+
+
+class DynamicSortStuff:
+    """``DynamicSortStuff`` (``src/sort/sort_dynamic.ts:9-24``): count comes from ``stats_buffer[0]`` on the device."""
+
+    def __init__(self, max_capacity: int, device: HipDevice, stats_buffer: HipBuffer):
+        self.device = device
+        h = C.c_void_p()
+        check(device.lib.wdgs_sorter_create(device.handle, int(max_capacity), C.c_void_p(stats_buffer.ptr), C.byref(h)))
+        self.handle = h
+        cap = device.lib.wdgs_sorter_capacity(h)
+        self.capacity = cap
+        self.ping_pong = [dict(sort_depths_buffer=device.view(device.lib.wdgs_sorter_keys(h, i), 4 * cap),
+                               sort_indices_buffer=device.view(device.lib.wdgs_sorter_values(h, i), 4 * cap)) for i in range(2)]
+        self.final_out_index = 0
+
+    def sort(self, encoder: Optional[HipEncoder] = None, key_bits: int = 32) -> None:
+        check(self.device.lib.wdgs_sorter_sort(self.handle, int(key_bits)))
+        self.final_out_index = self.device.lib.wdgs_sorter_final_out_index(self.handle)
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.device.lib.wdgs_sorter_destroy(self.handle)
+            self.handle = None
+
+
+def get_dynamic_sorter(max_capacity: int, device: HipDevice, stats_buffer: HipBuffer) -> DynamicSortStuff:
+    return DynamicSortStuff(max_capacity, device, stats_buffer)
+
+
+# ----------------------------------------------------------------------------- TiledForwardPass
+class TiledForwardPass:
+    """``TiledForwardPass`` (``src/renderers/tiled-forward-pass.ts:62-534``)."""
+
+    def __init__(self, device: HipDevice, pointCloud: PointCloud, cameraBuffer: HipBuffer, config: dict):
+        self.device, self.pointCloud, self.cameraBuffer = device, pointCloud, cameraBuffer
+        self.destroyed = False
+        cfg = _lib.TiledForwardConfig(
+            num_points=pointCloud.num_points, sh_deg=pointCloud.sh_deg, viewport_width=int(config["viewportWidth"]),
+            viewport_height=int(config["viewportHeight"]), gaussian_scale=float(config.get("gaussianScale", 1.0)),
+            point_size_px=float(config.get("pointSizePx", 3.0)), max_splat_radius_px=float(config.get("maxSplatRadiusPx", 128.0)),
+            render_mode=1 if config.get("renderMode", "gaussian") == "gaussian" else 0,
+            max_tile_entries=int(config.get("maxTileEntries", 0)), compat_caps=1 if config.get("compatCaps", False) else 0)
+        h = C.c_void_p()
+        check(device.lib.wdgs_tiled_forward_create(device.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h
+
+    def encode(self, encoder: Optional[HipEncoder] = None, options: Optional[dict] = None) -> None:
+        skip = 1 if (options or {}).get("skipSort") else 0
+        check(self.device.lib.wdgs_tiled_forward_encode(self.handle, self.pointCloud.gaussian_3d_buffer.ptr, self.pointCloud.sh_buffer.ptr,
+                                                        self.cameraBuffer.ptr, skip))
+
+    def setCameraBuffer(self, buffer: HipBuffer) -> None:
+        self.cameraBuffer = buffer
+
+    def setGaussianScale(self, value: float) -> None:
+        check(self.device.lib.wdgs_tiled_forward_set_gaussian_scale(self.handle, float(value)))
+
+    def setPointSize(self, value: float) -> None:
+        check(self.device.lib.wdgs_tiled_forward_set_point_size(self.handle, float(value)))
+
+    def setRenderMode(self, mode: str) -> None:
+        check(self.device.lib.wdgs_tiled_forward_set_render_mode(self.handle, 1 if mode == "gaussian" else 0))
+
+    def setViewport(self, width: int, height: int) -> None:
+        check(self.device.lib.wdgs_tiled_forward_set_viewport(self.handle, int(width), int(height)))
+
+    def _res(self) -> _lib.TiledForwardResources:
+        r = _lib.TiledForwardResources()
+        check(self.device.lib.wdgs_tiled_forward_get_resources(self.handle, C.byref(r)))
+        return r
+
+    def getResources(self) -> dict:
+        r, d, n = self._res(), self.device, max(1, self.pointCloud.num_points)
+        return dict(splatBuffer=d.view(r.splat_buffer, 24 * n), depthsBuffer=d.view(r.depths_buffer, 4 * n),
+                    tileKeysBuffer=d.view(r.tile_keys_buffer, 4 * r.max_tile_entries), tileIndicesBuffer=d.view(r.tile_indices_buffer, 4 * r.max_tile_entries),
+                    tileOffsetsBuffer=d.view(r.tile_offsets_buffer, 4 * n), tileCountsBuffer=d.view(r.tile_counts_buffer, 4 * n),
+                    statsBuffer=d.view(r.stats_buffer, 16), numTilesX=r.num_tiles_x, numTilesY=r.num_tiles_y, totalTiles=r.total_tiles,
+                    maxTileEntries=r.max_tile_entries, settings=np.array(list(r.settings), np.float32))
+
+    def getSortedIndicesBuffer(self) -> HipBuffer:
+        return self.getResources()["tileIndicesBuffer"]
+
+    def getSortedKeysBuffer(self) -> HipBuffer:
+        return self.getResources()["tileKeysBuffer"]
+
+    def getTileOffsetsBuffer(self) -> HipBuffer:
+        return self.getResources()["tileOffsetsBuffer"]
+
+    def getStatsBuffer(self) -> HipBuffer:
+        return self.getResources()["statsBuffer"]
+
+    def check(self) -> np.ndarray:
+        """Synchronises; raises ``CapacityError`` if the last encode overflowed ``maxTileEntries``. Returns the 4 stats words."""
+        st = (C.c_uint32 * 4)()
+        check(self.device.lib.wdgs_tiled_forward_check(self.handle, st))
+        return np.array(list(st), np.uint32)
+
+    def destroy(self) -> None:
+        if self.destroyed:
+            return
+        self.destroyed = True
+        self.device.lib.wdgs_tiled_forward_destroy(self.handle)
+        self.handle = None
+
+
+# ----------------------------------------------------------------------------- TiledRasterizer
+class TiledRasterizer:
+    """``TiledRasterizer`` (``src/renderers/tiled-rasterizer.ts:34-368``) without the swap-chain blit."""
+
+    def __init__(self, config: dict):
+        self.device: HipDevice = config["device"]
+        self.forwardPass: TiledForwardPass = config["forwardPass"]
+        self.destroyed = False
+        self.width = self.height = 0
+        h = C.c_void_p()
+        check(self.device.lib.wdgs_tiled_rasterizer_create(self.device.handle, self.forwardPass.handle, 1 if config.get("compatCaps") else 0, C.byref(h)))
+        self.handle = h
+
+    def encode(self, encoder: Optional[HipEncoder], width: int, height: int) -> None:
+        check(self.device.lib.wdgs_tiled_rasterizer_encode(self.handle, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def _get(self, fn, nbytes: int) -> HipBuffer:
+        p = C.c_void_p()
+        check(fn(self.handle, C.byref(p)))
+        return self.device.view(p.value, nbytes)
+
+    def getOutputTextureView(self) -> HipBuffer:
+        return self._get(self.device.lib.wdgs_tiled_rasterizer_get_output, 4 * self.width * self.height)
+
+    def getAlphaTextureView(self) -> HipBuffer:
+        return self._get(self.device.lib.wdgs_tiled_rasterizer_get_alpha, 4 * self.width * self.height)
+
+    def getNContribTextureView(self) -> HipBuffer:
+        return self._get(self.device.lib.wdgs_tiled_rasterizer_get_n_contrib, 4 * self.width * self.height)
+
+    def getTileOffsetsBuffer(self) -> HipBuffer:
+        tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
+        return self._get(self.device.lib.wdgs_tiled_rasterizer_get_tile_offsets, 4 * (tiles + 1))
+
+    def destroy(self) -> None:
+        if self.destroyed:
+            return
+        self.destroyed = True
+        self.device.lib.wdgs_tiled_rasterizer_destroy(self.handle)
+        self.handle = None
+
+
+# ----------------------------------------------------------------------------- TiledBackwardPass
+def _training_config(tc: Optional[dict]) -> _lib.TrainingConfig:
+    tc = tc or {}
+    return _lib.TrainingConfig(float(tc.get("lambda_l1", 0.8)), float(tc.get("lambda_l2", 0.0)), float(tc.get("lambda_dssim", 0.2)),
+                               float(tc.get("c1", 0.01 * 0.01)), float(tc.get("c2", 0.03 * 0.03)))
+
+
+class TiledBackwardPass:
+    """``TiledBackwardPass`` (``src/renderers/tiled-backward-pass.ts:71-861``)."""
+
+    def __init__(self, device: HipDevice, pointCloud: PointCloud, config: dict):
+        self.device, self.pointCloud = device, pointCloud
+        self.destroyed = False
+        self.viewportWidth, self.viewportHeight = int(config["viewportWidth"]), int(config["viewportHeight"])
+        self.trainingConfig = dict(config.get("trainingConfig") or {})
+        cfg = _lib.TiledBackwardConfig(pointCloud.num_points, pointCloud.sh_deg, self.viewportWidth, self.viewportHeight, _training_config(self.trainingConfig),
+                                       float(config.get("gaussianScale", 1.0)), float(config.get("pointSizePx", 3.0)),
+                                       float(config.get("maxSplatRadiusPx", 128.0)))
+        h = C.c_void_p()
+        check(device.lib.wdgs_tiled_backward_create(device.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def _resources(res: dict) -> _lib.TiledBackwardResources:
+        def p(k):
+            b = res.get(k)
+            return b.ptr if b is not None else None
+        return _lib.TiledBackwardResources(p("splatBuffer"), p("tileOffsetsBuffer"), p("tileIndicesBuffer"), p("cameraBuffer"), p("alphaTexture"),
+                                           p("nContribTexture"))
+
+    def encode(self, encoder: Optional[HipEncoder], predictedTexture: HipBuffer, targetTexture: HipBuffer, forwardResources: dict, options=None) -> None:
+        r = self._resources(forwardResources)
+        check(self.device.lib.wdgs_tiled_backward_encode(self.handle, predictedTexture.ptr, targetTexture.ptr, C.byref(r), self.pointCloud.gaussian_3d_buffer.ptr))
+
+    def computeLossOnly(self, encoder, predictedTexture: HipBuffer, targetTexture: HipBuffer) -> None:
+        check(self.device.lib.wdgs_tiled_backward_compute_loss_only(self.handle, predictedTexture.ptr, targetTexture.ptr))
+
+    def computeMetricMap(self, encoder, predictedTexture: HipBuffer, targetTexture: HipBuffer, options: Optional[dict] = None) -> None:
+        thr = float((options or {}).get("threshold", 0.5))
+        check(self.device.lib.wdgs_tiled_backward_compute_metric_map(self.handle, predictedTexture.ptr, targetTexture.ptr, thr))
+
+    def computeMetricCounts(self, encoder, resources: dict, options: Optional[dict] = None) -> None:
+        r = self._resources(resources)
+        clear = 1 if (options or {}).get("clear", True) else 0
+        n_inst = resources["tileIndicesBuffer"].size // 4
+        check(self.device.lib.wdgs_tiled_backward_compute_metric_counts(self.handle, C.byref(r), n_inst, clear))
+
+    def normalizeMetricCounts(self, encoder, options: dict) -> None:
+        check(self.device.lib.wdgs_tiled_backward_normalize_metric_counts(self.handle, max(1, int(options["divisor"]))))
+
+    def setViewport(self, width: int, height: int) -> None:
+        check(self.device.lib.wdgs_tiled_backward_set_viewport(self.handle, int(width), int(height)))
+        self.viewportWidth, self.viewportHeight = int(width), int(height)
+
+    def setTrainingConfig(self, next_cfg: dict) -> None:
+        self.trainingConfig.update({k: v for k, v in next_cfg.items() if v is not None})
+        tc = _training_config(self.trainingConfig)
+        check(self.device.lib.wdgs_tiled_backward_set_training_config(self.handle, C.byref(tc)))
+
+    def getGradientsBuffer(self) -> HipBuffer:
+        return self.device.view(self.device.lib.wdgs_tiled_backward_gradients(self.handle), 32 * max(1, self.pointCloud.num_points))
+
+    def getMetricCountsBuffer(self) -> HipBuffer:
+        return self.device.view(self.device.lib.wdgs_tiled_backward_metric_counts(self.handle), 4 * max(1, self.pointCloud.num_points))
+
+    def getLossTextureView(self) -> HipBuffer:
+        return self.device.view(self.device.lib.wdgs_tiled_backward_loss_image(self.handle), 16 * self.viewportWidth * self.viewportHeight)
+
+    def getMetricMapTextureView(self) -> HipBuffer:
+        return self.device.view(self.device.lib.wdgs_tiled_backward_metric_map(self.handle), 4 * self.viewportWidth * self.viewportHeight)
+
+    def getAccumulatorsBuffer(self) -> HipBuffer:
+        """INTERNAL (parity tests): i32[N*12] fixed-point accumulators of the last encode."""
+        return self.device.view(self.device.lib.wdgs_tiled_backward_accumulators(self.handle), 48 * max(1, self.pointCloud.num_points))
+
+    def getMetricMinMaxBuffer(self) -> HipBuffer:
+        return self.device.view(self.device.lib.wdgs_tiled_backward_metric_minmax(self.handle), 8)
+
+    def destroy(self) -> None:
+        if self.destroyed:
+            return
+        self.destroyed = True
+        self.device.lib.wdgs_tiled_backward_destroy(self.handle)
+        self.handle = None
+
+
+def downsampleRGBA8(device: HipDevice, src: HipBuffer, src_w: int, src_h: int, dst: HipBuffer, dst_w: int, dst_h: int) -> None:
+    """The GT down-sample render pass of ``trainer.ts:303-328`` (``blit.wgsl`` ``fs_main`` with a linear sampler)."""
+    check(device.lib.wdgs_downsample_rgba8(device.handle, src.ptr, src_w, src_h, dst.ptr, dst_w, dst_h))
+
+
+# ----------------------------------------------------------------------------- Optimizer
+DEFAULT_ADAM_HYPERPARAMETERS = dict(lr_pos=0.00016, lr_color=0.0025, lr_opacity=0.05, lr_scale=0.005, lr_rot=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8)
+_STATE_FIELDS = ("optPosBuffer", "optRotBuffer", "optScaleBuffer", "optOpacityBuffer", "paramSH", "stateSH")
+
+
+def allocateOptimizerStateBuffers(device: HipDevice, numPoints: int) -> dict:
+    """``allocateOptimizerStateBuffers`` (``src/renderers/optimizer.ts:27-38``): zero-filled."""
+    sizes = (C.c_size_t * 6)()
+    check(device.lib.wdgs_optimizer_state_sizes(int(numPoints), C.byref(sizes)))
+    return {k: device.createBuffer(sizes[i], k) for i, k in enumerate(_STATE_FIELDS)}
+
+
+def _state_struct(buffers: dict) -> _lib.OptimizerState:
+    return _lib.OptimizerState(*[buffers[k].ptr for k in _STATE_FIELDS])
+
+
+class Optimizer:
+    """``Optimizer`` (``src/renderers/optimizer.ts:40-363``)."""
+
+    def __init__(self, device: HipDevice, pointCloud: PointCloud, params: Optional[dict] = None, initialState: Optional[dict] = None):
+        self.device, self.numPoints = device, pointCloud.num_points
+        self.params = {**DEFAULT_ADAM_HYPERPARAMETERS, **(params or {})}
+        self.destroyed = False
+        hp = _lib.AdamHyperparameters(*[float(self.params[k]) for k in DEFAULT_ADAM_HYPERPARAMETERS])
+        if initialState and initialState.get("buffers"):
+            self.buffers = initialState["buffers"]  # adopted (optimizer.ts:81-88)
+            it = int(initialState.get("iteration") or 0)
+            fresh = False
+        else:
+            self.buffers = allocateOptimizerStateBuffers(device, self.numPoints)
+            it, fresh = 0, True
+        st = _state_struct(self.buffers)
+        h = C.c_void_p()
+        check(device.lib.wdgs_optimizer_create(device.handle, self.numPoints, C.byref(hp), None, None, C.byref(st), 0, it, C.byref(h)))
+        self.handle = h
+        if fresh:  # initBuffers (optimizer.ts:145-253): K20 unpack into the zero-filled state
+            check(device.lib.wdgs_optimizer_init_from_point_cloud(h, pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr))
+
+    def getIteration(self) -> int:
+        return int(self.device.lib.wdgs_optimizer_get_iteration(self.handle))
+
+    def getHyperparameters(self) -> dict:
+        return dict(self.params)
+
+    def setHyperparameters(self, next_params: dict) -> None:
+        self.params.update(next_params)
+        hp = _lib.AdamHyperparameters(*[float(self.params[k]) for k in DEFAULT_ADAM_HYPERPARAMETERS])
+        check(self.device.lib.wdgs_optimizer_set_hyperparameters(self.handle, C.byref(hp)))
+
+    def getStateBuffers(self) -> dict:
+        return self.buffers
+
+    def step(self, encoder, coefficients: PointCloud, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer) -> None:
+        check(self.device.lib.wdgs_optimizer_step(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradientsBuffer.ptr, tileCountsBuffer.ptr))
+
+    def stepF32(self, encoder, coefficients: PointCloud, gradF32: HipBuffer, visibleCounts: HipBuffer) -> None:
+        """Data-parallel step on fp32 gradients summed over views."""
+        check(self.device.lib.wdgs_optimizer_step_f32(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradF32.ptr, visibleCounts.ptr))
+
+    def destroy(self) -> None:
+        if self.destroyed:
+            return
+        self.destroyed = True
+        self.device.lib.wdgs_optimizer_destroy(self.handle)
+        self.handle = None
+
+
+def accumulateGradients(device: HipDevice, numPoints: int, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer, accF32: HipBuffer, visibleCounts: HipBuffer) -> None:
+    check(device.lib.wdgs_accumulate_gradients(device.handle, int(numPoints), gradientsBuffer.ptr, tileCountsBuffer.ptr, accF32.ptr, visibleCounts.ptr))
+
+
+# ----------------------------------------------------------------------------- DensifyPrunePass
+class DensifyPrunePass:
+    """``DensifyPrunePass`` (``src/renderers/densify-prune.ts:75-687``), strategy ``gpu_rebuild``."""
+
+    def __init__(self, device: HipDevice, config: Optional[dict] = None):
+        self.device = device
+        self.config = dict(strategy="cpu_rebuild", numViews=1, cloneThreshold=0, splitThreshold=0, pruneThreshold=0, maxNewPointsPerStep=0,
+                           maxBufferBytes=128 * 1024 * 1024)
+        self.config.update(config or {})
+        self.numPoints = 0
+        c = self._cfg()
+        h = C.c_void_p()
+        check(device.lib.wdgs_densify_prune_create(device.handle, C.byref(c), C.byref(h)))
+        self.handle = h
+
+    def _cfg(self) -> _lib.DensifyConfig:
+        c = self.config
+        return _lib.DensifyConfig(max(1, int(c.get("numViews") or 1)), max(0, int(c.get("cloneThreshold") or 0)),
+                                  float(c["splitThreshold"] if c.get("splitThreshold") is not None else 1e9), float(c.get("pruneThreshold") or 0.0),
+                                  max(0, int(c.get("maxNewPointsPerStep") or 0)), int(c.get("maxBufferBytes") or 0))
+
+    def setConfig(self, next_cfg: dict) -> None:
+        self.config.update(next_cfg)
+        c = self._cfg()
+        check(self.device.lib.wdgs_densify_prune_set_config(self.handle, C.byref(c)))
+
+    def getConfig(self) -> dict:
+        return dict(self.config)
+
+    def ensureSize(self, numPoints: int) -> None:
+        check(self.device.lib.wdgs_densify_prune_ensure_size(self.handle, int(numPoints)))
+        self.numPoints = int(numPoints)
+
+    def encodePrepare(self, encoder, inputs: dict) -> dict:
+        pc: PointCloud = inputs["pointCloud"]
+        mc = inputs.get("metricCountsBuffer")
+        out = _lib.DensifyPrepared()
+        check(self.device.lib.wdgs_densify_prune_encode_prepare(self.handle, pc.num_points, pc.gaussian_3d_buffer.ptr, mc.ptr if mc is not None else None, C.byref(out)))
+        self.numPoints = pc.num_points
+        n, d = max(1, pc.num_points), self.device
+        return dict(actionBuffer=d.view(out.action_buffer, 4 * n), outCountBuffer=d.view(out.out_count_buffer, 4 * n),
+                    outOffsetBuffer=d.view(out.out_offset_buffer, 4 * n), outTotalBuffer=d.view(out.out_total_buffer, 4), maxOutPoints=int(out.max_out_points))
+
+    def readTotal(self) -> int:
+        t = C.c_uint32(0)
+        check(self.device.lib.wdgs_densify_prune_read_total(self.handle, C.byref(t)))
+        return int(t.value)
+
+    def encodeScatter(self, encoder, inputs: dict, outputs: dict) -> None:
+        pc: PointCloud = inputs["pointCloud"]
+        out_pc: PointCloud = outputs["outPointCloud"]
+        out_n = int(inputs["outNumPoints"])
+        if out_pc.num_points != out_n:
+            raise _lib.WdgsError(_lib.WDGS_E_INVALID, f"encodeScatter: outPointCloud.num_points ({out_pc.num_points}) != outNumPoints ({out_n})")
+        in_st, out_st = inputs.get("optimizerState"), outputs.get("outOptimizerState")
+        a = C.byref(_state_struct(in_st)) if in_st else None
+        b = C.byref(_state_struct(out_st)) if out_st else None
+        check(self.device.lib.wdgs_densify_prune_encode_scatter(self.handle, pc.num_points, pc.gaussian_3d_buffer.ptr, pc.sh_buffer.ptr, a, out_n,
+                                                                1 if inputs.get("resetNewOptimizerState", True) else 0, out_pc.gaussian_3d_buffer.ptr,
+                                                                out_pc.sh_buffer.ptr, b))
+
+    def applyActions(self, *_a, **_k):
+        raise NotImplementedError("DensifyPrunePass.applyActions is unimplemented in the reference (densify-prune.ts:680-686)")
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.device.lib.wdgs_densify_prune_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,66 @@
+"""View-sharded data parallelism over RCCL/xGMI; the reference has none (batch 1, one GPUDevice).
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm; ``gloo`` in CPU tests).  Every rank holds
+a full replica of the point cloud and optimizer state.  A global step processes ``world_size * views_per_rank`` views:
+each rank renders and back-propagates its own views, sums the per-view fp16 gradients into one fp32 block locally
+(after K17, so per-view values are exactly the reference's), then ONE all-reduce (sum) of that block plus the u32
+visibility counts precedes a single Adam step that every rank applies identically -- replicas stay bit-identical
+because all ranks consume the same reduced buffer.  Batch semantics (new; reduce to the reference at batch 1):
+``g = sum_views g_view``; Adam runs where ``sum_views (tile_counts > 0) > 0``.
+
+Payload: 14 f32 + 1 u32 = 60 B per Gaussian (c3: 60 MB): one fp32 all-reduce of the gradient block and one int32
+all-reduce of the visibility counts (4 B per Gaussian) -- integer so the mask is exact for any number of views.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+GRAD_FLOATS = 14  # pos3, opacity, rot4, log-sigma3, rgb3 (GaussianGradient component order)
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
+    """Initialises the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_views(view_ids: Sequence[int], rank: int, world: int) -> list[int]:
+    """The views of one global batch that ``rank`` processes: a strided split (views rank, rank+world, ...).
+
+    Every view is assigned to exactly one rank; ranks differ by at most one view.
+    """
+    return [v for i, v in enumerate(view_ids) if i % world == rank]
+
+
+def allreduce_gradients(grad_f32: torch.Tensor, visible_i32: torch.Tensor, group=None) -> None:
+    """Sums the ``[N*14]`` fp32 gradient block and the ``[N]`` int32 visibility counts over all ranks, in place."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(grad_f32, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(visible_i32, op=dist.ReduceOp.SUM, group=group)
+
+
+def allreduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
+    """Sums integer per-Gaussian counters (densify metric counts) over all ranks, in place."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
