@@ -427,3 +427,11 @@ void orc_rasterize(const f32* settings_f, const u32* tile_info, const u32* splat
 }
 
 }  // extern "C"
+
+// ---- test hooks for tests/test_oracle_math.py (dmath accuracy vs libm, fp16 conversions vs numpy)
+extern "C" {
+void orc_test_exp(u32 n, const f32* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = wd_exp(in[i]); }
+void orc_test_log(u32 n, const f32* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = wd_log(in[i]); }
+void orc_test_f32_to_f16(u32 n, const f32* in, uint16_t* out) { for (u32 i = 0; i < n; i++) out[i] = f32_to_f16(in[i]); }
+void orc_test_f16_to_f32(u32 n, const uint16_t* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = f16_to_f32(in[i]); }
+}

@@ -1,0 +1,7 @@
+"""webdgs_amd -- MI355X-native hot path of krispy-kenay/WebDGS (differentiable 3D Gaussian splatting).
+
+``csrc/`` holds the HIP kernels and the C ABI (``include/webdgs.h`` -> ``lib/libwebdgs_hip.so``); ``ops`` mirrors the
+reference's operator classes over that ABI; ``trainer`` mirrors ``src/trainer.ts``; ``parallel`` adds view-sharded data
+parallelism over RCCL; ``synth`` fabricates the seeded scenes of SURVEY.md section 8(d).
+"""
+__all__ = ["ops", "trainer", "parallel", "synth"]
