@@ -1,0 +1,33 @@
+// node bindings/napi/smoke.js [gpu] -- loads the addon; with "gpu" runs one forward+rasterize of a tiny scene.
+const path = require('path');
+const addon = require(path.join(__dirname, 'webdgs_napi.node'));
+if (addon.abiVersion() !== 1) { console.error('bad ABI version'); process.exit(1); }
+const names = Object.keys(addon);
+if (names.length < 25) { console.error('missing exports', names); process.exit(1); }
+if (process.argv[2] === 'gpu') {
+  const dev = addon.deviceCreate(0);
+  const n = 64, W = 64, H = 48;
+  // 12 fp16 per Gaussian: a grid of small opaque splats at z = 4 in front of an identity camera
+  const g = new Uint16Array(n * 12), sh = new Uint16Array(n * 48);
+  const f16 = (x) => { const f = new Float32Array([x]), u = new Uint32Array(f.buffer)[0]; const s = (u >> 16) & 0x8000, e = ((u >> 23) & 0xff) - 112, m = (u >> 13) & 0x3ff; return e <= 0 ? s : (s | (e << 10) | m); };
+  for (let i = 0; i < n; i++) { const o = i * 12; g[o] = f16(((i % 8) - 3.5) * 0.25); g[o + 1] = f16((Math.floor(i / 8) - 3.5) * 0.2); g[o + 2] = f16(4); g[o + 3] = f16(2);
+    g[o + 4] = f16(1); g[o + 8] = g[o + 9] = g[o + 10] = f16(-3); sh[i * 48] = f16(1.5); }
+  const cam = new Float32Array(68); [0, 5, 10, 15, 16, 21, 26, 31].forEach((k) => { cam[k] = 1; });
+  const fy = 60, zn = 0.01, zf = 100; cam[32] = 2 * fy / W; cam[37] = -2 * fy / H; cam[42] = zf / (zf - zn); cam[43] = 1; cam[46] = -zf * zn / (zf - zn);
+  cam[64] = W; cam[65] = H; cam[66] = fy; cam[67] = fy;
+  const gb = addon.bufferCreate(dev, g.byteLength), sb = addon.bufferCreate(dev, sh.byteLength), cb = addon.bufferCreate(dev, 272);
+  addon.copyToDevice(dev, gb.ptr, g); addon.copyToDevice(dev, sb.ptr, sh); addon.copyToDevice(dev, cb.ptr, cam);
+  const fwd = addon.tiledForwardCreate(dev, { numPoints: n, shDeg: 0, viewportWidth: W, viewportHeight: H });
+  const rast = addon.tiledRasterizerCreate(dev, fwd);
+  addon.tiledForwardEncode(fwd, gb.ptr, sb.ptr, cb.ptr, 0);
+  addon.tiledRasterizerEncode(rast, W, H);
+  addon.deviceSynchronize(dev);
+  const img = new Uint8Array(addon.copyToHost(dev, addon.tiledRasterizerGet(rast, 0), W * H * 4));
+  let lit = 0; for (let i = 0; i < W * H; i++) if (img[i * 4] > 0) lit++;
+  const stats = new Uint32Array(addon.copyToHost(dev, addon.tiledForwardGetResources(fwd).statsBuffer, 16));
+  console.log(`napi gpu smoke: E=${stats[0]} visible=${stats[1]} lit pixels=${lit}`);
+  if (stats[1] !== n || lit === 0) process.exit(1);
+  addon.tiledRasterizerDestroy(rast); addon.tiledForwardDestroy(fwd);
+  [gb, sb, cb].forEach((b) => addon.bufferDestroy(b.handle)); addon.deviceDestroy(dev);
+}
+console.log('napi smoke ok:', names.length, 'exports');
