@@ -55,6 +55,7 @@ typedef struct wdgs_tiled_rasterizer wdgs_tiled_rasterizer;
 typedef struct wdgs_tiled_backward wdgs_tiled_backward;
 typedef struct wdgs_optimizer wdgs_optimizer;
 typedef struct wdgs_densify_prune wdgs_densify_prune;
+typedef struct wdgs_command_buffer wdgs_command_buffer;
 
 const char* wdgs_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
@@ -77,6 +78,18 @@ typedef struct wdgs_kernel_time {
 } wdgs_kernel_time;
 int wdgs_device_get_kernel_times(wdgs_device* dev, wdgs_kernel_time* out, uint32_t cap, uint32_t* count);
 int wdgs_device_reset_kernel_times(wdgs_device* dev);
+
+/* ---------------------------------------------------------------- recorded command buffers (hipGraph)
+ * Replaces device.createCommandEncoder() ... encoder.finish() -> GPUCommandBuffer -> queue.submit([cmd]) (trainer.ts:603-645).
+ * Between begin and end every encode call is captured into a HIP graph instead of running; wdgs_queue_submit replays it on
+ * the device's stream.  Unlike a GPUCommandBuffer the result may be submitted any number of times, as long as the buffers it
+ * was recorded against are alive (all sizes the kernels need are read on the device, so a replay adapts to new data).
+ * Calls that synchronise or allocate (copy_to_host, *_check, first-use allocations inside encode) are not allowed while
+ * recording: run one eager step first.  Per-kernel profiling is suspended inside a recording. */
+int wdgs_encoder_begin(wdgs_device* dev);
+int wdgs_encoder_finish(wdgs_device* dev, wdgs_command_buffer** out);
+int wdgs_queue_submit(wdgs_device* dev, wdgs_command_buffer* cmd);
+int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd);
 
 /* Raw device<->host copies on the device's stream (copy_to_host synchronises): mapAsync/getMappedRange
  * (trainer.ts:455-458) and queue.writeBuffer. */
@@ -249,6 +262,8 @@ int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians_dev, void* sh_de
 int wdgs_accumulate_gradients(wdgs_device* dev, uint32_t num_points, const void* gradients_dev, const void* tile_counts_dev,
                               void* acc_f32_dev, void* visible_counts_dev);
 uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op);
+/* Host-side counter only (optimizer.ts:301): call when a recorded command buffer containing step() is re-submitted. */
+int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count);
 int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out);
 int wdgs_optimizer_set_hyperparameters(wdgs_optimizer* op, const wdgs_adam_hyperparameters* params);
 int wdgs_optimizer_get_state(wdgs_optimizer* op, wdgs_optimizer_state* out); /* getStateBuffers */

@@ -96,6 +96,10 @@ SIGNATURES = {
     "wdgs_device_set_profiling": (_I, [_P, _I]),
     "wdgs_device_get_kernel_times": (_I, [_P, C.POINTER(KernelTime), _U, C.POINTER(_U)]),
     "wdgs_device_reset_kernel_times": (_I, [_P]),
+    "wdgs_encoder_begin": (_I, [_P]),
+    "wdgs_encoder_finish": (_I, [_P, C.POINTER(_P)]),
+    "wdgs_queue_submit": (_I, [_P, _P]),
+    "wdgs_command_buffer_destroy": (_I, [_P]),
     "wdgs_copy_to_host": (_I, [_P, _P, _P, _Z]),
     "wdgs_copy_to_device": (_I, [_P, _P, _P, _Z]),
     "wdgs_memset": (_I, [_P, _P, _I, _Z]),
@@ -159,6 +163,7 @@ SIGNATURES = {
     "wdgs_optimizer_step_f32": (_I, [_P, _P, _P, _P, _P]),
     "wdgs_accumulate_gradients": (_I, [_P, _U, _P, _P, _P, _P]),
     "wdgs_optimizer_get_iteration": (_U, [_P]),
+    "wdgs_optimizer_advance_iteration": (_I, [_P, _U]),
     "wdgs_optimizer_get_hyperparameters": (_I, [_P, C.POINTER(AdamHyperparameters)]),
     "wdgs_optimizer_set_hyperparameters": (_I, [_P, C.POINTER(AdamHyperparameters)]),
     "wdgs_optimizer_get_state": (_I, [_P, C.POINTER(OptimizerState)]),

@@ -155,6 +155,7 @@ static int collect_profile(wdgs_device* d) {
 
 int wdgs_device_synchronize(wdgs_device* d) {
     WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_synchronize: null device");
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_synchronize while recording a command buffer");
     WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
     WDGS_CHECK_HIP(hipStreamSynchronize(d->stream));
     collect_profile(d);
@@ -207,8 +208,48 @@ int wdgs_device_reset_kernel_times(wdgs_device* d) {
     return WDGS_OK;
 }
 
+// ---------------------------------------------------------------- recorded command buffers
+struct wdgs_command_buffer_impl { hipGraph_t graph; hipGraphExec_t exec; };
+
+int wdgs_encoder_begin(wdgs_device* d) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_encoder_begin: a recording is already open on this device");
+    WDGS_CHECK_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed));
+    d->capturing = true;
+    return WDGS_OK;
+}
+int wdgs_encoder_finish(wdgs_device* d, wdgs_command_buffer** out) {
+    WDGS_REQUIRE(d && out, WDGS_E_INVALID, "null argument");
+    WDGS_REQUIRE(d->capturing, WDGS_E_STATE, "wdgs_encoder_finish without wdgs_encoder_begin");
+    d->capturing = false;
+    hipGraph_t graph = nullptr;
+    WDGS_CHECK_HIP(hipStreamEndCapture(d->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); wdgs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return WDGS_E_HIP; }
+    auto* c = new wdgs_command_buffer_impl{graph, exec};
+    *out = reinterpret_cast<wdgs_command_buffer*>(c);
+    return WDGS_OK;
+}
+int wdgs_queue_submit(wdgs_device* d, wdgs_command_buffer* cmd) {
+    WDGS_REQUIRE(d && cmd, WDGS_E_INVALID, "null argument");
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_submit while recording");
+    auto* c = reinterpret_cast<wdgs_command_buffer_impl*>(cmd);
+    WDGS_CHECK_HIP(hipGraphLaunch(c->exec, d->stream));
+    return WDGS_OK;
+}
+int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd) {
+    if (!cmd) return WDGS_OK;
+    auto* c = reinterpret_cast<wdgs_command_buffer_impl*>(cmd);
+    (void)hipGraphExecDestroy(c->exec);
+    (void)hipGraphDestroy(c->graph);
+    delete c;
+    return WDGS_OK;
+}
+
 int wdgs_copy_to_host(wdgs_device* d, void* dst, const void* src, size_t bytes) {
     WDGS_REQUIRE(d && (bytes == 0 || (dst && src)), WDGS_E_INVALID, "wdgs_copy_to_host: null argument");
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_copy_to_host while recording a command buffer");
     if (bytes == 0) return WDGS_OK;
     WDGS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
     WDGS_CHECK_HIP(hipStreamSynchronize(d->stream));
@@ -470,6 +511,7 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
     wdgs_device* d = op->dev;
     const TileInfo& ti = f->tile_info;
     if (width != op->width || height != op->height) {  // ensureTextures (tiled-rasterizer.ts:244-306)
+        WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledRasterizer.encode allocates its textures on first use: run one eager encode before recording");
         (void)hipStreamSynchronize(d->stream);
         free_dev(op->rgba8); free_dev(op->alpha); free_dev(op->n_contrib);
         op->rgba8 = nullptr; op->alpha = nullptr; op->n_contrib = nullptr;
@@ -481,6 +523,7 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
         op->height = height;
     }
     if (ti.total_tiles + 1 > op->ranges_capacity) {
+        WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledRasterizer.encode allocates its range table on first use: run one eager encode before recording");
         (void)hipStreamSynchronize(d->stream);
         free_dev(op->ranges);
         op->ranges = nullptr;
@@ -690,6 +733,11 @@ int wdgs_accumulate_gradients(wdgs_device* d, uint32_t n, const void* gradients,
     return launch_accumulate_gradients(d, n, gradients, tile_counts, acc, visible);
 }
 uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op) { return op ? op->iteration : 0; }
+int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    op->iteration += count;
+    return WDGS_OK;
+}
 int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out) {
     WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
     *out = op->params;

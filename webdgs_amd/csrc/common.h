@@ -43,6 +43,7 @@ struct wdgs_device {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
+    bool capturing = false;
     struct Pending { const char* name; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
@@ -58,13 +59,13 @@ struct KernelScope {
     const char* name;
     hipEvent_t a = nullptr, b = nullptr;
     KernelScope(wdgs_device* dev, const char* n) : d(dev), name(n) {
-        if (d->profiling) {
+        if (d->profiling && !d->capturing) {
             a = take(); b = take();
             (void)hipEventRecord(a, d->stream);
         }
     }
     ~KernelScope() {
-        if (d->profiling) {
+        if (a) {
             (void)hipEventRecord(b, d->stream);
             d->pending.push_back({name, a, b});
         }

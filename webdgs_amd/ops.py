@@ -58,11 +58,26 @@ class HipBuffer:
         self._owner = None
 
 
-class HipEncoder:
-    """``GPUCommandEncoder``: ops enqueue on the device stream as they are encoded; ``finish()`` is a marker."""
+class HipCommandBuffer:
+    """``GPUCommandBuffer`` backed by an instantiated HIP graph; unlike WebGPU's it may be submitted repeatedly."""
 
-    def __init__(self, device: "HipDevice", label: str = ""):
-        self.device, self.label = device, label
+    def __init__(self, device: "HipDevice", handle):
+        self.device, self.handle = device, handle
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.device.lib.wdgs_command_buffer_destroy(self.handle)
+            self.handle = None
+
+
+class HipEncoder:
+    """``GPUCommandEncoder``.  Eager (default): ops enqueue on the device stream as they are encoded and ``finish()`` is a
+    marker.  ``record=True``: encodes are captured into a HIP graph; ``finish()`` returns a replayable ``HipCommandBuffer``."""
+
+    def __init__(self, device: "HipDevice", label: str = "", record: bool = False):
+        self.device, self.label, self.record = device, label, record
+        if record:
+            check(device.lib.wdgs_encoder_begin(device.handle))
 
     def clearBuffer(self, buf: HipBuffer) -> None:
         buf.clear()
@@ -70,16 +85,23 @@ class HipEncoder:
     def copyBufferToBuffer(self, src: HipBuffer, src_off: int, dst: HipBuffer, dst_off: int, size: int) -> None:
         dst.tensor().view(torch.uint8)[dst_off:dst_off + size].copy_(src.tensor().view(torch.uint8)[src_off:src_off + size])
 
-    def finish(self) -> "HipEncoder":
-        return self
+    def finish(self):
+        if not self.record:
+            return self
+        h = C.c_void_p()
+        check(self.device.lib.wdgs_encoder_finish(self.device.handle, C.byref(h)))
+        return HipCommandBuffer(self.device, h)
 
 
 class _Queue:
     def __init__(self, device: "HipDevice"):
         self.device = device
 
-    def submit(self, _cmds) -> None:  # work is already on the stream
-        return None
+    def submit(self, cmds) -> None:
+        """Eager encoders have already put their work on the stream; recorded command buffers are launched here."""
+        for c in cmds or ():
+            if isinstance(c, HipCommandBuffer):
+                check(self.device.lib.wdgs_queue_submit(self.device.handle, c.handle))
 
     def onSubmittedWorkDone(self) -> None:
         self.device.synchronize()
@@ -111,8 +133,8 @@ class HipDevice:
         self.queue = _Queue(self)
         self._keepalive: list = []
 
-    def createCommandEncoder(self, label: str = "") -> HipEncoder:
-        return HipEncoder(self, label)
+    def createCommandEncoder(self, label: str = "", record: bool = False) -> HipEncoder:
+        return HipEncoder(self, label, record)
 
     def createBuffer(self, size: int, label: str = "") -> HipBuffer:
         """Zero-filled like a WebGPU buffer."""
@@ -494,6 +516,10 @@ class Optimizer:
 
     def getStateBuffers(self) -> dict:
         return self.buffers
+
+    def advanceIteration(self, count: int = 1) -> None:
+        """Bumps the host-side step counter when a recorded command buffer containing ``step`` is re-submitted."""
+        check(self.device.lib.wdgs_optimizer_advance_iteration(self.handle, int(count)))
 
     def step(self, encoder, coefficients: PointCloud, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer) -> None:
         check(self.device.lib.wdgs_optimizer_step(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradientsBuffer.ptr, tileCountsBuffer.ptr))

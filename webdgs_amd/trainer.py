@@ -23,12 +23,18 @@ from . import ops, parallel
 
 class Trainer:
     def __init__(self, device: ops.HipDevice, trainingConfig: Optional[dict] = None, seed: int = 0, world_size: int = 1, rank: int = 0,
-                 views_per_rank: int = 1, maxTileEntries: int = 0):
+                 views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True):
         self.device = device
         self.trainingConfig = dict(trainingConfig or dict(lambda_l1=0.8, lambda_l2=0.0, lambda_dssim=0.2))  # trainer.ts:100-104
         self.optimizerHyperparameters = dict(ops.DEFAULT_ADAM_HYPERPARAMETERS)
         self.world_size, self.rank, self.views_per_rank = int(world_size), int(rank), max(1, int(views_per_rank))
         self.maxTileEntries = int(maxTileEntries)
+        # Recorded command buffers (HIP graphs), one per view set: the reference re-records its encoder every step; here the
+        # recording is kept and re-submitted, because every size the kernels need is read on the device.
+        self.use_command_buffers = bool(use_command_buffers)
+        self._cmd_cache: dict = {}
+        self._eager_steps = 0
+        self._camera_buffers: list = []
         # every rank draws the same view sequence (same seed), then takes its shard
         self._rng = random.Random(seed)
 
@@ -97,16 +103,29 @@ class Trainer:
             old.gaussian_3d_buffer.destroy()
             old.sh_buffer.destroy()
         self._dp_grad = self._dp_visible = None
+        self._invalidate_command_buffers()
         self.ensurePipelines(self.lastViewportWidth, self.lastViewportHeight)
+
+    def _invalidate_command_buffers(self) -> None:
+        """Recorded kernels bake pointers, viewport, hyper-parameters and loss weights: any change drops the recordings."""
+        for cmds in self._cmd_cache.values():
+            for c in cmds:
+                c.destroy()
+        self._cmd_cache = {}
+        self._eager_steps = 0
 
     def setDataset(self, cameras: list, images: list) -> None:
         self.trainCameras, self.images = list(cameras), list(images)
+        # one resident 272-byte camera block per training view (the reference rewrites a single uniform buffer every step)
+        self._camera_buffers = [self.device.bufferFrom(np.asarray(c["camera"], np.float32)) for c in self.trainCameras]
+        self._invalidate_command_buffers()
 
     def getTrainingConfig(self) -> dict:
         return dict(self.trainingConfig)
 
     def setTrainingConfig(self, next_cfg: dict) -> None:
         self.trainingConfig.update({k: v for k, v in next_cfg.items() if v is not None})
+        self._invalidate_command_buffers()
         for p in (self.backwardPass, self.metricsPass):
             if p is not None:
                 p.setTrainingConfig(next_cfg)
@@ -116,6 +135,7 @@ class Trainer:
 
     def setOptimizerHyperparameters(self, next_params: dict) -> None:
         self.optimizerHyperparameters.update(next_params)
+        self._invalidate_command_buffers()
         if self.optimizer:
             self.optimizer.setHyperparameters(next_params)
 
@@ -175,6 +195,8 @@ class Trainer:
 
     # ------------------------------------------------------------------ pipelines
     def ensurePipelines(self, width: int, height: int) -> None:
+        if (max(1, int(width)), max(1, int(height))) != (self.lastViewportWidth, self.lastViewportHeight):
+            self._invalidate_command_buffers()
         self.lastViewportWidth, self.lastViewportHeight = max(1, int(width)), max(1, int(height))
         w, h = self.lastViewportWidth, self.lastViewportHeight
         if self.forwardPass is None:
@@ -220,12 +242,13 @@ class Trainer:
 
     # ------------------------------------------------------------------ one training step
     def _encode_view(self, encoder, index: int) -> None:
-        camData, image = self.trainCameras[index], self.images[index]
-        self.cameraBuffer.write(np.asarray(camData["camera"], np.float32))  # camera.update_buffer -> queue.writeBuffer
+        image = self.images[index]
+        cam = self._camera_buffers[index]  # camera.set_preset + update_buffer (trainer.ts:583-586): the view's resident block
+        self.forwardPass.setCameraBuffer(cam)
         self.forwardPass.encode(encoder)
         self.rasterizer.encode(encoder, image["width"], image["height"])
         res = dict(splatBuffer=self.forwardPass.getResources()["splatBuffer"], tileOffsetsBuffer=self.rasterizer.getTileOffsetsBuffer(),
-                   tileIndicesBuffer=self.forwardPass.getSortedIndicesBuffer(), cameraBuffer=self.cameraBuffer,
+                   tileIndicesBuffer=self.forwardPass.getSortedIndicesBuffer(), cameraBuffer=cam,
                    alphaTexture=self.rasterizer.getAlphaTextureView(), nContribTexture=self.rasterizer.getNContribTextureView())
         self.backwardPass.encode(encoder, self.rasterizer.getOutputTextureView(), image["texture"], res)
 
@@ -244,27 +267,49 @@ class Trainer:
         warmup, interval, stop = s["warmupIterations"], max(1, s["interval"]), s["stopIterations"]
         shouldDensify = s["enabled"] and warmup <= nextIteration <= stop and (nextIteration == warmup or (nextIteration - warmup) % interval == 0)
 
-        encoder = self.device.createCommandEncoder("trainer-step")
         tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
-        if n_views == 1:
-            self._encode_view(encoder, mine[0])
-            self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
+        key = tuple(mine)
+        cmds = self._cmd_cache.get(key)
+        if cmds is None:
+            # the first steps run eagerly (they allocate textures); afterwards each view set is recorded once and replayed
+            record = self.use_command_buffers and self._eager_steps >= 1
+            encoder = self.device.createCommandEncoder("trainer-step", record=record)
+            if n_views == 1:
+                self._encode_view(encoder, mine[0])
+                self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
+                cmds = [encoder.finish()]
+                self.device.queue.submit(cmds)
+            else:
+                n = self.pointCloud.num_points
+                if self._dp_grad is None:
+                    self._dp_grad = self.device.createBuffer(4 * parallel.GRAD_FLOATS * n, "dp-grad-f32")
+                    self._dp_visible = self.device.createBuffer(4 * n, "dp-visible")
+                    if record:  # allocation happened inside an open recording: restart it cleanly
+                        encoder.finish().destroy()
+                        encoder = self.device.createCommandEncoder("trainer-step", record=True)
+                encoder.clearBuffer(self._dp_grad)
+                encoder.clearBuffer(self._dp_visible)
+                for v in mine:
+                    self._encode_view(encoder, v)
+                    ops.accumulateGradients(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts, self._dp_grad, self._dp_visible)
+                first = encoder.finish()
+                self.device.queue.submit([first])
+                self._allreduce()
+                encoder2 = self.device.createCommandEncoder("trainer-step-adam", record=record)
+                self.optimizer.stepF32(encoder2, self.pointCloud, self._dp_grad, self._dp_visible)
+                second = encoder2.finish()
+                self.device.queue.submit([second])
+                cmds = [first, second]
+            if record:
+                self._cmd_cache[key] = cmds
+            else:
+                self._eager_steps += 1
         else:
-            n = self.pointCloud.num_points
-            if self._dp_grad is None:
-                self._dp_grad = self.device.createBuffer(4 * parallel.GRAD_FLOATS * n, "dp-grad-f32")
-                self._dp_visible = self.device.createBuffer(4 * n, "dp-visible")
-            self._dp_grad.clear()
-            self._dp_visible.clear()
-            for v in mine:
-                self._encode_view(encoder, v)
-                ops.accumulateGradients(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts, self._dp_grad, self._dp_visible)
-            g = self._dp_grad.tensor().view(torch.float32)[: parallel.GRAD_FLOATS * n]
-            vis = self._dp_visible.tensor()[:n]
-            parallel.allreduce_gradients(g, vis)
-            self.optimizer.stepF32(encoder, self.pointCloud, self._dp_grad, self._dp_visible)
-
-        self.device.queue.submit([encoder.finish()])
+            self.device.queue.submit([cmds[0]])
+            if len(cmds) > 1:
+                self._allreduce()
+                self.device.queue.submit([cmds[1]])
+            self.optimizer.advanceIteration(1)
         self.device.queue.onSubmittedWorkDone()
 
         self.iteration += 1
@@ -278,6 +323,12 @@ class Trainer:
                 self.applyPointCloudSwap(req)
         if self.iteration >= self.maxIterations:
             self.stop()
+
+    def _allreduce(self) -> None:
+        n = self.pointCloud.num_points
+        g = self._dp_grad.tensor().view(torch.float32)[: parallel.GRAD_FLOATS * n]
+        vis = self._dp_visible.tensor()[:n]
+        parallel.allreduce_gradients(g, vis)
 
     # ------------------------------------------------------------------ densify / prune
     def runDensifyPruneMultiView(self) -> None:
