@@ -1,11 +1,16 @@
 // Stable LSD radix sort of (key u32, value u32) pairs with a device-resident element count, and the per-tile range
 // table built from the sorted keys.
 //
-// Replaces src/sort/sort_dynamic.ts + radix_sort.wgsl (K7-K11: 4 x 8-bit passes, decoupled look-back, a 32-lane
-// lock-step assumption in its rank loop -- SURVEY section 5 "race detection") and src/shaders/tile-ranges.wgsl (K12-K13:
-// E atomicMins).  Here every pass is histogram -> scan -> scatter over 4096-key partitions; ranks come from wave64
-// ballots (no lock-step assumption), only the significant digits are sorted, and the range table is a boundary
-// detect with plain stores.  HBM traffic per pass: 4E (histogram) + 16E (scatter); ranges: 4E + 4(T+1).
+// Replaces src/sort/sort_dynamic.ts + radix_sort.wgsl (K7-K11: 4 x 8-bit passes with decoupled look-back whose rank
+// loop assumes 32 lanes run in lock-step -- SURVEY section 5) and src/shaders/tile-ranges.wgsl (K12-K13: E atomicMins).
+//
+// Per significant 8-bit digit (reduce-then-scan; a decoupled look-back variant was measured slower here, because at
+// E ~ 6 M all ~1500 partitions are co-resident and every one walks hundreds of unfinished predecessors):
+//   sort_hist      per-partition digit counts: 16-byte key loads, wave-private LDS bins -> counts[digit][partition]
+//   sort_scan_rows one workgroup per digit: exclusive scan of its row over the ACTIVE partitions (count read on device)
+//   sort_scan_base exclusive scan of the 256 row totals
+//   sort_scatter   ranks by wave64 ballot match (stable: order = wave, round, lane = input order) and scatters
+// HBM traffic per pass: 4E (hist) + 16E (scatter); ranges: 4E + 4(T+1).  Only digits that can be non-zero are sorted.
 #include "common.h"
 
 namespace {
@@ -16,28 +21,94 @@ constexpr u32 SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per partition
 constexpr u32 RADIX = 256;
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 shift,
-                                                                 u32 num_parts, u32* __restrict__ hist /*[RADIX][num_parts]*/) {
-    __shared__ u32 lh[RADIX];
+                                                                 u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/) {
+    __shared__ u32 lh[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
     const u32 base = part * SORT_TILE;
-    lh[threadIdx.x] = 0;
+    if (base >= count) return;
+    const u32 wave = threadIdx.x >> 6;
+#pragma unroll
+    for (u32 w = 0; w < SORT_THREADS / 64; w++) lh[w][threadIdx.x] = 0;
     __syncthreads();
-    if (base < count) {
-#pragma unroll 4
+    if (base + SORT_TILE <= count) {
+#pragma unroll
+        for (u32 j = 0; j < SORT_ITEMS / 4; j++) {
+            const uint4 q = *reinterpret_cast<const uint4*>(keys + base + (j * SORT_THREADS + threadIdx.x) * 4u);
+            atomicAdd(&lh[wave][(q.x >> shift) & 0xFFu], 1u);
+            atomicAdd(&lh[wave][(q.y >> shift) & 0xFFu], 1u);
+            atomicAdd(&lh[wave][(q.z >> shift) & 0xFFu], 1u);
+            atomicAdd(&lh[wave][(q.w >> shift) & 0xFFu], 1u);
+        }
+    } else {
         for (u32 j = 0; j < SORT_ITEMS; j++) {
             const u32 i = base + j * SORT_THREADS + threadIdx.x;
-            if (i < count) atomicAdd(&lh[(keys[i] >> shift) & (RADIX - 1u)], 1u);
+            if (i < count) atomicAdd(&lh[wave][(keys[i] >> shift) & 0xFFu], 1u);
         }
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * num_parts + part] = lh[threadIdx.x];
+    counts[(size_t)threadIdx.x * num_parts + part] = lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
+}
+
+// One workgroup per digit: in-place exclusive scan of counts[digit][0 .. active_parts), row total -> totals[digit].
+__global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ counts, const u32* __restrict__ count_ptr, u32 num_parts,
+                                                              u32* __restrict__ totals) {
+    __shared__ u32 s_w[4];
+    const u32 active = (*count_ptr + SORT_TILE - 1u) / SORT_TILE;
+    u32* row = counts + (size_t)blockIdx.x * num_parts;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32 carry = 0;
+    for (u32 base = 0; base < active; base += 1024u) {
+        const u32 i0 = base + threadIdx.x * 4u;
+        u32 x[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) x[j] = (i0 + j < active) ? row[i0 + j] : 0u;
+        const u32 tsum = x[0] + x[1] + x[2] + x[3];
+        u32 inc = tsum;
+#pragma unroll
+        for (u32 d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63u) s_w[wave] = inc;
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+#pragma unroll
+        for (u32 w = 0; w < 4; w++) { const u32 v = s_w[w]; if (w < wave) woff += v; tot += v; }
+        __syncthreads();
+        u32 run = carry + woff + inc - tsum;
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) {
+            if (i0 + j < active) row[i0 + j] = run;
+            run += x[j];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(RADIX) void sort_scan_base_kernel(u32* __restrict__ totals) {
+    __shared__ u32 s_w[4];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 v = totals[threadIdx.x];
+    u32 inc = v;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63u) s_w[wave] = inc;
+    __syncthreads();
+    u32 woff = 0;
+#pragma unroll
+    for (u32 w = 0; w < 4; w++) if (w < wave) woff += s_w[w];
+    totals[threadIdx.x] = woff + inc - v;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                     u32* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                                     const u32* __restrict__ count_ptr, u32 shift, u32 num_parts,
-                                                                    const u32* __restrict__ offsets /*scanned hist*/) {
+                                                                    const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_base) {
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
@@ -58,6 +129,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         const bool valid = i < count;
         k[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
         v[j] = valid ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (u32 j = 0; j < SORT_ITEMS; j++) {
+        const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
+        const bool valid = i < count;
         const u32 digit = (k[j] >> shift) & (RADIX - 1u);
         unsigned long long m = __ballot(valid);
 #pragma unroll
@@ -76,7 +152,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     __syncthreads();
     {   // turn per-wave counts into global base addresses: digit d, waves in order
         const u32 d = threadIdx.x;
-        u32 run = offsets[(size_t)d * num_parts + part];
+        u32 run = digit_base[d] + offsets[(size_t)d * num_parts + part];
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) {
             const u32 c = whist[w][d];
@@ -123,8 +199,8 @@ struct wdgs_sorter {
     const u32* count_ptr;
     u32* keys[2];
     u32* vals[2];
-    u32* hist;          // [RADIX * num_parts], scanned in place
-    ScanScratch scan;
+    u32* counts;        // [RADIX][num_parts], scanned in place per pass
+    u32* totals;        // [RADIX]
     int final_out_index;
 };
 
@@ -132,6 +208,7 @@ extern "C" {
 
 int wdgs_sorter_create(wdgs_device* dev, uint32_t max_capacity, const void* stats_dev, wdgs_sorter** out) {
     WDGS_REQUIRE(dev && out && stats_dev, WDGS_E_INVALID, "wdgs_sorter_create: null argument");
+    WDGS_REQUIRE(max_capacity <= 0xFFFFF000u, WDGS_E_CAPACITY, "sorter capacity %u too large", max_capacity);
     wdgs_sorter* s = new wdgs_sorter();
     s->dev = dev;
     s->capacity = (u32)align_up(max_capacity > 0 ? max_capacity : 1, SORT_TILE);
@@ -139,14 +216,15 @@ int wdgs_sorter_create(wdgs_device* dev, uint32_t max_capacity, const void* stat
     s->count_ptr = (const u32*)stats_dev;
     s->final_out_index = 0;
     for (int i = 0; i < 2; i++) { s->keys[i] = nullptr; s->vals[i] = nullptr; }
-    s->hist = nullptr;
+    s->counts = nullptr;
+    s->totals = nullptr;
     int r = WDGS_OK;
     for (int i = 0; i < 2 && r == WDGS_OK; i++) {
         r = wdgs_alloc((void**)&s->keys[i], sizeof(u32) * (size_t)s->capacity, true, dev->stream);
         if (r == WDGS_OK) r = wdgs_alloc((void**)&s->vals[i], sizeof(u32) * (size_t)s->capacity, true, dev->stream);
     }
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&s->hist, sizeof(u32) * (size_t)RADIX * s->num_parts, true, dev->stream);
-    if (r == WDGS_OK) r = scan_scratch_create(&s->scan, RADIX * s->num_parts);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&s->counts, sizeof(u32) * (size_t)RADIX * s->num_parts, true, dev->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&s->totals, sizeof(u32) * RADIX, true, dev->stream);
     if (r != WDGS_OK) { wdgs_sorter_destroy(s); return r; }
     *out = s;
     return WDGS_OK;
@@ -158,8 +236,8 @@ int wdgs_sorter_destroy(wdgs_sorter* s) {
         if (s->keys[i]) (void)hipFree(s->keys[i]);
         if (s->vals[i]) (void)hipFree(s->vals[i]);
     }
-    if (s->hist) (void)hipFree(s->hist);
-    scan_scratch_destroy(&s->scan);
+    if (s->counts) (void)hipFree(s->counts);
+    if (s->totals) (void)hipFree(s->totals);
     delete s;
     return WDGS_OK;
 }
@@ -177,10 +255,11 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
     int src = 0;
     for (u32 p = 0; p < passes; p++) {
         const u32 shift = p * 8u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->hist);
-        WDGS_TRY(scan_exclusive_u32(dev, &s->scan, s->hist, s->hist, RADIX * s->num_parts, nullptr));
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->counts);
+        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        WDGS_LAUNCH(dev, "sort_scan_base", sort_scan_base_kernel, dim3(1), dim3(RADIX), 0, s->totals);
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->hist);
+                    s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->counts, s->totals);
         src ^= 1;
     }
     WDGS_CHECK_HIP(hipGetLastError());
