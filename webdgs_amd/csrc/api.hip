@@ -7,7 +7,7 @@
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
 int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*);
-int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*);
+int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*, void*);
 int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
 int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
@@ -66,7 +66,7 @@ struct wdgs_tiled_forward {
     wdgs_tiled_forward_config cfg;
     RenderSettings settings;
     TileInfo tile_info;
-    u32* stats;   // {total_tile_entries, visible_gaussians, overflow (0 or requested total), pad}
+    u32* stats;   // {total_tile_entries, visible_gaussians, overflow (0 or requested total), pad} + 64 visible-count shards
     u32* splats;
     u32* depths;
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
@@ -382,7 +382,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
                                   cfg->max_splat_radius_px != 0.f ? cfg->max_splat_radius_px : 128.0f};
     op->tile_info.max_tile_entries = (u32)cap;
     forward_set_viewport(op, cfg->viewport_width, cfg->viewport_height);
-    int r = wdgs_alloc((void**)&op->stats, 16, true, d->stream);
+    int r = wdgs_alloc((void**)&op->stats, 16 + 64 * 4, true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->splats, (size_t)24 * std::max(n, 1u), true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * std::max(n, 1u), true, d->stream);
     if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, std::max(n, 1u), &op->scanner);
@@ -418,9 +418,9 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     wdgs_device* d = op->dev;
     const u32 n = op->cfg.num_points;
     WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16, d->stream));  // clearBuffer(pipelineStatsBuffer), tiled-forward-pass.ts:345
-    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats));
+    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4));
     WDGS_TRY(scan_exclusive_u32(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr));
-    WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats));
+    WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4));
     WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->settings, op->tile_info, wdgs_sorter_keys(op->sorter, 0),
                          wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
     if (!skip_sort) {

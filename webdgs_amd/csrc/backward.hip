@@ -1,163 +1,17 @@
-// Backward rasterization (K16) and per-Gaussian geometry backward (K17).
+// Per-Gaussian geometry backward (K17): chain rule from (mean2D, conic, opacity, colour) gradients to mean3D, log-scale,
+// quaternion and raw opacity; colour passes through.
 //
-// K16 replaces backward_rasterize_main (src/shaders/tiled-backward-rasterize.wgsl:34-172): per pixel, back to front
-// over its first n_contrib tile entries, with every lane re-loading the splat from global memory and issuing 9 global
-// fixed-point atomics per contributing (pixel, splat) pair -- the reference's dominant cost.  Here one workgroup
-// walks a tile: splats are staged in LDS once per 256-entry batch, each wave owns an 8x8 pixel block and skips
-// splats none of its pixels touches, and the 9 per-pixel contributions are summed across the wave in registers
-// (DPP row reduce + readlane) before ONE 36-byte atomic per (wave, splat).  The contributions keep the reference's
-// semantics exactly: each is truncated to i32 at x1e6 per pixel (common.wgsl:113-116), and integer addition is
-// order-free, so the result is bit-reproducible and equal to the oracle's.
-// Bound: fp32 VALU issue (exp, one IEEE division, about 45 further lane-ops per contributing pair).
-//
-// K17 replaces main_geometry_backward (src/shaders/tiled-backward.wgsl:41-298): N-wide, HBM-bound
-// (24 B Gaussian + 48 B accumulators in, 32 B packed gradient out).
+// Replaces main_geometry_backward (src/shaders/tiled-backward.wgsl:41-298): N-wide, HBM-bound (24 B Gaussian + 48 B
+// accumulators in, 32 B packed fp16 gradient out), runs on culled Gaussians too.  The reference's quirks are
+// kept: W = view3x3 here vs its transpose in the forward (Q10), +0.5*viewport for both NDC axes (Q11), fp16 output (Q13).
 #include "common.h"
 #include "wgslm.h"
 
 namespace {
 
-constexpr u32 BATCH = 256;
-constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity, rgb, 3 pad
+constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity, rgb, 3 pad (backward_raster.hip)
 
-WD_DEV int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }       // quad_perm [1,0,3,2]
-WD_DEV int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }       // quad_perm [2,3,0,1]
-WD_DEV int dpp_half_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); }
-WD_DEV int dpp_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); }
-
-// Sum of v over the 64 lanes, returned wave-uniform (wrapping i32 arithmetic).
-WD_DEV int wave_sum(int v) {
-    v += dpp_xor1(v);
-    v += dpp_xor2(v);
-    v += dpp_half_mirror(v);
-    v += dpp_mirror(v);  // every lane of a 16-lane row now holds the row sum
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-           __builtin_amdgcn_readlane(v, 48);
-}
-
-WD_DEV int to_fixed(float v) {
-    // i32(v * 1e6): truncate toward zero, saturate, NaN -> 0 -- exactly v_cvt_i32_f32.
-    const float s = v * 1000000.0f;
-    int r;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(s));
-    return r;
-}
 WD_DEV float from_fixed(int v) { return wd_div((float)v, 1000000.0f); }
-
-__global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
-                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
-                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc) {
-    __shared__ float4 s_geo[BATCH];  // centre.x, centre.y, extent.x, extent.y
-    __shared__ float4 s_con[BATCH];  // conic.x, conic.y, conic.z, opacity
-    __shared__ float4 s_col[BATCH];  // r, g, b, gaussian index (bits)
-    __shared__ u32 s_max[4];
-
-    const u32 tile_id = blockIdx.x;
-    const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
-    const u32 pixel_x = tile_x * 16u + lx, pixel_y = tile_y * 16u + ly;
-    const float vx = settings.viewport_x, vy = settings.viewport_y;
-    const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
-    const bool in_bounds = pixel_x < W && pixel_y < H;
-    const size_t p = (size_t)pixel_y * W + pixel_x;
-    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
-
-    const u32 range_start = ranges[tile_id];
-    const u32 range_end = ranges[tile_id + 1u];
-    const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
-    const u32 n_val = in_bounds ? n_contrib[p] : 0u;
-    const u32 pix_n = min(n_val, tile_entries);
-
-    // wave / block maxima of pix_n (uniform)
-    u32 wmax = pix_n;
-#pragma unroll
-    for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
-    if (lane == 0) s_max[wave] = wmax;
-    __syncthreads();
-    const u32 block_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    if (block_max == 0u) return;
-
-    float T = 0.0f;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pix_n > 0u) { T = final_T[p]; g = loss_grad[p]; }
-    const float pxf = (float)pixel_x + 0.5f, pyf = (float)pixel_y + 0.5f;
-    float ar_r = 0.f, ar_g = 0.f, ar_b = 0.f, lc_r = 0.f, lc_g = 0.f, lc_b = 0.f, la = 0.f;
-
-    for (u32 hi = block_max; hi > 0u;) {
-        const u32 lo = (hi > BATCH) ? hi - BATCH : 0u;
-        const u32 cnt = hi - lo;
-        if (threadIdx.x < cnt) {
-            const u32 gidx = instances[range_start + lo + threadIdx.x];
-            const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)gidx * 6);
-            const uint2 w01 = sp[0], w23 = sp[1], w45 = sp[2];
-            const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
-            const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-            s_geo[threadIdx.x] = make_float4(cx, cy, fminf(wd_unpack_lo(w01.y), cap), fminf(wd_unpack_hi(w01.y), cap));
-            s_con[threadIdx.x] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-            s_col[threadIdx.x] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx));
-        }
-        __syncthreads();
-        if (wmax > lo) {
-            const u32 top = min(cnt, wmax - lo);
-            for (u32 i = top; i-- > 0u;) {
-                const float4 geo = s_geo[i];
-                const float dx = pxf - geo.x, dy = pyf - geo.y;
-                const bool cand = (lo + i < pix_n) && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
-                if (!__any(cand)) continue;
-                const float4 con = s_con[i];
-                const float t1 = __builtin_fmaf(con.x, dx, (2.0f * con.y) * dy);
-                const float power = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
-                const float G = wd_exp(-0.5f * power);
-                const float og = con.w * G;
-                const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
-                const bool act = cand && !(alpha < (1.0f / 255.0f));
-                if (!__any(act)) continue;
-                const float4 col = s_col[i];
-                int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
-                if (act) {
-                    T = wd_div(T, 1.0f - alpha);
-                    ar_r = la * lc_r + (1.0f - la) * ar_r;
-                    ar_g = la * lc_g + (1.0f - la) * ar_g;
-                    ar_b = la * lc_b + (1.0f - la) * ar_b;
-                    const float aT = alpha * T;
-                    f_r = to_fixed(aT * g.x);
-                    f_g = to_fixed(aT * g.y);
-                    f_b = to_fixed(aT * g.z);
-                    float dL_dalpha = 0.0f;
-                    dL_dalpha += (col.x - ar_r) * g.x;
-                    dL_dalpha += (col.y - ar_g) * g.y;
-                    dL_dalpha += (col.z - ar_b) * g.z;
-                    dL_dalpha *= T;
-                    la = alpha; lc_r = col.x; lc_g = col.y; lc_b = col.z;
-                    const float dL_dG = con.w * dL_dalpha;
-                    f_op = to_fixed(G * dL_dalpha);
-                    const float dpow_dx = 2.0f * con.x * dx + 2.0f * con.y * dy;
-                    const float dpow_dy = 2.0f * con.z * dy + 2.0f * con.y * dx;
-                    const float mhG = -0.5f * G;
-                    const float dG_ddx = mhG * dpow_dx, dG_ddy = mhG * dpow_dy;
-                    f_mx = to_fixed(dL_dG * (-dG_ddx));
-                    f_my = to_fixed(dL_dG * (-dG_ddy));
-                    f_cx = to_fixed(dL_dG * (mhG * dx * dx));
-                    f_cy = to_fixed(dL_dG * (mhG * 2.0f * dx * dy));
-                    f_cz = to_fixed(dL_dG * (mhG * dy * dy));
-                }
-                const int s0 = wave_sum(f_mx), s1 = wave_sum(f_my), s2 = wave_sum(f_cx), s3 = wave_sum(f_cy), s4 = wave_sum(f_cz);
-                const int s5 = wave_sum(f_op), s6 = wave_sum(f_r), s7 = wave_sum(f_g), s8 = wave_sum(f_b);
-                if (lane < 9u) {
-                    int v = s0;
-                    v = lane == 1u ? s1 : v; v = lane == 2u ? s2 : v; v = lane == 3u ? s3 : v; v = lane == 4u ? s4 : v;
-                    v = lane == 5u ? s5 : v; v = lane == 6u ? s6 : v; v = lane == 7u ? s7 : v; v = lane == 8u ? s8 : v;
-                    const u32 gidx = __float_as_uint(col.w);
-                    if (v != 0) atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + lane], v);
-                }
-            }
-        }
-        __syncthreads();
-        hi = lo;
-    }
-}
 
 __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
                                                                  const u32* __restrict__ gaussians, const int* __restrict__ acc,
@@ -302,16 +156,6 @@ __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const flo
 }
 
 }  // namespace
-
-int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 num_tiles_x, u32 num_tiles_y, const void* ranges, const void* instances,
-                              const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc) {
-    const u32 tiles = num_tiles_x * num_tiles_y;
-    if (tiles == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel, dim3(tiles), dim3(256), 0, st, num_tiles_x, (const u32*)ranges, (const u32*)instances,
-                (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc);
-    WDGS_CHECK_HIP(hipGetLastError());
-    return WDGS_OK;
-}
 
 int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc, void* gradients) {
     if (n == 0) return WDGS_OK;

@@ -16,8 +16,10 @@ WD_DEV float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); 
 __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32* __restrict__ pred, const u32* __restrict__ targ,
                                                          wdgs_training_config cfg, float4* __restrict__ out) {
     __shared__ float s_lut[256];
-    __shared__ float4 sp[20][20];
-    __shared__ float4 st[20][20];
+    // row stride 32 float4 = 512 B: rows land on the same banks, so the four 16-lane groups of a ds_read_b128 (which mix two
+    // tile rows) stay conflict-free; a 20-wide row (320 B) made 59% of the LDS cycles bank conflicts.
+    __shared__ float4 sp[20][32];
+    __shared__ float4 st[20][32];
     s_lut[threadIdx.x] = wd_div((float)threadIdx.x, 255.0f);
     __syncthreads();
     const int bx = blockIdx.x * 16, by = blockIdx.y * 16;
