@@ -76,7 +76,8 @@ def main() -> None:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    dev = ops.HipDevice(local_rank)
+    # WDGS_FORCE_DEVICE (with WDGS_DIST_BACKEND=gloo): rehearse N > 1 on a single-GPU box; never set by the driver
+    dev = ops.HipDevice(int(os.environ.get("WDGS_FORCE_DEVICE", local_rank)))
 
     cfg = synth.CONFIGS[args.config]
     g, sh = synth.make_gaussians(cfg)

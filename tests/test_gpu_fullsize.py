@@ -1,0 +1,105 @@
+"""GPU: BASELINE-size workloads (1 M Gaussians, 1920x1080, SH 3) checked through size-independent properties, because
+the CPU oracle needs seconds per stage at this size: sortedness + stability, permutation, ranges partition, count
+identities, image/gradient checksums equal across runs and across submission modes, and one oracle spot check of K1."""
+import hashlib
+import subprocess
+import os
+
+import numpy as np
+import pytest
+
+from webdgs_amd import ops, synth
+
+import harness
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def c3_forward(hip_device):
+    cfg = synth.CONFIGS["c3"]
+    g, sh = synth.make_gaussians(cfg)
+    cam = synth.circle_cameras(cfg, 8)[3]
+    pipe = harness.HipPipeline(hip_device, cfg, g, sh, cam)
+    pipe.forward()
+    out = pipe.collect_forward()
+    yield cfg, g, sh, cam, pipe, out
+    pipe.destroy()
+
+
+def test_c3_forward_structure(c3_forward, orc):
+    cfg, g, sh, cam, pipe, out = c3_forward
+    counts, offsets, keys, vals, ranges = out["tile_counts"], out["tile_offsets"], out["sorted_keys"], out["sorted_values"], out["tile_ranges"]
+    e = out["total_entries"]
+    assert e > 3_000_000 and int(out["stats"][2]) == 0
+    assert int(counts.astype(np.uint64).sum()) == e
+    assert np.array_equal(offsets[1:], np.cumsum(counts.astype(np.uint64))[:-1].astype(np.uint32))
+    assert int(out["stats"][1]) == int((counts > 0).sum())
+    assert np.all(keys[:-1] <= keys[1:]), "sorted"
+    same = keys[:-1] == keys[1:]
+    assert np.all(vals[:-1][same] < vals[1:][same]), "stable: ties in ascending Gaussian index"
+    assert np.array_equal(np.bincount(vals, minlength=cfg.num_points).astype(np.uint32), counts), "permutation of the emitted entries"
+    assert np.array_equal(keys & 0xFFFF, out["depths"][vals] >> 16)
+    tile_of = (keys >> 16).astype(np.int64) - 1
+    first = np.full(cfg.total_tiles, 0xFFFFFFFF, np.uint32)
+    idx = np.flatnonzero(np.concatenate([[True], tile_of[1:] != tile_of[:-1]]))
+    first[tile_of[idx]] = idx.astype(np.uint32)
+    assert np.array_equal(ranges[:-1], first) and ranges[-1] == e
+    # K1 spot check against the oracle on the first 50k Gaussians (same camera)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    rs, rd, rc, _ = orc.project_count(g[:50_000].copy(), sh[:50_000].copy(), cam, st, ti)
+    assert np.array_equal(rc, counts[:50_000])
+    vis = rc > 0
+    assert np.array_equal(rs[vis], out["splats"][:50_000][vis]) and np.array_equal(rd[vis], out["depths"][:50_000][vis])
+    # image sanity: n_contrib never exceeds the tile's entry count; T in [0,1]
+    assert out["final_T"].min() >= 0.0 and out["final_T"].max() <= 1.0
+    per_tile = np.bincount(tile_of, minlength=cfg.total_tiles)
+    tile_max = np.zeros(cfg.total_tiles, np.int64)
+    yy, xx = np.mgrid[0:cfg.height, 0:cfg.width]
+    np.maximum.at(tile_max, (yy // 16) * cfg.tiles_x + xx // 16, out["n_contrib"].astype(np.int64))
+    assert np.all(tile_max <= per_tile)
+
+
+def test_c3_train_step_is_deterministic_and_mode_independent(hip_device):
+    """Two eager runs and one recorded (HIP graph) run of 3 training steps give identical bits: integer accumulation makes the
+    backward order-free, and the recorded command buffer replays the same kernels."""
+    cfg = synth.CONFIGS["c3"]
+    g, sh = synth.make_gaussians(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    cams = synth.circle_cameras(cfg, 2)
+    from webdgs_amd.trainer import Trainer
+    dev = hip_device
+    tp = harness.HipPipeline(dev, cfg, tg, tsh, cams[0])
+    images, cameras = [], []
+    for i in range(2):
+        tp.camera.write(cams[i]); tp.forward()
+        images.append(dict(texture=dev.bufferFrom(tp.rast.getOutputTextureView().read(np.uint8)), width=cfg.width, height=cfg.height))
+        cameras.append(dict(camera=cams[i], width=cfg.width, height=cfg.height))
+    tp.destroy()
+    digests = []
+    for use_cb in (False, False, True):
+        t = Trainer(dev, seed=5, use_command_buffers=use_cb)
+        t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg)); t.setDataset(cameras, images); t.start()
+        for _ in range(4):
+            t.step()
+        digests.append((_digest(t.pointCloud.gaussian_3d_buffer.read(np.uint32)), _digest(t.optimizer.getStateBuffers()["optPosBuffer"].read(np.uint32)),
+                        _digest(t.backwardPass.getGradientsBuffer().read(np.uint32))))
+        changed = (t.pointCloud.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6) != g).any(axis=1).sum()
+        assert changed > 50_000  # only Gaussians inside some pixel's first n_contrib entries receive a gradient (~180 k here)
+        t.applyPointCloudSwap(dict(pointCloud=ops.createPointCloud(dev, g[:10], sh[:10], cfg.sh_deg)))  # frees the big buffers
+    assert digests[0] == digests[1] == digests[2]
+
+
+def test_napi_addon_renders_on_the_gpu():
+    """The N-API binding (bindings/napi) drives the same library from node: tiny forward + composite."""
+    addon = os.path.join(ROOT, "bindings", "napi", "webdgs_napi.node")
+    if not os.path.exists(addon):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bindings", "napi")])
+    out = subprocess.run(["node", os.path.join(ROOT, "bindings", "napi", "smoke.js"), "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "napi gpu smoke: E=" in out.stdout and "visible=64" in out.stdout

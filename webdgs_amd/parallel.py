@@ -32,7 +32,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # WDGS_DIST_BACKEND=gloo lets several ranks share one GPU (functional rehearsal of the N > 1 path on a 1-GPU box)
+            backend = os.environ.get("WDGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
