@@ -167,6 +167,21 @@ def main() -> None:
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 5), traffic=None,
                         avg_ms_per_step=round(per_step[dom], 4), algorithmic_bytes=abytes,
                         note="K14/K16 are fp32-VALU-issue bound (SURVEY 8(d)); see valu_* for the binding resource")
+        # HBM traffic of that kernel from the committed PMC passes (scripts/pmc.sh -> profiles/*_pmc.json; rocprofv3 cannot be
+        # run from inside this process): FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch, same workload and kernels.
+        try:
+            import glob
+            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+            if pmcs and args.config == "c3":
+                pk = json.load(open(pmcs[-1]))["kernels"]
+                launches = {"sort": passes}.get(dom, 1)
+                names = {"sort": ("sort_hist", "sort_scan_rows", "sort_scan_base", "sort_scatter"), "scan": ("scan_reduce", "scan_block_sums", "scan_downsweep")}.get(dom, (dom,))
+                tr = sum(pk[nm]["hbm_bytes_corrected"] for nm in names if nm in pk and "hbm_bytes_corrected" in pk[nm]) * launches
+                if tr > 0:
+                    roofline["traffic"] = round(tr)
+                    roofline["traffic_source"] = os.path.basename(pmcs[-1])
+        except Exception as exc:  # a missing or malformed profile must never break the bench line
+            roofline["traffic_note"] = f"no PMC profile: {exc}"
         fwd_flops = 256.0 * e_entries * 23
         bwd_flops = 256.0 * e_entries * 12 + pairs * 60.0
         if dom in ("rasterize", "backward_rasterize"):

@@ -1,14 +1,18 @@
-// Backward rasterization (K16): dL/d{mean2D, conic, opacity, colour} per splat.
+// Backward rasterization (K16): dL/d{mean2D, conic, opacity, colour} per splat; one WAVE (64-thread workgroup) per 8x8
+// pixel block, four per 16x16 tile.
 //
 // Replaces backward_rasterize_main (src/shaders/tiled-backward-rasterize.wgsl:34-172): per pixel, back to front over its
 // first n_contrib tile entries, with every lane re-loading the splat from global memory and issuing 9 global fixed-point
-// atomics per contributing (pixel, splat) pair -- the reference's dominant cost.  Here one workgroup walks a tile:
-//   * splats are staged in LDS once per 256-entry batch (back to front);
-//   * each wave owns an 8x8 pixel block and compacts the batch to the splats that overlap the block and lie below the
-//     block's largest n_contrib (ballot + prefix popcount, order preserving);
+// atomics per contributing (pixel, splat) pair -- the reference's dominant cost.  Here:
+//   * a wave walks the entries [0, max n_contrib of its 64 pixels) back to front in chunks of 64 (lane = entry); the
+//     Gaussian index two chunks ahead and the Splat one chunk ahead are fetched into registers (latency overlaps compute);
+//   * the chunk is compacted (ballot + prefix popcount, order preserving) to the splats whose extent box overlaps the block,
+//     into 3 KB of wave-private LDS; no workgroup barrier exists, so a block with few contributors never waits for a
+//     neighbour with many;
 //   * the 9 per-pixel contributions are summed across the wave in registers by a halving butterfly
 //     (v_permlane32_swap, v_permlane16_swap, DPP row reduce: 28 VALU ops for all nine sums instead of 9 full reductions)
-//     and land in nine lanes that issue ONE atomic instruction per (wave, splat) -- instead of 9 per (pixel, splat).
+//     and land in nine lanes that issue ONE atomic instruction per (wave, splat) -- instead of 9 per (pixel, splat);
+//   * a tile's four waves run on one XCD (see raster.hip) so its entries and splats come from that XCD's L2.
 // The contributions keep the reference's semantics exactly: each is truncated to i32 at x1e6 per pixel
 // (common.wgsl:113-116) and integer addition is order-free, so the result is bit-reproducible and equal to the oracle's.
 // Bound: fp32 VALU issue (exp, one IEEE division, about 45 further lane-ops per contributing pair).
@@ -17,7 +21,6 @@
 
 namespace {
 
-constexpr u32 BATCH = 256;
 constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity, rgb, 3 pad
 
 WD_DEV int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }       // quad_perm [1,0,3,2]
@@ -53,20 +56,30 @@ WD_DEV int to_fixed(float v) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
-                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
-                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc) {
-    __shared__ float4 s_geo[BATCH];  // centre.x, centre.y, extent.x, extent.y
-    __shared__ float4 s_con[BATCH];  // conic.x, conic.y, conic.z, opacity
-    __shared__ float4 s_col[BATCH];  // r, g, b, gaussian index (bits)
-    __shared__ unsigned char s_list[4][BATCH];
-    __shared__ u32 s_max[4];
+__device__ __forceinline__ u32 xcd_contiguous_id(u32 b, u32 nblocks) {
+    const u32 q = nblocks / 8u, r = nblocks % 8u, xcd = b % 8u, local = b / 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
+}
 
-    const u32 tile_id = blockIdx.x;
+__global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
+                                                                 const u32* __restrict__ instances, const u32* __restrict__ splats,
+                                                                 const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
+                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc) {
+    __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, extent.x, extent.y
+    __shared__ float4 s_con_all[4][64];  // conic.x, conic.y, conic.z, opacity
+    __shared__ float4 s_col_all[4][64];  // r, g, b, gaussian index (bits)
+    __shared__ u32 s_pos_all[4][64];     // position of the entry in the tile's list
+
+    // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
+    // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
+    const u32 tile_id = blockIdx.x, sub = threadIdx.x >> 6;
     const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 bx = tile_x * 16u + (wave & 1u) * 8u, by = tile_y * 16u + (wave >> 1) * 8u;
+    const u32 lane = threadIdx.x & 63u;
+    float4* const s_geo = s_geo_all[sub];  // wave-private record sets
+    float4* const s_con = s_con_all[sub];
+    float4* const s_col = s_col_all[sub];
+    u32* const s_pos = s_pos_all[sub];
+    const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
     const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
@@ -82,14 +95,10 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     const u32 n_val = in_bounds ? n_contrib[p] : 0u;
     const u32 pix_n = min(n_val, tile_entries);
 
-    // wave / block maxima of pix_n (uniform)
-    u32 wmax = pix_n;
+    u32 wmax = pix_n;  // wave maximum (uniform)
 #pragma unroll
     for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
-    if (lane == 0) s_max[wave] = wmax;
-    __syncthreads();
-    const u32 block_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    if (block_max == 0u) return;
+    if (wmax == 0u) return;
 
     float T = 0.0f;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -97,101 +106,105 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     const float pxf = (float)pixel_x + 0.5f, pyf = (float)pixel_y + 0.5f;
     float ar_r = 0.f, ar_g = 0.f, ar_b = 0.f, lc_r = 0.f, lc_g = 0.f, lc_b = 0.f, la = 0.f;
 
-    for (u32 hi = block_max; hi > 0u;) {
-        const u32 lo = (hi > BATCH) ? hi - BATCH : 0u;
-        const u32 cnt = hi - lo;
-        if (threadIdx.x < cnt) {
-            const u32 gidx = instances[range_start + lo + threadIdx.x];
-            const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)gidx * 6);
-            const uint2 w01 = sp[0], w23 = sp[1], w45 = sp[2];
-            const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
-            const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-            s_geo[threadIdx.x] = make_float4(cx, cy, fminf(wd_unpack_lo(w01.y), cap), fminf(wd_unpack_hi(w01.y), cap));
-            s_con[threadIdx.x] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-            s_col[threadIdx.x] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx));
+    // chunk [lo, hi) of the tile list, lane j <-> entry lo + j; software pipeline: index two chunks ahead, Splat one ahead
+    auto chunk_lo = [&](u32 hi_) { return (hi_ > 64u) ? hi_ - 64u : 0u; };
+    auto fetch_idx = [&](u32 hi_) -> u32 {  // hi_ == 0: no such chunk
+        const u32 lo_ = chunk_lo(hi_);
+        return (hi_ > 0u && lane < hi_ - lo_) ? instances[range_start + lo_ + lane] : 0xFFFFFFFFu;
+    };
+    u32 gidx_c = fetch_idx(wmax);
+    u32 gidx_n = fetch_idx(chunk_lo(wmax));
+    uint2 w01 = make_uint2(0u, 0u), w23 = w01, w45 = w01;
+    if (gidx_c != 0xFFFFFFFFu) {
+        const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)gidx_c * 6);
+        w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
+    }
+    for (u32 hi = wmax; hi > 0u;) {
+        const u32 lo = chunk_lo(hi);
+        // ---- this lane's entry: overlap test against the wave's block, order-preserving compaction into LDS
+        const bool have = gidx_c != 0xFFFFFFFFu;
+        const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
+        const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
+        const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
+        const bool ok = have && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+        const unsigned long long m = __ballot(ok);
+        const u32 n_list = (u32)__popcll(m);
+        if (ok) {
+            const u32 slot = (u32)__popcll(m & lt_mask);
+            s_geo[slot] = make_float4(cx, cy, ex, ey);
+            s_con[slot] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+            s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx_c));
+            s_pos[slot] = lo + lane;
         }
-        __syncthreads();
-        if (wmax > lo) {
-            const u32 top = min(cnt, wmax - lo);  // staged entries this wave may still contribute to
-            u32 n_list = 0;
-            for (u32 r = 0; r * 64u < top; r++) {
-                const u32 j = r * 64u + lane;
-                bool ok = false;
-                if (j < top) {
-                    const float4 geo = s_geo[j];
-                    ok = !((blk_x0 - geo.x) > geo.z || (geo.x - blk_x1) > geo.z || (blk_y0 - geo.y) > geo.w || (geo.y - blk_y1) > geo.w);
-                }
-                const unsigned long long m = __ballot(ok);
-                if (ok) s_list[wave][n_list + (u32)__popcll(m & lt_mask)] = (unsigned char)j;
-                n_list += (u32)__popcll(m);
+        // next chunk's Splat gather and the index fetch of the chunk after it: in flight while this chunk is processed
+        gidx_c = gidx_n;
+        if (gidx_c != 0xFFFFFFFFu) {
+            const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)gidx_c * 6);
+            w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
+        }
+        gidx_n = fetch_idx(chunk_lo(lo));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS records written above are read below by other lanes
+        __builtin_amdgcn_wave_barrier();
+
+        for (u32 i = n_list; i-- > 0u;) {  // back to front
+            const float4 geo = s_geo[i];
+            const float dx = pxf - geo.x, dy = pyf - geo.y;
+            const bool cand = (s_pos[i] < pix_n) && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
+            if (!__any(cand)) continue;
+            const float4 con = s_con[i];
+            const float t1 = __builtin_fmaf(con.x, dx, (2.0f * con.y) * dy);
+            const float power = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
+            const float G = wd_exp(-0.5f * power);
+            const float og = con.w * G;
+            const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
+            const bool act = cand && !(alpha < (1.0f / 255.0f));
+            if (!__any(act)) continue;
+            const float4 col = s_col[i];
+            int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
+            if (act) {
+                T = wd_div(T, 1.0f - alpha);
+                ar_r = la * lc_r + (1.0f - la) * ar_r;
+                ar_g = la * lc_g + (1.0f - la) * ar_g;
+                ar_b = la * lc_b + (1.0f - la) * ar_b;
+                const float aT = alpha * T;
+                f_r = to_fixed(aT * g.x);
+                f_g = to_fixed(aT * g.y);
+                f_b = to_fixed(aT * g.z);
+                float dL_dalpha = 0.0f;
+                dL_dalpha += (col.x - ar_r) * g.x;
+                dL_dalpha += (col.y - ar_g) * g.y;
+                dL_dalpha += (col.z - ar_b) * g.z;
+                dL_dalpha *= T;
+                la = alpha; lc_r = col.x; lc_g = col.y; lc_b = col.z;
+                const float dL_dG = con.w * dL_dalpha;
+                f_op = to_fixed(G * dL_dalpha);
+                const float dpow_dx = 2.0f * con.x * dx + 2.0f * con.y * dy;
+                const float dpow_dy = 2.0f * con.z * dy + 2.0f * con.y * dx;
+                const float mhG = -0.5f * G;
+                const float dG_ddx = mhG * dpow_dx, dG_ddy = mhG * dpow_dy;
+                f_mx = to_fixed(dL_dG * (-dG_ddx));
+                f_my = to_fixed(dL_dG * (-dG_ddy));
+                f_cx = to_fixed(dL_dG * (mhG * dx * dx));
+                f_cy = to_fixed(dL_dG * (mhG * 2.0f * dx * dy));
+                f_cz = to_fixed(dL_dG * (mhG * dy * dy));
             }
-            // back to front: last list entry first, in chunks of 64 indices held in one VGPR
-            for (u32 c_hi = n_list; c_hi > 0u;) {
-                const u32 c_lo = (c_hi > 64u) ? c_hi - 64u : 0u;
-                const u32 mine = (c_lo + lane < c_hi) ? (u32)s_list[wave][c_lo + lane] : 0u;
-                for (u32 kk = c_hi - c_lo; kk-- > 0u;) {
-                    const u32 i = (u32)__builtin_amdgcn_readlane((int)mine, (int)kk);
-                    const float4 geo = s_geo[i];
-                    const float dx = pxf - geo.x, dy = pyf - geo.y;
-                    const bool cand = (lo + i < pix_n) && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
-                    if (!__any(cand)) continue;
-                    const float4 con = s_con[i];
-                    const float t1 = __builtin_fmaf(con.x, dx, (2.0f * con.y) * dy);
-                    const float power = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
-                    const float G = wd_exp(-0.5f * power);
-                    const float og = con.w * G;
-                    const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
-                    const bool act = cand && !(alpha < (1.0f / 255.0f));
-                    if (!__any(act)) continue;
-                    const float4 col = s_col[i];
-                    int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
-                    if (act) {
-                        T = wd_div(T, 1.0f - alpha);
-                        ar_r = la * lc_r + (1.0f - la) * ar_r;
-                        ar_g = la * lc_g + (1.0f - la) * ar_g;
-                        ar_b = la * lc_b + (1.0f - la) * ar_b;
-                        const float aT = alpha * T;
-                        f_r = to_fixed(aT * g.x);
-                        f_g = to_fixed(aT * g.y);
-                        f_b = to_fixed(aT * g.z);
-                        float dL_dalpha = 0.0f;
-                        dL_dalpha += (col.x - ar_r) * g.x;
-                        dL_dalpha += (col.y - ar_g) * g.y;
-                        dL_dalpha += (col.z - ar_b) * g.z;
-                        dL_dalpha *= T;
-                        la = alpha; lc_r = col.x; lc_g = col.y; lc_b = col.z;
-                        const float dL_dG = con.w * dL_dalpha;
-                        f_op = to_fixed(G * dL_dalpha);
-                        const float dpow_dx = 2.0f * con.x * dx + 2.0f * con.y * dy;
-                        const float dpow_dy = 2.0f * con.z * dy + 2.0f * con.y * dx;
-                        const float mhG = -0.5f * G;
-                        const float dG_ddx = mhG * dpow_dx, dG_ddy = mhG * dpow_dy;
-                        f_mx = to_fixed(dL_dG * (-dG_ddx));
-                        f_my = to_fixed(dL_dG * (-dG_ddy));
-                        f_cx = to_fixed(dL_dG * (mhG * dx * dx));
-                        f_cy = to_fixed(dL_dG * (mhG * 2.0f * dx * dy));
-                        f_cz = to_fixed(dL_dG * (mhG * dy * dy));
-                    }
-                    // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
-                    // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
-                    const int w0 = fold32(f_mx, f_cz), w1 = fold32(f_my, f_op), w2 = fold32(f_cx, f_r), w3 = fold32(f_cy, f_g);
-                    // fold16: rows 0..3 of u0 carry slots 0,2,4,6; rows of u1 carry slots 1,3,5,7 (per column)
-                    const int u0 = row_sum(fold16(w0, w2)), u1 = row_sum(fold16(w1, w3));
-                    int t8 = row_sum(f_b);
-                    t8 = fold32(t8, t8);
-                    t8 = fold16(t8, t8);  // every lane: total of slot 8
-                    const u32 col_in_row = lane & 15u;
-                    if (col_in_row < 2u || lane == 2u) {
-                        const u32 slot = (lane == 2u) ? 8u : 2u * (lane >> 4) + col_in_row;
-                        const int v = (lane == 2u) ? t8 : (col_in_row == 0u ? u0 : u1);
-                        const u32 gidx = __float_as_uint(col.w);
-                        if (v != 0) atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + slot], v);
-                    }
-                }
-                c_hi = c_lo;
+            // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
+            // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
+            const int w0 = fold32(f_mx, f_cz), w1 = fold32(f_my, f_op), w2 = fold32(f_cx, f_r), w3 = fold32(f_cy, f_g);
+            // fold16: rows 0..3 of u0 carry slots 0,2,4,6; rows of u1 carry slots 1,3,5,7 (per column)
+            const int u0 = row_sum(fold16(w0, w2)), u1 = row_sum(fold16(w1, w3));
+            int t8 = row_sum(f_b);
+            t8 = fold32(t8, t8);
+            t8 = fold16(t8, t8);  // every lane: total of slot 8
+            const u32 col_in_row = lane & 15u;
+            if (col_in_row < 2u || lane == 2u) {
+                const u32 slot = (lane == 2u) ? 8u : 2u * (lane >> 4) + col_in_row;
+                const int v = (lane == 2u) ? t8 : (col_in_row == 0u ? u0 : u1);
+                const u32 gidx = __float_as_uint(col.w);
+                if (v != 0) atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + slot], v);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // all lanes are done reading the records before the next chunk overwrites them
         hi = lo;
     }
 }

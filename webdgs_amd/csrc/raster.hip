@@ -1,39 +1,49 @@
-// Front-to-back alpha compositing, one 256-thread workgroup per 16x16 tile (K14).
+// Front-to-back alpha compositing (K14), one WAVE (64-thread workgroup) per 8x8 pixel block, four per 16x16 tile.
 //
 // Replaces tiled_rasterize (src/shaders/tiled-rasterizer.wgsl:82-273): a fixed 32 x 256 batch loop with three
 // barriers per batch even when empty, a 48-byte AoS LDS record and no early-out.  Here:
-//   * splats are staged once per 256-entry batch as three float4 LDS planes (centre+extent | conic+opacity | colour);
-//   * each wave owns an 8x8 pixel block and first compacts the batch to the splats whose extent box overlaps that
-//     block (one lane per splat, ballot + prefix popcount, order preserving), so its inner loop only visits splats that
-//     at least one of its pixels accepts -- the per-pixel extent test of the reference is kept and is what decides;
-//   * the inner loop walks the compacted list through v_readlane (index in an SGPR, LDS planes read by broadcast);
-//   * the walk ends when the tile's entries end or when every pixel of the tile is saturated (A > 0.99), which
-//     cannot change any output: after saturation the reference's loop `continue`s without touching C, A or
-//     last_contributor (lines 224-226).
-// Bound: fp32 VALU issue (about 40 lane-ops per accepted pixel-splat pair incl. the deterministic exp), not HBM: the
-// tile's splat list is read once (4 B key + 4 B index + 24 B Splat per entry) and 12 B/pixel are written.
+//   * a wave walks its tile's sorted entries in chunks of 64 (lane = entry): (key, index) two chunks ahead and the 24-byte
+//     Splat one chunk ahead are fetched into registers, so both global round trips overlap with compositing;
+//   * the chunk is compacted to the splats whose extent box overlaps the wave's 8x8 block (ballot + prefix popcount, order
+//     preserving) into a 3 KB wave-private LDS record set; the per-pixel extent test of the reference still decides;
+//   * the inner loop reads the compacted records by broadcast ds_read_b128;
+//   * no workgroup barrier exists: a wave stops as soon as ITS 64 pixels are saturated (A > 0.99) or the tile's entries
+//     end -- after saturation the reference's loop `continue`s without touching C, A or last_contributor (lines 224-226),
+//     so stopping cannot change an output.  (A 256-thread version spent half its wave-cycles waiting at barriers for the
+//     slowest of its four waves: profiles/r01a_pmc_summary.txt.)
+//   * the four waves of a tile are mapped to one XCD (blockIdx is dealt round-robin over the 8 XCDs), so the tile's
+//     entries and splats are fetched from HBM once and served to the other three waves by that XCD's L2.
+// Bound: fp32 VALU issue (about 40 lane-ops per accepted pixel-splat pair incl. the deterministic exp), not HBM.
 // Arithmetic is the pinned contraction of DESIGN.md "raster math", bit-identical to the parity oracle.
 #include "common.h"
 #include "dmath.h"
 
 namespace {
 
-constexpr u32 BATCH = 256;
+// Logical workgroup id such that ids 4t..4t+3 (one tile) run on one XCD: hardware deals blockIdx b to XCD b % 8.
+__device__ __forceinline__ u32 xcd_contiguous_id(u32 b, u32 nblocks) {
+    const u32 q = nblocks / 8u, r = nblocks % 8u, xcd = b % 8u, local = b / 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
+}
 
 template <bool GAUSSIAN_MODE>
 __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
-                                                         const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
-                                                         const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_batches,
-                                                         u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib) {
-    __shared__ float4 s_geo[BATCH];  // centre.x, centre.y, extent.x, extent.y   (pixels)
-    __shared__ float4 s_con[BATCH];  // conic.x, 2*conic.y, conic.z, opacity
-    __shared__ float4 s_col[BATCH];  // r, g, b, -
-    __shared__ unsigned char s_list[4][BATCH];  // per wave: staged indices that overlap the wave's 8x8 block, in order
+                                                        const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
+                                                        const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
+                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib) {
+    __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, extent.x, extent.y   (pixels)
+    __shared__ float4 s_con_all[4][64];  // conic.x, 2*conic.y, conic.z, opacity
+    __shared__ float4 s_col_all[4][64];  // r, g, b, position in the tile list + 1 (bits)
 
-    const u32 tile_id = blockIdx.x;
+    // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
+    // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
+    const u32 tile_id = blockIdx.x, sub = threadIdx.x >> 6;
     const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 bx = tile_x * 16u + (wave & 1u) * 8u, by = tile_y * 16u + (wave >> 1) * 8u;  // block origin
+    const u32 lane = threadIdx.x & 63u;
+    float4* const s_geo = s_geo_all[sub];  // wave-private record sets
+    float4* const s_con = s_con_all[sub];
+    float4* const s_col = s_col_all[sub];
+    const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;  // block origin
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
     const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
@@ -43,99 +53,96 @@ __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings,
     const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    const u32 total = *count_ptr;
-    const u32 start = ranges[tile_id];
-    const bool has_data = start < total;  // 0xFFFFFFFF (empty tile) fails this too
-
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, A = 0.0f;
     u32 last_contributor = 0u;
 
-    if (has_data) {
-        for (u32 batch = 0; max_batches == 0u || batch < max_batches; batch++) {
-            const u32 entry = start + batch * BATCH + threadIdx.x;
-            bool valid = false;
-            if (entry < total) {
-                const u32 key = sorted_keys[entry];
-                if ((key >> 16u) == tile_id + 1u) {
-                    const u32 g = sorted_vals[entry];
-                    if (g < num_splats) {
-                        const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)g * 6);
-                        const uint2 w01 = sp[0], w23 = sp[1], w45 = sp[2];
-                        const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
-                        const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-                        s_geo[threadIdx.x] = make_float4(cx, cy, fminf(wd_unpack_lo(w01.y), cap), fminf(wd_unpack_hi(w01.y), cap));
-                        s_con[threadIdx.x] = make_float4(wd_unpack_lo(w23.x), 2.0f * wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-                        s_col[threadIdx.x] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), 0.0f);
-                        valid = true;
-                    }
-                }
+    const u32 total = *count_ptr;
+    const u32 start = ranges[tile_id];
+    if (__any(in_bounds) && start < total) {  // 0xFFFFFFFF (empty tile) fails the second test too
+        const u32 want_key = tile_id + 1u;
+        auto fetch_kv = [&](u32 c, u32& key, u32& val) {
+            const u32 pos = c * 64u + lane;  // position in the tile's list
+            const u32 entry = start + pos;
+            const bool in_range = entry < total && (max_entries == 0u || pos < max_entries);
+            key = in_range ? sorted_keys[entry] : 0u;
+            val = in_range ? sorted_vals[entry] : 0xFFFFFFFFu;
+        };
+        u32 key_c, val_c, key_n, val_n;
+        fetch_kv(0u, key_c, val_c);
+        fetch_kv(1u, key_n, val_n);
+        bool valid = (key_c >> 16u) == want_key && val_c < num_splats;
+        uint2 w01 = make_uint2(0u, 0u), w23 = w01, w45 = w01;
+        if (valid) {
+            const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)val_c * 6);
+            w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
+        }
+        for (u32 chunk = 0;; chunk++) {
+            // entries of a tile are contiguous, so the valid lanes are a prefix of the chunk
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0ull) break;
+            // ---- this lane's entry: overlap test against the wave's block (conservative and exact per axis: a splat is dropped
+            //      only if the nearest block pixel already fails the per-pixel test |p - c| > extent, which is monotone in p)
+            const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
+            const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
+            const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
+            const bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+            const unsigned long long m = __ballot(ok);
+            const u32 cnt = (u32)__popcll(m);
+            if (ok) {
+                const u32 slot = (u32)__popcll(m & lt_mask);
+                s_geo[slot] = make_float4(cx, cy, ex, ey);
+                s_con[slot] = make_float4(wd_unpack_lo(w23.x), 2.0f * wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+                s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(chunk * 64u + lane + 1u));
             }
-            // Entries of a tile are contiguous, so the valid lanes are a prefix of the batch.
-            const u32 n_valid = (u32)__syncthreads_count(valid);
-            if (n_valid == 0u) break;
+            // issue the next chunk's gather and the (key, index) loads of the chunk after it; they land while this chunk composites
+            valid = (key_n >> 16u) == want_key && val_n < num_splats;
+            if (valid) {
+                const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)val_n * 6);
+                w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
+            }
+            fetch_kv(chunk + 2u, key_n, val_n);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS records written above are read below by other lanes
+            __builtin_amdgcn_wave_barrier();
 
-            const bool lane_live = in_bounds && (!GAUSSIAN_MODE || !(A > 0.99f));
-            if (__any(lane_live)) {
-                // --- compact the batch to this wave's block (conservative and exact per axis: a splat is dropped only if
-                //     the nearest block pixel already fails the per-pixel test |p - c| > extent, which is monotone in p)
-                u32 cnt = 0;
-                for (u32 r = 0; r * 64u < n_valid; r++) {
-                    const u32 j = r * 64u + lane;
-                    bool ok = false;
-                    if (j < n_valid) {
-                        const float4 geo = s_geo[j];
-                        ok = !((blk_x0 - geo.x) > geo.z || (geo.x - blk_x1) > geo.z || (blk_y0 - geo.y) > geo.w || (geo.y - blk_y1) > geo.w);
+            for (u32 i = 0; i < cnt; i++) {
+                const float4 geo = s_geo[i];
+                const float dx = px - geo.x, dy = py - geo.y;
+                const bool inside = in_bounds && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
+                if (GAUSSIAN_MODE) {
+                    const bool active = inside && !(A > 0.99f);
+                    if (!__any(active)) continue;
+                    if (active) {
+                        const float4 con = s_con[i];
+                        const float4 col = s_col[i];
+                        const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
+                        const float q = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
+                        const float G = wd_exp(-0.5f * q);
+                        // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G in [0, inf]), so the hardware
+                        // min/max equal WGSL's select-based clamp.
+                        const float alpha = fminf(fmaxf(G * con.w, 0.0f), 0.99f);
+                        const float w = alpha * (1.0f - A);
+                        cr = __builtin_fmaf(col.x, w, cr);
+                        cg = __builtin_fmaf(col.y, w, cg);
+                        cb = __builtin_fmaf(col.z, w, cb);
+                        A = A + w;
+                        if (alpha >= (1.0f / 255.0f)) last_contributor = __float_as_uint(col.w);
                     }
-                    const unsigned long long m = __ballot(ok);
-                    if (ok) s_list[wave][cnt + (u32)__popcll(m & lt_mask)] = (unsigned char)j;
-                    cnt += (u32)__popcll(m);
-                }
-                const u32 processed_base = batch * BATCH;
-                for (u32 c0 = 0; c0 < cnt; c0 += 64u) {
-                    // wave-private LDS list: this read is ordered after the writes above within the wave
-                    const u32 mine = (c0 + lane < cnt) ? (u32)s_list[wave][c0 + lane] : 0u;
-                    const u32 chunk = min(64u, cnt - c0);
-                    for (u32 kk = 0; kk < chunk; kk++) {
-                        const u32 i = (u32)__builtin_amdgcn_readlane((int)mine, (int)kk);
-                        const float4 geo = s_geo[i];
-                        const float dx = px - geo.x, dy = py - geo.y;
-                        const bool inside = in_bounds && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
-                        if (GAUSSIAN_MODE) {
-                            const bool active = inside && !(A > 0.99f);
-                            if (!__any(active)) continue;
-                            if (active) {
-                                const float4 con = s_con[i];
-                                const float4 col = s_col[i];
-                                const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
-                                const float q = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
-                                const float G = wd_exp(-0.5f * q);
-                                // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G in [0, inf]), so the hardware
-                                // min/max equal WGSL's select-based clamp.
-                                const float alpha = fminf(fmaxf(G * con.w, 0.0f), 0.99f);
-                                const float w = alpha * (1.0f - A);
-                                cr = __builtin_fmaf(col.x, w, cr);
-                                cg = __builtin_fmaf(col.y, w, cg);
-                                cb = __builtin_fmaf(col.z, w, cb);
-                                A = A + w;
-                                if (alpha >= (1.0f / 255.0f)) last_contributor = processed_base + i + 1u;
-                            }
-                        } else {
-                            // point-cloud preview (tiled-rasterizer.wgsl:212-222): paints yellow discs, no saturation test
-                            if (inside) {
-                                const float dist_sq = dx * dx + dy * dy;
-                                const float limit = fminf(settings.point_size_px, cap);
-                                if (dist_sq <= limit * limit) {
-                                    cr = 1.0f; cg = 1.0f; cb = 0.0f; A = 1.0f;
-                                    last_contributor = processed_base + i + 1u;
-                                }
-                            }
+                } else {
+                    // point-cloud preview (tiled-rasterizer.wgsl:212-222): paints yellow discs, no saturation test
+                    if (inside) {
+                        const float dist_sq = dx * dx + dy * dy;
+                        const float limit = fminf(settings.point_size_px, cap);
+                        if (dist_sq <= limit * limit) {
+                            cr = 1.0f; cg = 1.0f; cb = 0.0f; A = 1.0f;
+                            last_contributor = __float_as_uint(s_col[i].w);
                         }
                     }
                 }
             }
-            // every pixel of the tile saturated -> nothing later can change an output
-            const bool done = !in_bounds || (GAUSSIAN_MODE && A > 0.99f);
-            if (__syncthreads_and(done)) break;
+            __builtin_amdgcn_wave_barrier();  // all lanes are done reading the records before the next chunk overwrites them
+            // every pixel of this wave saturated -> nothing later can change an output of this wave
+            if (GAUSSIAN_MODE && !__any(in_bounds && !(A > 0.99f))) break;
+            if (vmask != ~0ull) break;  // the tile's list ended inside this chunk
         }
     }
 
@@ -156,12 +163,13 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
                      const void* sorted_keys, const void* sorted_vals, const void* count_ptr, u32 max_batches, void* out_rgba8, void* out_alpha,
                      void* out_ncontrib) {
     if (ti.total_tiles == 0) return WDGS_OK;
+    const u32 max_entries = max_batches * 256u;  // compat cap: 32 batches x 256 splats per tile; 0 = unlimited
     if (st.gaussian_mode >= 0.5f) {
         WDGS_LAUNCH(dev, "rasterize", rasterize_kernel<true>, dim3(ti.total_tiles), dim3(256), 0, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
-                    (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_batches, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib);
+                    (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib);
     } else {
         WDGS_LAUNCH(dev, "rasterize_points", rasterize_kernel<false>, dim3(ti.total_tiles), dim3(256), 0, st, ti, (const u32*)splats, num_splats,
-                    (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_batches, (u32*)out_rgba8,
+                    (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8,
                     (float*)out_alpha, (u32*)out_ncontrib);
     }
     WDGS_CHECK_HIP(hipGetLastError());
