@@ -228,6 +228,10 @@ void* wdgs_tiled_backward_metric_minmax(wdgs_tiled_backward* op); /* u32[2] glob
 /* Bilinear down-sample of an rgba8 image (the blit render pass of trainer.ts:303-328, shaders/blit.wgsl fs_main). */
 int wdgs_downsample_rgba8(wdgs_device* dev, const void* src_dev, uint32_t src_w, uint32_t src_h, void* dst_dev, uint32_t dst_w, uint32_t dst_h);
 
+/* Exact integer sum of squared differences over the R,G,B bytes of two rgba8 images -> *out_u64_dev (u64, device).
+ * The reference has no scalar loss (it only visualises the gradient image, trainer.ts:695-768); PSNR = 10 log10(255^2 * 3P / SSE). */
+int wdgs_image_sse_rgb8(wdgs_device* dev, const void* a_rgba8_dev, const void* b_rgba8_dev, uint32_t num_pixels, void* out_u64_dev);
+
 /* ---------------------------------------------------------------- Optimizer
  * Replaces allocateOptimizerStateBuffers (renderers/optimizer.ts:27-38), `new Optimizer(device, pointCloud, params?,
  * initialState?)` (71-88), .step (295-350), hyperparameter accessors (256-278), .destroy (352). */

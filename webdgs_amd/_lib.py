@@ -155,6 +155,7 @@ SIGNATURES = {
     "wdgs_tiled_backward_accumulators": (_P, [_P]),
     "wdgs_tiled_backward_metric_minmax": (_P, [_P]),
     "wdgs_downsample_rgba8": (_I, [_P, _P, _U, _U, _P, _U, _U]),
+    "wdgs_image_sse_rgb8": (_I, [_P, _P, _P, _U, _P]),
     "wdgs_optimizer_state_sizes": (_I, [_U, C.POINTER(_Z * 6)]),
     "wdgs_optimizer_create": (_I, [_P, _U, C.POINTER(AdamHyperparameters), _P, _P, C.POINTER(OptimizerState), _I, _U, C.POINTER(_P)]),
     "wdgs_optimizer_destroy": (_I, [_P]),

@@ -465,6 +465,19 @@ def downsampleRGBA8(device: HipDevice, src: HipBuffer, src_w: int, src_h: int, d
     check(device.lib.wdgs_downsample_rgba8(device.handle, src.ptr, src_w, src_h, dst.ptr, dst_w, dst_h))
 
 
+def imageSSE(device: HipDevice, a: HipBuffer, b: HipBuffer, num_pixels: int) -> int:
+    """Exact sum of squared rgb8 differences of two rgba8 images (synchronises)."""
+    out = device.createBuffer(8, "sse")
+    check(device.lib.wdgs_image_sse_rgb8(device.handle, a.ptr, b.ptr, int(num_pixels), out.ptr))
+    return int(out.read(np.uint64, count=1)[0])
+
+
+def imagePSNR(device: HipDevice, a: HipBuffer, b: HipBuffer, num_pixels: int) -> float:
+    """PSNR in dB over the rgb channels of two rgba8 images; +inf when identical."""
+    sse = imageSSE(device, a, b, num_pixels)
+    return float("inf") if sse == 0 else 10.0 * float(np.log10(255.0 * 255.0 * 3.0 * num_pixels / sse))
+
+
 # ----------------------------------------------------------------------------- Optimizer
 DEFAULT_ADAM_HYPERPARAMETERS = dict(lr_pos=0.00016, lr_color=0.0025, lr_opacity=0.05, lr_scale=0.005, lr_rot=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8)
 _STATE_FIELDS = ("optPosBuffer", "optRotBuffer", "optScaleBuffer", "optOpacityBuffer", "paramSH", "stateSH")
