@@ -270,7 +270,11 @@ uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op);
 int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count);
 int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out);
 int wdgs_optimizer_set_hyperparameters(wdgs_optimizer* op, const wdgs_adam_hyperparameters* params);
-int wdgs_optimizer_get_state(wdgs_optimizer* op, wdgs_optimizer_state* out); /* getStateBuffers */
+/* getStateBuffers.  The optimizer trains a compact copy of the SH-DC parameter and moments (36 B per Gaussian instead of
+ * three cache lines at 192/384-byte strides); param_sh / state_sh rows 0..2 are brought up to date HERE, in
+ * wdgs_optimizer_release_state and in wdgs_optimizer_destroy (adopted state).  Always fetch the state through one of these
+ * before reading those two arrays or handing them to wdgs_densify_prune_encode_scatter. */
+int wdgs_optimizer_get_state(wdgs_optimizer* op, wdgs_optimizer_state* out);
 /* Detaches the state so destroy does not free it (hand-over across a densify swap, trainer.ts:492-495). */
 int wdgs_optimizer_release_state(wdgs_optimizer* op, wdgs_optimizer_state* out);
 

@@ -16,8 +16,10 @@ int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdg
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*);
-int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*);
-int launch_adam_repack_f32(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*);
+int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*);
+int launch_adam_repack_f32(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*);
+int launch_dc_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
+int launch_dc_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
 int launch_accumulate_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
 int launch_unpack(wdgs_device*, u32, const void*, const void*, const wdgs_optimizer_state&);
 int launch_metric_map(wdgs_device*, u32, u32, const void*, const void*, float, float, void*, void*, void*, void*);
@@ -108,7 +110,17 @@ struct wdgs_optimizer {
     wdgs_optimizer_state state;
     bool owns_state;
     u32 iteration;
+    float* dc;        // compact SH-DC copy float[N][9] {param rgb, m rgb, v rgb} (optimizer.hip "HBM layout note"); always owned
+    bool dc_dirty;    // dc is ahead of state.param_sh / state.state_sh
 };
+
+// Brings the reference-layout SH arrays up to date with the compact DC copy (no-op when nothing was trained since).
+static int optimizer_flush_dc(wdgs_optimizer* op) {
+    if (!op->dc_dirty) return WDGS_OK;
+    WDGS_TRY(launch_dc_flush(op->dev, op->num_points, op->dc, op->state));
+    op->dc_dirty = false;
+    return WDGS_OK;
+}
 
 extern "C" {
 
@@ -704,29 +716,39 @@ int wdgs_optimizer_create(wdgs_device* d, uint32_t n, const wdgs_adam_hyperparam
         if (r != WDGS_OK) { optimizer_free_state(op); delete op; return r; }
         op->iteration = 0;
     }
+    int r = wdgs_alloc((void**)&op->dc, sizeof(float) * 9 * (size_t)std::max(n, 1u), true, d->stream);
+    if (r == WDGS_OK) r = launch_dc_load(d, n, op->state, op->dc);
+    if (r != WDGS_OK) { free_dev(op->dc); if (op->owns_state) optimizer_free_state(op); delete op; return r; }
+    op->dc_dirty = false;
     *out = op;
     return WDGS_OK;
 }
 int wdgs_optimizer_destroy(wdgs_optimizer* op) {
     if (!op) return WDGS_OK;
+    if (!op->owns_state) (void)optimizer_flush_dc(op);  // adopted buffers outlive the optimizer: leave them current
     (void)hipStreamSynchronize(op->dev->stream);
     if (op->owns_state) optimizer_free_state(op);
+    free_dev(op->dc);
     delete op;
     return WDGS_OK;
 }
 int wdgs_optimizer_init_from_point_cloud(wdgs_optimizer* op, const void* gaussians, const void* sh) {
     WDGS_REQUIRE(op && gaussians && sh, WDGS_E_INVALID, "wdgs_optimizer_init_from_point_cloud: null argument");
-    return launch_unpack(op->dev, op->num_points, gaussians, sh, op->state);
+    WDGS_TRY(launch_unpack(op->dev, op->num_points, gaussians, sh, op->state));
+    op->dc_dirty = false;
+    return launch_dc_load(op->dev, op->num_points, op->state, op->dc);
 }
 int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const void* gradients, const void* tile_counts) {
     WDGS_REQUIRE(op && gaussians && sh && gradients && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step: null argument");
     op->iteration++;  // optimizer.ts:301
-    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, gaussians, sh);
+    op->dc_dirty = true;
+    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");
     op->iteration++;
-    return launch_adam_repack_f32(op->dev, op->num_points, op->params, visible, grad_f32, op->state, gaussians, sh);
+    op->dc_dirty = true;
+    return launch_adam_repack_f32(op->dev, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh);
 }
 int wdgs_accumulate_gradients(wdgs_device* d, uint32_t n, const void* gradients, const void* tile_counts, void* acc, void* visible) {
     WDGS_REQUIRE(d && gradients && tile_counts && acc && visible, WDGS_E_INVALID, "wdgs_accumulate_gradients: null argument");
@@ -736,6 +758,7 @@ uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op) { return op ? op
 int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
     op->iteration += count;
+    if (count) op->dc_dirty = true;  // a recorded step() was re-submitted
     return WDGS_OK;
 }
 int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out) {
@@ -750,11 +773,13 @@ int wdgs_optimizer_set_hyperparameters(wdgs_optimizer* op, const wdgs_adam_hyper
 }
 int wdgs_optimizer_get_state(wdgs_optimizer* op, wdgs_optimizer_state* out) {
     WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    WDGS_TRY(optimizer_flush_dc(op));  // stream-ordered: later kernels and copies on this device see current SH rows
     *out = op->state;
     return WDGS_OK;
 }
 int wdgs_optimizer_release_state(wdgs_optimizer* op, wdgs_optimizer_state* out) {
     WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    WDGS_TRY(optimizer_flush_dc(op));
     *out = op->state;
     op->owns_state = false;
     return WDGS_OK;

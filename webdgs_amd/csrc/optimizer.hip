@@ -3,8 +3,15 @@
 //
 // Replaces src/shaders/adam.wgsl:53-175, src/shaders/update-gaussians.wgsl:35-77 and the inline unpack shader of
 // src/renderers/optimizer.ts:166-223.  The reference runs Adam and the re-pack as two N-wide launches; here they are
-// one kernel (the re-pack only reads what Adam just wrote).  HBM-bound: per visible Gaussian 32 B gradient + 4 B
-// visibility + 2 x (3 x 48 + 12 + 12 + 24) B state, per Gaussian 24 B + 8 B re-pack writes.
+// one kernel (the re-pack only reads what Adam just wrote).
+//
+// HBM layout note.  The reference keeps the SH-DC parameter in param_sh[idx*48 + c] (192-byte stride) and its moments in
+// state_sh[idx*48 + c] (384-byte stride): 36 useful bytes cost three extra cache lines per Gaussian per step (measured:
+// 1.06 GB moved for 0.49 GB algorithmic at N = 1 M, profiles/r01b_pmc.json).  The optimizer therefore trains a compact
+// copy "dc" = float[N][9] {param rgb, m rgb, v rgb} and the reference-layout arrays are brought up to date by dc_flush at
+// every hand-over point (get_state / release_state / destroy), loaded by dc_load when state is adopted or unpacked.
+// Arithmetic and visible results are unchanged.  Per visible Gaussian: 32 B gradient + 4 B visibility + 2 x (3 x 48 + 12
+// + 36) B state; per Gaussian 24 B + 8 B re-pack writes.
 #include "common.h"
 #include "wgslm.h"
 
@@ -34,12 +41,13 @@ WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
 // Adam on one Gaussian's 14 trained scalars (SH: DC only) followed by the fp16 re-pack of that Gaussian.
 WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_pos,
                             float4* __restrict__ opt_rot, float4* __restrict__ opt_scale, float* __restrict__ opt_opacity,
-                            float* __restrict__ param_sh, float2* __restrict__ state_sh, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer) {
+                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer) {
     float4 P = opt_pos[(size_t)idx * 3];
     float4 R = opt_rot[(size_t)idx * 3];
     float4 S = opt_scale[(size_t)idx * 3];
     float op = opt_opacity[(size_t)idx * 3];
-    float c0 = param_sh[(size_t)idx * 48 + 0], c1 = param_sh[(size_t)idx * 48 + 1], c2 = param_sh[(size_t)idx * 48 + 2];
+    float* d = dc + (size_t)idx * 9;
+    float c0 = d[0], c1 = d[1], c2 = d[2];
     if (update) {
         {
             const float4 m = opt_pos[(size_t)idx * 3 + 1], v = opt_pos[(size_t)idx * 3 + 2];
@@ -77,16 +85,12 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
             opt_opacity[(size_t)idx * 3 + 2] = r.v;
         }
         {
-            float pc[3] = {c0, c1, c2};
-#pragma unroll
-            for (u32 c = 0; c < 3u; c++) {
-                const float2 mv = state_sh[(size_t)idx * 48 + c];
-                const Adam3 r = adam_step(h, pc[c], g.color[c], mv.x, mv.y, h.lr_color);
-                pc[c] = r.p;
-                param_sh[(size_t)idx * 48 + c] = r.p;
-                state_sh[(size_t)idx * 48 + c] = make_float2(r.m, r.v);
-            }
-            c0 = pc[0]; c1 = pc[1]; c2 = pc[2];
+            const Adam3 r0 = adam_step(h, c0, g.color[0], d[3], d[6], h.lr_color), r1 = adam_step(h, c1, g.color[1], d[4], d[7], h.lr_color),
+                        r2 = adam_step(h, c2, g.color[2], d[5], d[8], h.lr_color);
+            c0 = r0.p; c1 = r1.p; c2 = r2.p;
+            d[0] = r0.p; d[1] = r1.p; d[2] = r2.p;
+            d[3] = r0.m; d[4] = r1.m; d[5] = r2.m;
+            d[6] = r0.v; d[7] = r1.v; d[8] = r2.v;
         }
     }
     // re-pack (update-gaussians.wgsl:41-75): whole Gaussian, SH word 0, low half of SH word 1
@@ -103,19 +107,18 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
 
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
                                                            const u32* __restrict__ gradients, float4* opt_pos, float4* opt_rot, float4* opt_scale,
-                                                           float* opt_opacity, float* param_sh, float2* state_sh, u32* gaussians, u32* sh_buffer) {
+                                                           float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const bool update = tile_counts[idx] != 0u;
     Grad14 g = {};
     if (update) g = unpack_gradient(gradients, idx);
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, param_sh, state_sh, gaussians, sh_buffer);
+    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer);
 }
 
 __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
                                                                const float* __restrict__ grad_f32, float4* opt_pos, float4* opt_rot,
-                                                               float4* opt_scale, float* opt_opacity, float* param_sh, float2* state_sh,
-                                                               u32* gaussians, u32* sh_buffer) {
+                                                               float4* opt_scale, float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const bool update = visible[idx] != 0u;
@@ -127,7 +130,33 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 n, wdgs_adam_h
         g.scale[0] = gp[8]; g.scale[1] = gp[9]; g.scale[2] = gp[10];
         g.color[0] = gp[11]; g.color[1] = gp[12]; g.color[2] = gp[13];
     }
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, param_sh, state_sh, gaussians, sh_buffer);
+    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer);
+}
+
+// reference layout -> compact DC copy
+__global__ __launch_bounds__(256) void dc_load_kernel(u32 n, const float* __restrict__ param_sh, const float2* __restrict__ state_sh, float* __restrict__ dc) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float* d = dc + (size_t)idx * 9;
+#pragma unroll
+    for (u32 c = 0; c < 3u; c++) {
+        const float2 mv = state_sh[(size_t)idx * 48 + c];
+        d[c] = param_sh[(size_t)idx * 48 + c];
+        d[3 + c] = mv.x;
+        d[6 + c] = mv.y;
+    }
+}
+
+// compact DC copy -> reference layout
+__global__ __launch_bounds__(256) void dc_flush_kernel(u32 n, const float* __restrict__ dc, float* __restrict__ param_sh, float2* __restrict__ state_sh) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float* d = dc + (size_t)idx * 9;
+#pragma unroll
+    for (u32 c = 0; c < 3u; c++) {
+        param_sh[(size_t)idx * 48 + c] = d[c];
+        state_sh[(size_t)idx * 48 + c] = make_float2(d[3 + c], d[6 + c]);
+    }
 }
 
 __global__ __launch_bounds__(256) void accumulate_gradients_kernel(u32 n, const u32* __restrict__ gradients, const u32* __restrict__ tile_counts,
@@ -167,21 +196,33 @@ __global__ __launch_bounds__(256) void unpack_kernel(u32 n, const u32* __restric
 }  // namespace
 
 int launch_adam_repack(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* tile_counts, const void* gradients,
-                       const wdgs_optimizer_state& st, void* gaussians, void* sh) {
+                       const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack", adam_repack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)tile_counts, (const u32*)gradients,
-                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)st.param_sh, (float2*)st.state_sh,
-                (u32*)gaussians, (u32*)sh);
+                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
 int launch_adam_repack_f32(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
-                           const wdgs_optimizer_state& st, void* gaussians, void* sh) {
+                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)visible, (const float*)grad_f32,
-                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)st.param_sh, (float2*)st.state_sh,
-                (u32*)gaussians, (u32*)sh);
+                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_dc_load(wdgs_device* dev, u32 n, const wdgs_optimizer_state& st, void* dc) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "optimizer_dc_load", dc_load_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)st.param_sh, (const float2*)st.state_sh, (float*)dc);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_dc_flush(wdgs_device* dev, u32 n, const void* dc, const wdgs_optimizer_state& st) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "optimizer_dc_flush", dc_flush_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)dc, (float*)st.param_sh, (float2*)st.state_sh);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -528,6 +528,10 @@ class Optimizer:
         check(self.device.lib.wdgs_optimizer_set_hyperparameters(self.handle, C.byref(hp)))
 
     def getStateBuffers(self) -> dict:
+        """``getStateBuffers`` (``optimizer.ts:267-278``).  Goes through ``wdgs_optimizer_get_state`` so the compact SH-DC copy the
+        kernels train is written back into ``paramSH`` / ``stateSH`` (stream-ordered) before anyone reads them."""
+        st = _lib.OptimizerState()
+        check(self.device.lib.wdgs_optimizer_get_state(self.handle, C.byref(st)))
         return self.buffers
 
     def advanceIteration(self, count: int = 1) -> None:
