@@ -150,9 +150,33 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         // wave-private LDS words: the next round's read is ordered after this write within the wave
     }
     __syncthreads();
-    {   // turn per-wave counts into global base addresses: digit d, waves in order
+    // Reorder the partition in LDS so that it leaves in digit runs: position in the partition's sorted order =
+    // (digits below) + (same digit in earlier waves) + rank in own wave.  A direct scatter writes each run 4 B at a time from 16
+    // different wave-instructions (write amplification 1.9x measured); from LDS consecutive lanes write consecutive addresses.
+    __shared__ u32 s_keys[SORT_TILE];
+    __shared__ u32 s_vals[SORT_TILE];
+    __shared__ u32 s_gdelta[RADIX];   // global base of digit d minus its start in the partition's sorted order
+    __shared__ u32 s_wsum[SORT_THREADS / 64];
+    {
         const u32 d = threadIdx.x;
-        u32 run = digit_base[d] + offsets[(size_t)d * num_parts + part];
+        u32 cnt_d = 0;
+#pragma unroll
+        for (u32 w = 0; w < SORT_THREADS / 64; w++) cnt_d += whist[w][d];
+        // exclusive scan of cnt_d over the 256 digits (4 waves x 64 lanes)
+        u32 inc = cnt_d;
+#pragma unroll
+        for (u32 s = 1; s < 64; s <<= 1) {
+            const u32 t = __shfl_up(inc, s, 64);
+            if (lane >= s) inc += t;
+        }
+        if (lane == 63u) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 woff = 0;
+#pragma unroll
+        for (u32 w = 0; w < SORT_THREADS / 64; w++) if (w < wave) woff += s_wsum[w];
+        const u32 local_start = woff + inc - cnt_d;
+        s_gdelta[d] = digit_base[d] + offsets[(size_t)d * num_parts + part] - local_start;
+        u32 run = local_start;   // per-wave start of digit d inside the partition's sorted order
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) {
             const u32 c = whist[w][d];
@@ -166,10 +190,19 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
         if (i < count) {
             const u32 digit = (k[j] >> shift) & (RADIX - 1u);
-            const u32 pos = whist[wave][digit] + rk[j];
-            keys_out[pos] = k[j];
-            vals_out[pos] = v[j];
+            const u32 lpos = whist[wave][digit] + rk[j];
+            s_keys[lpos] = k[j];
+            s_vals[lpos] = v[j];
         }
+    }
+    __syncthreads();
+    const u32 n_here = min(SORT_TILE, count - base);
+#pragma unroll 4
+    for (u32 e = threadIdx.x; e < n_here; e += SORT_THREADS) {
+        const u32 key = s_keys[e];
+        const u32 pos = s_gdelta[(key >> shift) & (RADIX - 1u)] + e;
+        keys_out[pos] = key;
+        vals_out[pos] = s_vals[e];
     }
 }
 
