@@ -90,6 +90,12 @@ int wdgs_encoder_begin(wdgs_device* dev);
 int wdgs_encoder_finish(wdgs_device* dev, wdgs_command_buffer** out);
 int wdgs_queue_submit(wdgs_device* dev, wdgs_command_buffer* cmd);
 int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd);
+/* queue.onSubmittedWorkDone() as a completion callback (trainer.ts:639-645): `fn(user)` runs on a runtime thread once everything
+ * submitted to the device's stream before this call has finished.  It must not call back into this library or HIP; an N-API
+ * host resolves its Promise from it through a thread-safe function.  Deferred device-side checks (tile-entry overflow) are
+ * still reported by wdgs_device_synchronize / wdgs_tiled_forward_check. */
+typedef void (*wdgs_done_callback)(void* user);
+int wdgs_queue_on_done(wdgs_device* dev, wdgs_done_callback fn, void* user);
 
 /* Raw device<->host copies on the device's stream (copy_to_host synchronises): mapAsync/getMappedRange
  * (trainer.ts:455-458) and queue.writeBuffer. */
@@ -105,6 +111,12 @@ void* wdgs_buffer_ptr(const wdgs_buffer* buf);
 size_t wdgs_buffer_size(const wdgs_buffer* buf);
 int wdgs_buffer_write(wdgs_device* dev, wdgs_buffer* buf, size_t offset, const void* src_host, size_t bytes);
 int wdgs_buffer_read(wdgs_device* dev, const wdgs_buffer* buf, size_t offset, void* dst_host, size_t bytes);
+/* mapAsync(READ) counterpart (trainer.ts:455-458): queues the copy on the device's stream and returns; dst_host is valid after
+ * a later wdgs_queue_on_done callback or wdgs_device_synchronize.  dst_host should come from wdgs_host_alloc (pinned) for the
+ * copy to overlap with the host. */
+int wdgs_buffer_read_async(wdgs_device* dev, const wdgs_buffer* buf, size_t offset, void* dst_host, size_t bytes);
+int wdgs_host_alloc(size_t bytes, void** out_host); /* pinned host memory */
+int wdgs_host_free(void* host);
 
 /* ---------------------------------------------------------------- prefix scanner
  * Replaces get_prefix_scanner(maxElements, device): PrefixScanner (prefix/prefix.ts:140, interface 26-43).
@@ -184,6 +196,10 @@ int wdgs_tiled_rasterizer_get_output(wdgs_tiled_rasterizer* op, void** rgba8_dev
 int wdgs_tiled_rasterizer_get_alpha(wdgs_tiled_rasterizer* op, void** final_t_dev);       /* getAlphaTextureView  f32[W*H] */
 int wdgs_tiled_rasterizer_get_n_contrib(wdgs_tiled_rasterizer* op, void** n_contrib_dev); /* getNContribTextureView u32[W*H] */
 int wdgs_tiled_rasterizer_get_tile_offsets(wdgs_tiled_rasterizer* op, void** ranges_dev); /* getTileOffsetsBuffer: per-TILE table u32[T+1] */
+/* blitToTexture (tiled-rasterizer.ts:333-357, shaders/blit.wgsl vs_main/fs_main): full-target draw that samples the output
+ * image with a linear clamp-to-edge sampler into an rgba8 target of any size (the viewer's swap-chain image, viewer.ts:76-86).
+ * WDGS_E_STATE before the first encode, as the reference throws. */
+int wdgs_tiled_rasterizer_blit(wdgs_tiled_rasterizer* op, void* target_rgba8_dev, uint32_t target_width, uint32_t target_height);
 
 /* ---------------------------------------------------------------- TiledBackwardPass
  * Replaces `new TiledBackwardPass(device, pointCloud, config)` (renderers/tiled-backward-pass.ts:136-140, config 27-34,
@@ -303,6 +319,16 @@ int wdgs_densify_prune_set_config(wdgs_densify_prune* op, const wdgs_densify_con
 int wdgs_densify_prune_ensure_size(wdgs_densify_prune* op, uint32_t num_points);
 int wdgs_densify_prune_encode_prepare(wdgs_densify_prune* op, uint32_t num_points, const void* gaussians_dev,
                                       const void* metric_counts_dev, wdgs_densify_prepared* out);
+/* The stages encodePrepare is made of, individually recordable as in the reference: .encodeDecision (densify-prune.ts:412-456,
+ * K26), .encodePrefixSum (327-337: exclusive scan of out_count into out_offset), .encodeCapToMax (363-388, K27),
+ * .encodeTotalOut (339-361, K28) and computeMaxOutPoints (390-410).  The work buffers are the ones encode_prepare reports. */
+int wdgs_densify_prune_encode_decision(wdgs_densify_prune* op, uint32_t num_points, const void* gaussians_dev, const void* metric_counts_dev);
+int wdgs_densify_prune_encode_prefix_sum(wdgs_densify_prune* op, uint32_t num_points);
+int wdgs_densify_prune_encode_cap_to_max(wdgs_densify_prune* op, uint32_t num_points, uint32_t max_out_points);
+int wdgs_densify_prune_encode_total_out(wdgs_densify_prune* op, uint32_t num_points);
+int wdgs_densify_prune_compute_max_out_points(wdgs_densify_prune* op, uint32_t num_points, uint32_t* max_out_points);
+/* getOutTotalBuffer & co. (densify-prune.ts:314-324): the pass's work buffers; WDGS_E_STATE before they exist. */
+int wdgs_densify_prune_get_buffers(wdgs_densify_prune* op, wdgs_densify_prepared* out);
 /* Reads the 4-byte total back (the one device->host crossing of the densify path, trainer.ts:440-458). */
 int wdgs_densify_prune_read_total(wdgs_densify_prune* op, uint32_t* total_out);
 /* encodeScatter: out_num_points must equal the size of the output buffers (the reference throws otherwise,
@@ -310,6 +336,25 @@ int wdgs_densify_prune_read_total(wdgs_densify_prune* op, uint32_t* total_out);
 int wdgs_densify_prune_encode_scatter(wdgs_densify_prune* op, uint32_t in_points, const void* in_gaussians_dev, const void* in_sh_dev,
                                       const wdgs_optimizer_state* in_state, uint32_t out_num_points, int reset_new_optimizer_state,
                                       void* out_gaussians_dev, void* out_sh_dev, const wdgs_optimizer_state* out_state);
+
+/* ---------------------------------------------------------------- data-parallel communicator (RCCL over xGMI)
+ * No counterpart in the reference, which trains one view per step on one GPU (trainer.ts:573).  View-sharded data parallelism
+ * (SURVEY 8(e)): every rank holds a full replica, runs K1-K17 on its own views, sums GaussianGradients into acc_f32[N*14] +
+ * visible[N] (wdgs_accumulate_gradients), all-reduces both, and applies wdgs_optimizer_step_f32 -- identical on every rank,
+ * so replicas stay bit-identical; world_size = 1 reduces to the reference step.  One process (or host thread) per GPU: rank 0
+ * calls wdgs_comm_get_unique_id and ships the 128 bytes to the others over any host channel; all ranks then call
+ * wdgs_comm_create.  Reductions are queued on the device's stream (no host sync).  RCCL is bound lazily, on first use. */
+#define WDGS_COMM_ID_BYTES 128
+typedef struct wdgs_comm wdgs_comm;
+int wdgs_comm_get_unique_id(uint8_t id_out[WDGS_COMM_ID_BYTES]);
+int wdgs_comm_create(wdgs_device* dev, const uint8_t id[WDGS_COMM_ID_BYTES], int world_size, int rank, wdgs_comm** out);
+int wdgs_comm_destroy(wdgs_comm* comm);
+int wdgs_comm_world_size(const wdgs_comm* comm);
+int wdgs_comm_rank(const wdgs_comm* comm);
+/* In place: grad_f32[N*14] (f32 sum) and visible_counts[N] (u32 sum) over all ranks, one RCCL group. */
+int wdgs_comm_allreduce_gradients(wdgs_comm* comm, void* grad_f32_dev, void* visible_counts_dev, uint32_t num_points);
+/* In place u32 sum (densify metric counts, SURVEY 8(e) "Determinism"). */
+int wdgs_comm_allreduce_counts(wdgs_comm* comm, void* counts_u32_dev, uint32_t count);
 
 #ifdef __cplusplus
 }

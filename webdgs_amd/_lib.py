@@ -85,6 +85,7 @@ _U = C.c_uint32
 _I = C.c_int
 _F = C.c_float
 _Z = C.c_size_t
+DoneCallback = C.CFUNCTYPE(None, C.c_void_p)  # wdgs_done_callback
 
 # name -> (restype, argtypes).  Every symbol include/webdgs.h declares is listed (tests/test_abi.py checks both ways).
 SIGNATURES = {
@@ -100,6 +101,24 @@ SIGNATURES = {
     "wdgs_encoder_finish": (_I, [_P, C.POINTER(_P)]),
     "wdgs_queue_submit": (_I, [_P, _P]),
     "wdgs_command_buffer_destroy": (_I, [_P]),
+    "wdgs_queue_on_done": (_I, [_P, DoneCallback, _P]),
+    "wdgs_buffer_read_async": (_I, [_P, _P, _Z, _P, _Z]),
+    "wdgs_host_alloc": (_I, [_Z, C.POINTER(_P)]),
+    "wdgs_host_free": (_I, [_P]),
+    "wdgs_tiled_rasterizer_blit": (_I, [_P, _P, _U, _U]),
+    "wdgs_densify_prune_encode_decision": (_I, [_P, _U, _P, _P]),
+    "wdgs_densify_prune_encode_prefix_sum": (_I, [_P, _U]),
+    "wdgs_densify_prune_encode_cap_to_max": (_I, [_P, _U, _U]),
+    "wdgs_densify_prune_encode_total_out": (_I, [_P, _U]),
+    "wdgs_densify_prune_compute_max_out_points": (_I, [_P, _U, C.POINTER(_U)]),
+    "wdgs_densify_prune_get_buffers": (_I, [_P, C.POINTER(DensifyPrepared)]),
+    "wdgs_comm_get_unique_id": (_I, [C.POINTER(C.c_uint8)]),
+    "wdgs_comm_create": (_I, [_P, C.POINTER(C.c_uint8), _I, _I, C.POINTER(_P)]),
+    "wdgs_comm_destroy": (_I, [_P]),
+    "wdgs_comm_world_size": (_I, [_P]),
+    "wdgs_comm_rank": (_I, [_P]),
+    "wdgs_comm_allreduce_gradients": (_I, [_P, _P, _P, _U]),
+    "wdgs_comm_allreduce_counts": (_I, [_P, _P, _U]),
     "wdgs_copy_to_host": (_I, [_P, _P, _P, _Z]),
     "wdgs_copy_to_device": (_I, [_P, _P, _P, _Z]),
     "wdgs_memset": (_I, [_P, _P, _I, _Z]),

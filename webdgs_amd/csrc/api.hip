@@ -250,6 +250,22 @@ int wdgs_queue_submit(wdgs_device* d, wdgs_command_buffer* cmd) {
     WDGS_CHECK_HIP(hipGraphLaunch(c->exec, d->stream));
     return WDGS_OK;
 }
+namespace {
+struct DoneThunk { wdgs_done_callback fn; void* user; };
+void done_trampoline(void* p) {
+    DoneThunk* t = static_cast<DoneThunk*>(p);
+    t->fn(t->user);
+    delete t;
+}
+}  // namespace
+int wdgs_queue_on_done(wdgs_device* d, wdgs_done_callback fn, void* user) {
+    WDGS_REQUIRE(d && fn, WDGS_E_INVALID, "wdgs_queue_on_done: null argument");
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_on_done while recording a command buffer");
+    DoneThunk* t = new DoneThunk{fn, user};
+    hipError_t e = hipLaunchHostFunc(d->stream, done_trampoline, t);
+    if (e != hipSuccess) { delete t; wdgs_set_error("hipLaunchHostFunc failed: %s", hipGetErrorString(e)); return WDGS_E_HIP; }
+    return WDGS_OK;
+}
 int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd) {
     if (!cmd) return WDGS_OK;
     auto* c = reinterpret_cast<wdgs_command_buffer_impl*>(cmd);
@@ -309,6 +325,23 @@ int wdgs_buffer_read(wdgs_device* d, const wdgs_buffer* b, size_t off, void* dst
     WDGS_REQUIRE(d && b, WDGS_E_INVALID, "wdgs_buffer_read: null argument");
     WDGS_REQUIRE(off + bytes <= b->size, WDGS_E_INVALID, "wdgs_buffer_read: range [%zu, %zu) exceeds buffer size %zu", off, off + bytes, b->size);
     return wdgs_copy_to_host(d, dst, (const char*)b->ptr + off, bytes);
+}
+int wdgs_buffer_read_async(wdgs_device* d, const wdgs_buffer* b, size_t off, void* dst, size_t bytes) {
+    WDGS_REQUIRE(d && b && (bytes == 0 || dst), WDGS_E_INVALID, "wdgs_buffer_read_async: null argument");
+    WDGS_REQUIRE(off + bytes <= b->size, WDGS_E_INVALID, "wdgs_buffer_read_async: range [%zu, %zu) exceeds buffer size %zu", off, off + bytes, b->size);
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_buffer_read_async while recording a command buffer");
+    if (bytes == 0) return WDGS_OK;
+    WDGS_CHECK_HIP(hipMemcpyAsync(dst, (const char*)b->ptr + off, bytes, hipMemcpyDeviceToHost, d->stream));
+    return WDGS_OK;
+}
+int wdgs_host_alloc(size_t bytes, void** out) {
+    WDGS_REQUIRE(out, WDGS_E_INVALID, "wdgs_host_alloc: null argument");
+    WDGS_CHECK_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return WDGS_OK;
+}
+int wdgs_host_free(void* p) {
+    if (p) WDGS_CHECK_HIP(hipHostFree(p));
+    return WDGS_OK;
 }
 
 // ---------------------------------------------------------------- prefix scanner
@@ -563,6 +596,13 @@ RASTER_GETTER(wdgs_tiled_rasterizer_get_alpha, alpha, "alpha texture")
 RASTER_GETTER(wdgs_tiled_rasterizer_get_n_contrib, n_contrib, "n_contrib texture")
 RASTER_GETTER(wdgs_tiled_rasterizer_get_tile_offsets, ranges, "tile offsets")
 #undef RASTER_GETTER
+
+int wdgs_tiled_rasterizer_blit(wdgs_tiled_rasterizer* op, void* target, uint32_t tw, uint32_t th) {
+    WDGS_REQUIRE(op && target, WDGS_E_INVALID, "wdgs_tiled_rasterizer_blit: null argument");
+    WDGS_REQUIRE(op->encoded && op->rgba8, WDGS_E_STATE, "TiledRasterizer: no output texture to blit from. Call encode() first.");
+    WDGS_REQUIRE(tw > 0 && th > 0, WDGS_E_INVALID, "wdgs_tiled_rasterizer_blit: empty target %ux%u", tw, th);
+    return launch_downsample(op->dev, op->rgba8, op->width, op->height, target, tw, th);
+}
 
 // ---------------------------------------------------------------- TiledBackwardPass
 static int backward_alloc_images(wdgs_tiled_backward* op, u32 w, u32 h) {

@@ -413,23 +413,67 @@ static u32 compute_max_out(const wdgs_densify_config& c, u32 n) {
     return (u32)std::min<uint64_t>(m, 0xFFFFFFFFull);
 }
 
+// The four stages of encodePrepare, individually recordable like the reference's public methods.
+int wdgs_densify_prune_encode_decision(wdgs_densify_prune* op, uint32_t n, const void* gaussians, const void* metric_counts) {
+    WDGS_REQUIRE(op && gaussians, WDGS_E_INVALID, "wdgs_densify_prune_encode_decision: null argument");
+    WDGS_TRY(wdgs_densify_prune_ensure_size(op, n));
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(op->dev, "densify_decide", decide_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)metric_counts,
+                op->cfg.clone_threshold, op->cfg.prune_threshold, op->cfg.split_threshold, op->counts, op->actions);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int wdgs_densify_prune_encode_prefix_sum(wdgs_densify_prune* op, uint32_t n) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    WDGS_REQUIRE(op->actions && n <= op->capacity, WDGS_E_STATE, "encodePrefixSum before encodeDecision/ensureSize for %u points", n);
+    if (n == 0) return WDGS_OK;
+    return scan_exclusive_u32(op->dev, &op->scan, op->counts, op->offsets, n, nullptr);
+}
+
+int wdgs_densify_prune_encode_cap_to_max(wdgs_densify_prune* op, uint32_t n, uint32_t max_out_points) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    WDGS_REQUIRE(op->actions && n <= op->capacity, WDGS_E_STATE, "encodeCapToMax before encodeDecision/ensureSize for %u points", n);
+    op->last_max_out = max_out_points;
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(op->dev, "densify_cap", cap_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, max_out_points, op->offsets, op->counts, op->actions);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int wdgs_densify_prune_encode_total_out(wdgs_densify_prune* op, uint32_t n) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    WDGS_REQUIRE(n == 0 || (op->actions && n <= op->capacity), WDGS_E_STATE, "encodeTotalOut before encodeDecision/ensureSize for %u points", n);
+    WDGS_LAUNCH(op->dev, "densify_total", total_kernel, dim3(1), dim3(64), 0, n, op->offsets, op->counts, op->total);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int wdgs_densify_prune_compute_max_out_points(wdgs_densify_prune* op, uint32_t n, uint32_t* out) {
+    WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    *out = compute_max_out(op->cfg, n);
+    return WDGS_OK;
+}
+
+int wdgs_densify_prune_get_buffers(wdgs_densify_prune* op, wdgs_densify_prepared* out) {
+    WDGS_REQUIRE(op && out, WDGS_E_INVALID, "null argument");
+    WDGS_REQUIRE(op->actions, WDGS_E_STATE, "DensifyPrunePass: buffers not created yet (call ensureSize or an encode first)");
+    out->action_buffer = op->actions;
+    out->out_count_buffer = op->counts;
+    out->out_offset_buffer = op->offsets;
+    out->out_total_buffer = op->total;
+    out->max_out_points = op->last_max_out;
+    return WDGS_OK;
+}
+
 int wdgs_densify_prune_encode_prepare(wdgs_densify_prune* op, uint32_t n, const void* gaussians, const void* metric_counts, wdgs_densify_prepared* out) {
     WDGS_REQUIRE(op && gaussians && out, WDGS_E_INVALID, "wdgs_densify_prune_encode_prepare: null argument");
-    WDGS_TRY(wdgs_densify_prune_ensure_size(op, n));
-    wdgs_device* dev = op->dev;
     const u32 max_out = compute_max_out(op->cfg, n);
-    op->last_max_out = max_out;
-    if (n > 0) {
-        const u32 grid = ceil_div(n, 256);
-        const float split = op->cfg.split_threshold;
-        WDGS_LAUNCH(dev, "densify_decide", decide_kernel, dim3(grid), dim3(256), 0, n, (const u32*)gaussians, (const u32*)metric_counts, op->cfg.clone_threshold,
-                    op->cfg.prune_threshold, split, op->counts, op->actions);
-        WDGS_TRY(scan_exclusive_u32(dev, &op->scan, op->counts, op->offsets, n, nullptr));
-        WDGS_LAUNCH(dev, "densify_cap", cap_kernel, dim3(grid), dim3(256), 0, n, max_out, op->offsets, op->counts, op->actions);
-        WDGS_TRY(scan_exclusive_u32(dev, &op->scan, op->counts, op->offsets, n, nullptr));
-    }
-    WDGS_LAUNCH(dev, "densify_total", total_kernel, dim3(1), dim3(64), 0, n, op->offsets, op->counts, op->total);
-    WDGS_CHECK_HIP(hipGetLastError());
+    WDGS_TRY(wdgs_densify_prune_encode_decision(op, n, gaussians, metric_counts));
+    WDGS_TRY(wdgs_densify_prune_encode_prefix_sum(op, n));
+    WDGS_TRY(wdgs_densify_prune_encode_cap_to_max(op, n, max_out));
+    WDGS_TRY(wdgs_densify_prune_encode_prefix_sum(op, n));
+    WDGS_TRY(wdgs_densify_prune_encode_total_out(op, n));
     out->action_buffer = op->actions;
     out->out_count_buffer = op->counts;
     out->out_offset_buffer = op->offsets;

@@ -103,8 +103,15 @@ class _Queue:
             if isinstance(c, HipCommandBuffer):
                 check(self.device.lib.wdgs_queue_submit(self.device.handle, c.handle))
 
-    def onSubmittedWorkDone(self) -> None:
-        self.device.synchronize()
+    def onSubmittedWorkDone(self, callback=None) -> None:
+        """Without a callback: block until the stream drains (the awaited Promise of trainer.ts:639-645).  With one: return
+        at once; ``callback()`` runs on a runtime thread when the work submitted so far is done (it must not touch the GPU)."""
+        if callback is None:
+            self.device.synchronize()
+            return
+        cb = _lib.DoneCallback(lambda _user: callback())
+        self.device._keepalive.append(cb)  # the trampoline must outlive its call; released at the next synchronize()
+        check(self.device.lib.wdgs_queue_on_done(self.device.handle, cb, None))
 
     def writeBuffer(self, buf: HipBuffer, offset: int, data: np.ndarray) -> None:
         buf.write(data, offset)
@@ -366,6 +373,14 @@ class TiledRasterizer:
         tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
         return self._get(self.device.lib.wdgs_tiled_rasterizer_get_tile_offsets, 4 * (tiles + 1))
 
+    def blitToTexture(self, encoder: Optional[HipEncoder], target: HipBuffer, width: Optional[int] = None, height: Optional[int] = None) -> None:
+        """``blitToTexture(encoder, targetView)`` (tiled-rasterizer.ts:333-357): ``target`` is an rgba8 image buffer of
+        ``width x height`` (default: the rasterizer's own size); raises before the first ``encode`` like the reference."""
+        w, h = int(width or self.width), int(height or self.height)
+        if self.handle is not None and w * h * 4 > target.size:
+            raise _lib.WdgsError(_lib.WDGS_E_INVALID, f"blitToTexture: target of {target.size} bytes is smaller than {w}x{h} rgba8")
+        check(self.device.lib.wdgs_tiled_rasterizer_blit(self.handle, target.ptr, max(w, 0), max(h, 0)))
+
     def destroy(self) -> None:
         if self.destroyed:
             return
@@ -599,6 +614,41 @@ class DensifyPrunePass:
         n, d = max(1, pc.num_points), self.device
         return dict(actionBuffer=d.view(out.action_buffer, 4 * n), outCountBuffer=d.view(out.out_count_buffer, 4 * n),
                     outOffsetBuffer=d.view(out.out_offset_buffer, 4 * n), outTotalBuffer=d.view(out.out_total_buffer, 4), maxOutPoints=int(out.max_out_points))
+
+    # ---- the stages encodePrepare is made of (densify-prune.ts:327-456), for hosts that sequence them themselves
+    def _buffers(self) -> dict:
+        out = _lib.DensifyPrepared()
+        check(self.device.lib.wdgs_densify_prune_get_buffers(self.handle, C.byref(out)))
+        n, d = max(1, self.numPoints), self.device
+        return dict(actionBuffer=d.view(out.action_buffer, 4 * n), outCountBuffer=d.view(out.out_count_buffer, 4 * n),
+                    outOffsetBuffer=d.view(out.out_offset_buffer, 4 * n), outTotalBuffer=d.view(out.out_total_buffer, 4), maxOutPoints=int(out.max_out_points))
+
+    def computeMaxOutPoints(self, pointCloud: PointCloud) -> int:
+        m = C.c_uint32(0)
+        check(self.device.lib.wdgs_densify_prune_compute_max_out_points(self.handle, pointCloud.num_points, C.byref(m)))
+        return int(m.value)
+
+    def encodeDecision(self, encoder, inputs: dict) -> dict:
+        pc: PointCloud = inputs["pointCloud"]
+        mc = inputs.get("metricCountsBuffer")
+        check(self.device.lib.wdgs_densify_prune_encode_decision(self.handle, pc.num_points, pc.gaussian_3d_buffer.ptr, mc.ptr if mc is not None else None))
+        self.numPoints = pc.num_points
+        b = self._buffers()
+        return dict(actionBuffer=b["actionBuffer"], outCountBuffer=b["outCountBuffer"])
+
+    def encodePrefixSum(self, encoder) -> HipBuffer:
+        check(self.device.lib.wdgs_densify_prune_encode_prefix_sum(self.handle, self.numPoints))
+        return self._buffers()["outOffsetBuffer"]
+
+    def encodeCapToMax(self, encoder, outOffsetBuffer: Optional[HipBuffer], maxOutPoints: int) -> None:
+        check(self.device.lib.wdgs_densify_prune_encode_cap_to_max(self.handle, self.numPoints, max(0, int(maxOutPoints))))
+
+    def encodeTotalOut(self, encoder, outOffsetBuffer: Optional[HipBuffer] = None) -> HipBuffer:
+        check(self.device.lib.wdgs_densify_prune_encode_total_out(self.handle, self.numPoints))
+        return self._buffers()["outTotalBuffer"]
+
+    def getOutTotalBuffer(self) -> HipBuffer:
+        return self._buffers()["outTotalBuffer"]
 
     def readTotal(self) -> int:
         t = C.c_uint32(0)

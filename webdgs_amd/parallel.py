@@ -65,3 +65,53 @@ def allreduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+class Communicator:
+    """The C-ABI communicator (``wdgs_comm_*``, include/webdgs.h): RCCL driven by the library itself, for hosts that have no
+    ``torch.distributed`` (the N-API addon, a C++ trainer).  ``unique_id`` is the 128-byte id of rank 0
+    (``Communicator.uniqueId()``), shipped to the other ranks over any host channel; with a torch process group it is
+    broadcast through it (``Communicator.fromProcessGroup``).  Reductions are queued on the device's stream."""
+
+    def __init__(self, device, unique_id: bytes, world_size: int, rank: int):
+        import ctypes as C
+
+        from . import _lib
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        self.device, self.world_size, self.rank = device, int(world_size), int(rank)
+        ident = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(device.lib.wdgs_comm_create(device.handle, ident, self.world_size, self.rank, C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def uniqueId() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+        ident = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().wdgs_comm_get_unique_id(ident))
+        return bytes(ident)
+
+    @classmethod
+    def fromProcessGroup(cls, device, group=None) -> "Communicator":
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        box = [cls.uniqueId() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(device, box[0], world, rank)
+
+    def allreduceGradients(self, gradF32, visibleCounts, numPoints: int) -> None:
+        from . import _lib
+        _lib.check(self.device.lib.wdgs_comm_allreduce_gradients(self.handle, gradF32.ptr, visibleCounts.ptr, int(numPoints)))
+
+    def allreduceCounts(self, counts, count: int) -> None:
+        from . import _lib
+        _lib.check(self.device.lib.wdgs_comm_allreduce_counts(self.handle, counts.ptr, int(count)))
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.device.lib.wdgs_comm_destroy(self.handle)
+            self.handle = None

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import ops, parallel
+from . import loaders, ops, parallel
 
 
 class Trainer:
@@ -115,7 +115,16 @@ class Trainer:
         self._eager_steps = 0
 
     def setDataset(self, cameras: list, images: list) -> None:
-        self.trainCameras, self.images = list(cameras), list(images)
+        """``cameras[i]`` pairs with ``images[i]`` (trainer.ts:575-577).  Accepted shapes: the reference's own --
+        ``CameraData`` dicts from ``loaders`` and ``images.LoadedImage`` objects (the camera block is then built for the image
+        size as ``Camera.set_preset`` + ``update_buffer`` do, trainer.ts:583-586) -- or ready dicts carrying ``camera`` (68
+        floats) and ``width/height/texture``."""
+        cameras, images = list(cameras), list(images)
+        images = [im if isinstance(im, dict) else dict(name=im.name, width=im.width, height=im.height,
+                                                       texture=im.texture if im.texture is not None else self.device.bufferFrom(im.bitmap))
+                  for im in images]
+        cameras = [c if "camera" in c else dict(c, camera=loaders.cameraUniforms(c, im["width"], im["height"])) for c, im in zip(cameras, images)]
+        self.trainCameras, self.images = cameras, images
         # one resident 272-byte camera block per training view (the reference rewrites a single uniform buffer every step)
         self._camera_buffers = [self.device.bufferFrom(np.asarray(c["camera"], np.float32)) for c in self.trainCameras]
         self._invalidate_command_buffers()

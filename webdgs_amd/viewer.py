@@ -1,0 +1,121 @@
+"""Preview path: forward pass + rasterizer + blit, mirroring ``src/viewer.ts:8-115`` without the browser.
+
+The reference's ``Viewer`` owns a ``Camera`` bound to a canvas, builds a ``TiledForwardPass`` in ``'pointcloud'`` render mode
+and a ``TiledRasterizer`` on ``setPointCloud`` (viewer.ts:46-66), and per frame encodes forward -> rasterize ->
+``blitToTexture(swapChainView)`` (viewer.ts:72-87).  Here the canvas is a ``width x height`` rgba8 device buffer (the
+"swap-chain image"); ``readFrame`` / ``savePNG`` take the place of presentation.  Camera interaction (``CameraControl``) is
+UI and stays out; the camera is set from a ``CameraData`` dict or a ready 68-float block.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Optional
+
+import numpy as np
+
+from . import loaders
+from .ops import HipBuffer, HipDevice, HipEncoder, PointCloud, TiledForwardPass, TiledRasterizer
+
+
+def encodePNG(rgba: np.ndarray) -> bytes:
+    """Minimal PNG writer (8-bit RGBA, filter 0, one IDAT) for ``[H, W, 4]`` uint8 frames."""
+    a = np.ascontiguousarray(rgba, np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("encodePNG expects an [H, W, 4] uint8 array")
+    h, w = a.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * 4)], axis=1).tobytes()
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+class Viewer:
+    """``Viewer`` (``src/viewer.ts``): ``setPointCloud``, ``render(encoder)``, pass-through setters, resize handling."""
+
+    def __init__(self, device: HipDevice, width: int, height: int, format: str = "rgba8unorm"):
+        self.device = device
+        self.presentationFormat = format
+        self.width, self.height = int(width), int(height)
+        self.forwardPass: Optional[TiledForwardPass] = None
+        self.rasterizer: Optional[TiledRasterizer] = None
+        self.pointCloud: Optional[PointCloud] = None
+        self._camera_data: Optional[dict] = None
+        self.cameraBuffer: HipBuffer = device.createBuffer(272, "camera uniforms")
+        self.frameBuffer: HipBuffer = device.createBuffer(4 * self.width * self.height, "swap-chain image")
+        self.setCamera(dict(position=(0.0, 0.0, 5.0)))  # Camera defaults (camera.ts:113-136)
+
+    # ---- camera (camera.ts:138-205 via loaders.cameraUniforms)
+    def setCamera(self, camera) -> None:
+        """``camera``: a CameraData dict (``loaders.loadCameraJson`` / ``mergeColmap`` entries) or 68 floats."""
+        if isinstance(camera, dict):
+            self._camera_data = camera
+            block = loaders.cameraUniforms(camera, self.width, self.height)
+        else:
+            self._camera_data = None
+            block = np.asarray(camera, np.float32).reshape(68)
+        self.cameraBuffer.write(block)
+
+    def setPointCloud(self, pointCloud: PointCloud) -> None:
+        if self.forwardPass is not None:
+            self.forwardPass.destroy()
+        if self.rasterizer is not None:
+            self.rasterizer.destroy()
+        self.pointCloud = pointCloud
+        self.forwardPass = TiledForwardPass(self.device, pointCloud, self.cameraBuffer,
+                                            dict(viewportWidth=self.width, viewportHeight=self.height, renderMode="pointcloud"))
+        self.rasterizer = TiledRasterizer(dict(device=self.device, forwardPass=self.forwardPass, format=self.presentationFormat))
+
+    def update(self, dt: float) -> None:
+        """Camera-control integration step of the reference (viewer.ts:68-70); no interactive control here."""
+
+    def render(self, commandEncoder: Optional[HipEncoder] = None) -> None:
+        if self.forwardPass is None or self.rasterizer is None or self.pointCloud is None:
+            return
+        self.forwardPass.encode(commandEncoder)
+        self.rasterizer.encode(commandEncoder, self.width, self.height)
+        self.rasterizer.blitToTexture(commandEncoder, self.frameBuffer, self.width, self.height)
+
+    # ---- pass-through setters / getters (viewer.ts:89-104)
+    def setRenderMode(self, mode: str) -> None:
+        if self.forwardPass is not None:
+            self.forwardPass.setRenderMode(mode)
+
+    def setGaussianScale(self, value: float) -> None:
+        if self.forwardPass is not None:
+            self.forwardPass.setGaussianScale(value)
+
+    def setPointSize(self, value: float) -> None:
+        if self.forwardPass is not None:
+            self.forwardPass.setPointSize(value)
+
+    def getForwardPass(self) -> Optional[TiledForwardPass]:
+        return self.forwardPass
+
+    def resize(self, width: int, height: int) -> None:
+        """``handleResize`` (viewer.ts:106-113): new canvas size -> camera block and forward-pass viewport follow."""
+        self.width, self.height = int(width), int(height)
+        self.frameBuffer.destroy()
+        self.frameBuffer = self.device.createBuffer(4 * self.width * self.height, "swap-chain image")
+        if self._camera_data is not None:
+            self.cameraBuffer.write(loaders.cameraUniforms(self._camera_data, self.width, self.height))
+        if self.forwardPass is not None:
+            self.forwardPass.setViewport(self.width, self.height)
+
+    # ---- presentation
+    def readFrame(self) -> np.ndarray:
+        """The presented image as ``[H, W, 4]`` uint8 (synchronises)."""
+        return self.frameBuffer.read(np.uint8, 4 * self.width * self.height).reshape(self.height, self.width, 4)
+
+    def savePNG(self, path: str) -> None:
+        with open(path, "wb") as f:
+            f.write(encodePNG(self.readFrame()))
+
+    def destroy(self) -> None:
+        if self.forwardPass is not None:
+            self.forwardPass.destroy()
+        if self.rasterizer is not None:
+            self.rasterizer.destroy()
+        self.forwardPass = self.rasterizer = None
