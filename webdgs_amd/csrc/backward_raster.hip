@@ -48,11 +48,13 @@ WD_DEV int fold16(int a, int b) {
     return (int)(r[0] + r[1]);
 }
 
-WD_DEV int to_fixed(float v) {
-    // i32(v * 1e6): truncate toward zero, saturate, NaN -> 0 -- exactly v_cvt_i32_f32.
-    const float s = v * 1000000.0f;
+typedef float f2 __attribute__((ext_vector_type(2)));  // maps to v_pk_{add,mul}_f32: two IEEE binary32 operations per instruction
+
+constexpr float FIXED_SCALE = 1000000.0f;  // common.wgsl:113-116
+WD_DEV int cvt_fixed(float scaled) {
+    // i32(v * 1e6) after the multiply: truncate toward zero, saturate, NaN -> 0 -- exactly v_cvt_i32_f32.
     int r;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(s));
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(scaled));
     return r;
 }
 
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, extent.x, extent.y
     __shared__ float4 s_con_all[4][64];  // conic.x, conic.y, conic.z, opacity
     __shared__ float4 s_col_all[4][64];  // r, g, b, gaussian index (bits)
-    __shared__ u32 s_pos_all[4][64];     // position of the entry in the tile's list
+    __shared__ float4 s_aux_all[4][64];  // position of the entry in the tile's list (bits), 2*conic.xyz
 
     // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
     // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     float4* const s_geo = s_geo_all[sub];  // wave-private record sets
     float4* const s_con = s_con_all[sub];
     float4* const s_col = s_col_all[sub];
-    u32* const s_pos = s_pos_all[sub];
+    float4* const s_aux = s_aux_all[sub];
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -103,8 +105,11 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     float T = 0.0f;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pix_n > 0u) { T = final_T[p]; g = loss_grad[p]; }
-    const float pxf = (float)pixel_x + 0.5f, pyf = (float)pixel_y + 0.5f;
-    float ar_r = 0.f, ar_g = 0.f, ar_b = 0.f, lc_r = 0.f, lc_g = 0.f, lc_b = 0.f, la = 0.f;
+    const f2 pxy = (f2){(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
+    const f2 g_rg = (f2){g.x, g.y};
+    const float g_b = g.z;
+    f2 ar_rg = (f2){0.f, 0.f}, lc_rg = (f2){0.f, 0.f};
+    float ar_b = 0.f, lc_b = 0.f, la = 0.f;
 
     // chunk [lo, hi) of the tile list, lane j <-> entry lo + j; software pipeline: index two chunks ahead, Splat one ahead
     auto chunk_lo = [&](u32 hi_) { return (hi_ > 64u) ? hi_ - 64u : 0u; };
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
             s_geo[slot] = make_float4(cx, cy, ex, ey);
             s_con[slot] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
             s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx_c));
-            s_pos[slot] = lo + lane;
+            s_aux[slot] = make_float4(__uint_as_float(lo + lane), 2.0f * wd_unpack_lo(w23.x), 2.0f * wd_unpack_hi(w23.x), 2.0f * wd_unpack_lo(w23.y));
         }
         // next chunk's Splat gather and the index fetch of the chunk after it: in flight while this chunk is processed
         gidx_c = gidx_n;
@@ -148,12 +153,14 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
 
         for (u32 i = n_list; i-- > 0u;) {  // back to front
             const float4 geo = s_geo[i];
-            const float dx = pxf - geo.x, dy = pyf - geo.y;
-            const bool cand = (s_pos[i] < pix_n) && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
+            const float4 aux = s_aux[i];  // entry position (bits), 2*conic.x, 2*conic.y, 2*conic.z
+            const f2 d = pxy - (f2){geo.x, geo.y};
+            // (bitwise, not short-circuit: one LDS round trip and no branches for the three tests)
+            const bool cand = ((int)(__float_as_uint(aux.x) < pix_n) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
             if (!__any(cand)) continue;
             const float4 con = s_con[i];
-            const float t1 = __builtin_fmaf(con.x, dx, (2.0f * con.y) * dy);
-            const float power = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
+            const float t1 = __builtin_fmaf(con.x, d.x, aux.z * d.y);
+            const float power = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
             const float G = wd_exp(-0.5f * power);
             const float og = con.w * G;
             const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
@@ -162,31 +169,35 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
             const float4 col = s_col[i];
             int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
             if (act) {
+                // Two-wide (v_pk_*_f32) where the reference has the same operation on two components; every product and sum
+                // below is the reference's own, in its order (tiled-backward-rasterize.wgsl:108-160).
                 T = wd_div(T, 1.0f - alpha);
-                ar_r = la * lc_r + (1.0f - la) * ar_r;
-                ar_g = la * lc_g + (1.0f - la) * ar_g;
-                ar_b = la * lc_b + (1.0f - la) * ar_b;
+                const float oml = 1.0f - la;
+                ar_rg = la * lc_rg + oml * ar_rg;
+                ar_b = la * lc_b + oml * ar_b;
                 const float aT = alpha * T;
-                f_r = to_fixed(aT * g.x);
-                f_g = to_fixed(aT * g.y);
-                f_b = to_fixed(aT * g.z);
-                float dL_dalpha = 0.0f;
-                dL_dalpha += (col.x - ar_r) * g.x;
-                dL_dalpha += (col.y - ar_g) * g.y;
-                dL_dalpha += (col.z - ar_b) * g.z;
-                dL_dalpha *= T;
-                la = alpha; lc_r = col.x; lc_g = col.y; lc_b = col.z;
+                const f2 frg = (aT * g_rg) * FIXED_SCALE;
+                f_r = cvt_fixed(frg.x);
+                f_g = cvt_fixed(frg.y);
+                f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
+                const f2 col_rg = (f2){col.x, col.y};
+                const f2 p_rg = (col_rg - ar_rg) * g_rg;
+                // (the reference starts this sum from 0.0; that only decides the sign of an all-zero sum, which the fixed-point
+                // conversion of every product it feeds maps to 0 either way)
+                const float dL_dalpha = ((p_rg.x + p_rg.y) + (col.z - ar_b) * g_b) * T;
+                la = alpha; lc_rg = col_rg; lc_b = col.z;
                 const float dL_dG = con.w * dL_dalpha;
-                f_op = to_fixed(G * dL_dalpha);
-                const float dpow_dx = 2.0f * con.x * dx + 2.0f * con.y * dy;
-                const float dpow_dy = 2.0f * con.z * dy + 2.0f * con.y * dx;
+                f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
+                const f2 dpow = (f2){aux.y, aux.w} * d + (f2){aux.z, aux.z} * (f2){d.y, d.x};  // (dpow/ddx, dpow/ddy)
                 const float mhG = -0.5f * G;
-                const float dG_ddx = mhG * dpow_dx, dG_ddy = mhG * dpow_dy;
-                f_mx = to_fixed(dL_dG * (-dG_ddx));
-                f_my = to_fixed(dL_dG * (-dG_ddy));
-                f_cx = to_fixed(dL_dG * (mhG * dx * dx));
-                f_cy = to_fixed(dL_dG * (mhG * 2.0f * dx * dy));
-                f_cz = to_fixed(dL_dG * (mhG * dy * dy));
+                const f2 dG = mhG * dpow;
+                const f2 fm = (dL_dG * (-dG)) * FIXED_SCALE;
+                f_mx = cvt_fixed(fm.x);
+                f_my = cvt_fixed(fm.y);
+                const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;  // conic.x and conic.z terms
+                f_cx = cvt_fixed(fc.x);
+                f_cz = cvt_fixed(fc.y);
+                f_cy = cvt_fixed((dL_dG * (((mhG * 2.0f) * d.x) * d.y)) * FIXED_SCALE);
             }
             // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
             // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
