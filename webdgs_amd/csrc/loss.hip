@@ -1,30 +1,36 @@
 // Per-pixel loss gradient (K15): lambda_l1*sign(d) + lambda_l2*d + lambda_dssim * 0.5*(1-SSIM_5x5)*d.
 //
 // Replaces compute_loss_grad (src/shaders/loss.wgsl:85-115, computeSSIMGrad 30-82), which issues 2 x 25 x 2
-// uncached texture loads per pixel.  Here a 16x16 workgroup stages the 20x20 halo of both images in LDS as float4
+// uncached texture loads per pixel.  Here a workgroup stages the 36x36 halo of a 32x32 tile of both images in LDS as float4
 // texels (clamp-to-edge), converting rgba8unorm -> f32 ONCE per texel through a 256-entry table of i/255 (each entry one
 // correctly rounded division, so values equal the per-tap f32(u8)/255 of the restatement).  HBM traffic is the
-// compulsory 8 B read + 16 B write per pixel; the 2 x 50 window taps are broadcast-free ds_read_b128.
+// compulsory 8 B read + 16 B write per pixel; window taps are conflict-free ds_read_b128, shared by four pixels per thread.
 // The window sums keep the reference's order (dy outer, dx inner, one rounding per add).
 #include "common.h"
 #include "dmath.h"
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 WD_DEV float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+constexpr u32 LT = 32;       // tile edge in pixels
+constexpr u32 LH = LT + 4;   // halo edge in texels
+constexpr u32 PPT = 4;       // vertically adjacent pixels per thread
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32* __restrict__ pred, const u32* __restrict__ targ,
                                                          wdgs_training_config cfg, float4* __restrict__ out) {
     __shared__ float s_lut[256];
-    // row stride 32 float4 = 512 B: rows land on the same banks, so the four 16-lane groups of a ds_read_b128 (which mix two
-    // tile rows) stay conflict-free; a 20-wide row (320 B) made 59% of the LDS cycles bank conflicts.
-    __shared__ float4 sp[20][32];
-    __shared__ float4 st[20][32];
+    // A thread row is 32 lanes on 32 consecutive texels, so each 16-lane group of a ds_read_b128 covers 256 contiguous
+    // bytes = every bank once, whatever the row stride.
+    __shared__ float4 sp[LH][LH];
+    __shared__ float4 st[LH][LH];
     s_lut[threadIdx.x] = wd_div((float)threadIdx.x, 255.0f);
     __syncthreads();
-    const int bx = blockIdx.x * 16, by = blockIdx.y * 16;
-    for (u32 t = threadIdx.x; t < 400u; t += 256u) {
-        const int hy = (int)(t / 20u), hx = (int)(t % 20u);
+    const int bx = blockIdx.x * LT, by = blockIdx.y * LT;
+    for (u32 t = threadIdx.x; t < LH * LH; t += 256u) {
+        const int hy = (int)(t / LH), hx = (int)(t % LH);
         int gx = bx + hx - 2, gy = by + hy - 2;
         gx = gx < 0 ? 0 : (gx > (int)W - 1 ? (int)W - 1 : gx);
         gy = gy < 0 ? 0 : (gy > (int)H - 1 ? (int)H - 1 : gy);
@@ -33,64 +39,105 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
         st[hy][hx] = make_float4(s_lut[b & 0xFFu], s_lut[(b >> 8) & 0xFFu], s_lut[(b >> 16) & 0xFFu], 0.0f);
     }
     __syncthreads();
-    const u32 lx = threadIdx.x & 15u, ly = threadIdx.x >> 4;
-    const u32 x = bx + lx, y = by + ly;
-    if (x >= W || y >= H) return;
+    // Each thread owns PPT vertically adjacent pixels: their 5x5 windows share 8 x 5 texels, so a texel is read from LDS once
+    // per pass instead of up to four times (the kernel is bound by LDS read bandwidth).  Walking the shared texels row-major
+    // feeds every pixel its own window in the reference's order (dy outer, dx inner), one rounding per add.
+    const u32 lx = threadIdx.x & (LT - 1u), ly0 = (threadIdx.x / LT) * PPT;
+    const u32 x = bx + lx, y0 = by + ly0;
+    if (x >= W || y0 >= H) return;
 
-    const float4 p = sp[ly + 2][lx + 2], t = st[ly + 2][lx + 2];
-    const float d[3] = {p.x - t.x, p.y - t.y, p.z - t.z};
-    float g[3] = {0.0f, 0.0f, 0.0f};
-    if (cfg.lambda_dssim > 0.0f) {
-        float mx[3] = {0, 0, 0}, my[3] = {0, 0, 0};
+    const bool dssim = cfg.lambda_dssim > 0.0f;
+    const float n = 25.0f;
+    float mx[PPT][3], my[PPT][3], sx2[PPT][3], sy2[PPT][3], sxy[PPT][3];
+    if (dssim) {
+        // two channels per instruction (v_pk_add/mul_f32 on (r,g) and (b,0)): each half is the reference's scalar operation
+        f2 mxa[PPT], mxb[PPT], mya[PPT], myb[PPT];
 #pragma unroll
-        for (u32 dy = 0; dy < 5u; dy++)
+        for (u32 k = 0; k < PPT; k++) mxa[k] = mxb[k] = mya[k] = myb[k] = (f2){0.f, 0.f};
 #pragma unroll
-            for (u32 dx = 0; dx < 5u; dx++) {
-                const float4 a = sp[ly + dy][lx + dx], b = st[ly + dy][lx + dx];
-                mx[0] += a.x; mx[1] += a.y; mx[2] += a.z;
-                my[0] += b.x; my[1] += b.y; my[2] += b.z;
+        for (u32 r = 0; r < PPT + 4u; r++) {
+#pragma unroll
+            for (u32 c = 0; c < 5u; c++) {
+                const float4 a = sp[ly0 + r][lx + c], b = st[ly0 + r][lx + c];
+#pragma unroll
+                for (u32 k = 0; k < PPT; k++)
+                    if (r >= k && r <= k + 4u) {
+                        mxa[k] += (f2){a.x, a.y}; mxb[k] += (f2){a.z, a.w};
+                        mya[k] += (f2){b.x, b.y}; myb[k] += (f2){b.z, b.w};
+                    }
             }
-        const float n = 25.0f;
+            // pin the running sums here: otherwise the adds are sunk to their use and every loaded texel stays live (500 VGPRs)
 #pragma unroll
-        for (int c = 0; c < 3; c++) { mx[c] = wd_div(mx[c], n); my[c] = wd_div(my[c], n); }
-        float sx2[3] = {0, 0, 0}, sy2[3] = {0, 0, 0}, sxy[3] = {0, 0, 0};
+            for (u32 k = 0; k < PPT; k++) asm volatile("" : "+v"(mxa[k]), "+v"(mxb[k]), "+v"(mya[k]), "+v"(myb[k]));
+        }
+        f2 sx2a[PPT], sx2b[PPT], sy2a[PPT], sy2b[PPT], sxya[PPT], sxyb[PPT], ma[PPT], mb[PPT], na[PPT], nb[PPT];
 #pragma unroll
-        for (u32 dy = 0; dy < 5u; dy++)
+        for (u32 k = 0; k < PPT; k++) {
+            mx[k][0] = wd_div(mxa[k].x, n); mx[k][1] = wd_div(mxa[k].y, n); mx[k][2] = wd_div(mxb[k].x, n);
+            my[k][0] = wd_div(mya[k].x, n); my[k][1] = wd_div(mya[k].y, n); my[k][2] = wd_div(myb[k].x, n);
+            ma[k] = (f2){mx[k][0], mx[k][1]}; mb[k] = (f2){mx[k][2], 0.f};
+            na[k] = (f2){my[k][0], my[k][1]}; nb[k] = (f2){my[k][2], 0.f};
+            sx2a[k] = sx2b[k] = sy2a[k] = sy2b[k] = sxya[k] = sxyb[k] = (f2){0.f, 0.f};
+        }
 #pragma unroll
-            for (u32 dx = 0; dx < 5u; dx++) {
-                const float4 a = sp[ly + dy][lx + dx], b = st[ly + dy][lx + dx];
-                const float da[3] = {a.x - mx[0], a.y - mx[1], a.z - mx[2]}, db[3] = {b.x - my[0], b.y - my[1], b.z - my[2]};
+        for (u32 r = 0; r < PPT + 4u; r++) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    sx2[c] += da[c] * da[c];
-                    sy2[c] += db[c] * db[c];
-                    sxy[c] += da[c] * db[c];
-                }
+            for (u32 c = 0; c < 5u; c++) {
+                const float4 a = sp[ly0 + r][lx + c], b = st[ly0 + r][lx + c];
+#pragma unroll
+                for (u32 k = 0; k < PPT; k++)
+                    if (r >= k && r <= k + 4u) {
+                        const f2 daa = (f2){a.x, a.y} - ma[k], dab = (f2){a.z, a.w} - mb[k];
+                        const f2 dba = (f2){b.x, b.y} - na[k], dbb = (f2){b.z, b.w} - nb[k];
+                        sx2a[k] += daa * daa; sx2b[k] += dab * dab;
+                        sy2a[k] += dba * dba; sy2b[k] += dbb * dbb;
+                        sxya[k] += daa * dba; sxyb[k] += dab * dbb;
+                    }
             }
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float vx = wd_div(sx2[c], n), vy = wd_div(sy2[c], n), vxy = wd_div(sxy[c], n);
-            const float num1 = 2.0f * mx[c] * my[c] + cfg.c1;
-            const float num2 = 2.0f * vxy + cfg.c2;
-            const float den1 = mx[c] * mx[c] + my[c] * my[c] + cfg.c1;
-            const float den2 = vx + vy + cfg.c2;
-            const float ssim = wd_div(num1 * num2, den1 * den2);
-            g[c] = ((1.0f - ssim) * 0.5f) * d[c];
+            for (u32 k = 0; k < PPT; k++)
+                asm volatile("" : "+v"(sx2a[k]), "+v"(sx2b[k]), "+v"(sy2a[k]), "+v"(sy2b[k]), "+v"(sxya[k]), "+v"(sxyb[k]));
+        }
+#pragma unroll
+        for (u32 k = 0; k < PPT; k++) {
+            sx2[k][0] = sx2a[k].x; sx2[k][1] = sx2a[k].y; sx2[k][2] = sx2b[k].x;
+            sy2[k][0] = sy2a[k].x; sy2[k][1] = sy2a[k].y; sy2[k][2] = sy2b[k].x;
+            sxy[k][0] = sxya[k].x; sxy[k][1] = sxya[k].y; sxy[k][2] = sxyb[k].x;
         }
     }
-    float4 o;
-    o.x = cfg.lambda_l1 * sgn(d[0]) + cfg.lambda_l2 * d[0] + cfg.lambda_dssim * g[0];
-    o.y = cfg.lambda_l1 * sgn(d[1]) + cfg.lambda_l2 * d[1] + cfg.lambda_dssim * g[1];
-    o.z = cfg.lambda_l1 * sgn(d[2]) + cfg.lambda_l2 * d[2] + cfg.lambda_dssim * g[2];
-    o.w = 1.0f;
-    out[(size_t)y * W + x] = o;
+#pragma unroll
+    for (u32 k = 0; k < PPT; k++) {
+        const u32 y = y0 + k;
+        if (y >= H) break;
+        const float4 p = sp[ly0 + k + 2u][lx + 2u], t = st[ly0 + k + 2u][lx + 2u];
+        const float d[3] = {p.x - t.x, p.y - t.y, p.z - t.z};
+        float g[3] = {0.0f, 0.0f, 0.0f};
+        if (dssim) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float vx = wd_div(sx2[k][c], n), vy = wd_div(sy2[k][c], n), vxy = wd_div(sxy[k][c], n);
+                const float num1 = 2.0f * mx[k][c] * my[k][c] + cfg.c1;
+                const float num2 = 2.0f * vxy + cfg.c2;
+                const float den1 = mx[k][c] * mx[k][c] + my[k][c] * my[k][c] + cfg.c1;
+                const float den2 = vx + vy + cfg.c2;
+                const float ssim = wd_div(num1 * num2, den1 * den2);
+                g[c] = ((1.0f - ssim) * 0.5f) * d[c];
+            }
+        }
+        float4 o;
+        o.x = cfg.lambda_l1 * sgn(d[0]) + cfg.lambda_l2 * d[0] + cfg.lambda_dssim * g[0];
+        o.y = cfg.lambda_l1 * sgn(d[1]) + cfg.lambda_l2 * d[1] + cfg.lambda_dssim * g[1];
+        o.z = cfg.lambda_l1 * sgn(d[2]) + cfg.lambda_l2 * d[2] + cfg.lambda_dssim * g[2];
+        o.w = 1.0f;
+        out[(size_t)y * W + x] = o;
+    }
 }
 
 }  // namespace
 
 int launch_loss_grad(wdgs_device* dev, u32 W, u32 H, const void* pred, const void* targ, const wdgs_training_config& cfg, void* out) {
     if (W == 0 || H == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "loss_grad", loss_grad_kernel, dim3(ceil_div(W, 16), ceil_div(H, 16)), dim3(256), 0, W, H, (const u32*)pred, (const u32*)targ, cfg,
+    WDGS_LAUNCH(dev, "loss_grad", loss_grad_kernel, dim3(ceil_div(W, LT), ceil_div(H, LT)), dim3(256), 0, W, H, (const u32*)pred, (const u32*)targ, cfg,
                 (float4*)out);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
