@@ -107,13 +107,16 @@ __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings,
             for (u32 i = 0; i < cnt; i++) {
                 const float4 geo = s_geo[i];
                 const float dx = px - geo.x, dy = py - geo.y;
-                const bool inside = in_bounds && !(fabsf(dx) > geo.z || fabsf(dy) > geo.w);
+                // (bitwise, not short-circuit: one LDS round trip and no branches for the tests)
+                const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;
                 if (GAUSSIAN_MODE) {
-                    const bool active = inside && !(A > 0.99f);
+                    const bool active = ((int)inside & (int)!(A > 0.99f)) != 0;
                     if (!__any(active)) continue;
+                    const float4 con = s_con[i];
+                    const float4 col = s_col[i];
+                    u32 entry_pos = __float_as_uint(col.w);
+                    asm volatile("" : "+v"(entry_pos));  // keep the record a single ds_read_b128 (no second, conditional LDS round trip)
                     if (active) {
-                        const float4 con = s_con[i];
-                        const float4 col = s_col[i];
                         const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
                         const float q = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
                         const float G = wd_exp(-0.5f * q);
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings,
                         cg = __builtin_fmaf(col.y, w, cg);
                         cb = __builtin_fmaf(col.z, w, cb);
                         A = A + w;
-                        if (alpha >= (1.0f / 255.0f)) last_contributor = __float_as_uint(col.w);
+                        last_contributor = (alpha >= (1.0f / 255.0f)) ? entry_pos : last_contributor;
                     }
                 } else {
                     // point-cloud preview (tiled-rasterizer.wgsl:212-222): paints yellow discs, no saturation test
