@@ -110,6 +110,7 @@ def main() -> None:
 
     for _ in range(args.warmup):
         trainer.step()
+    trainer.warmupCommandBuffers()  # every view's command buffer recorded before the clock starts (set-up, like pipeline creation)
     stats = trainer.forwardPass.check()  # raises on tile-entry overflow
 
     # ---- timed region: recorded command buffers (HIP graphs), no per-kernel events

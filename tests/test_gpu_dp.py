@@ -1,0 +1,55 @@
+"""GPU, two processes: the Trainer's view-sharded data-parallel step end to end -- per-rank K1..K17, fp32
+accumulation, the gradient exchange, one Adam on every rank -- must leave BOTH replicas bit-identical to a single process that
+takes the same two views per step.  The exchange runs over gloo here (both ranks share the one GPU of the test box, which
+RCCL refuses); on a multi-GPU node the same code path runs over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from webdgs_amd import ops
+from webdgs_amd.trainer import Trainer
+
+import dp_common
+from harness import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("use_cb", [False, True])
+def test_two_rank_training_equals_single_process_batch_of_two(hip_device, tmp_path, use_cb):
+    steps = 7
+    env = dict(os.environ, WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(HERE, "dp_worker.py"), str(tmp_path), str(steps), "1" if use_cb else "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    assert_bits_equal(ranks[0]["gaussians"], ranks[1]["gaussians"], "replica gaussians")
+    assert_bits_equal(ranks[0]["sh"], ranks[1]["sh"], "replica sh")
+
+    cfg, g, sh, cameras, images = dp_common.dataset(hip_device)
+    t = Trainer(hip_device, seed=11, world_size=1, rank=0, views_per_rank=2, use_command_buffers=use_cb)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.setPointCloud(ops.createPointCloud(hip_device, g, sh, cfg.sh_deg))
+    t.setDataset(cameras, images)
+    t.start()
+    for ids in dp_common.view_schedule(steps, 2):
+        t.step(ids)
+    hip_device.synchronize()
+    assert_bits_equal(t.pointCloud.gaussian_3d_buffer.read(np.uint32), ranks[0]["gaussians"], "2 ranks x 1 view vs 1 rank x 2 views: gaussians")
+    assert_bits_equal(t.pointCloud.sh_buffer.read(np.uint32), ranks[0]["sh"], "2 ranks x 1 view vs 1 rank x 2 views: sh")
+    assert int(ranks[0]["iteration"][0]) == t.optimizer.getIteration() == steps
+    assert not np.array_equal(ranks[0]["gaussians"], g.reshape(ranks[0]["gaussians"].shape)), "training did not move the parameters"

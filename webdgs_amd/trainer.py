@@ -261,12 +261,28 @@ class Trainer:
                    alphaTexture=self.rasterizer.getAlphaTextureView(), nContribTexture=self.rasterizer.getNContribTextureView())
         self.backwardPass.encode(encoder, self.rasterizer.getOutputTextureView(), image["texture"], res)
 
-    def step(self) -> None:
+    def warmupCommandBuffers(self) -> int:
+        """Runs training steps on every view in turn until each view's command buffer is recorded (the first pass over a
+        dataset does this anyway; calling it up front keeps recording out of a timed region).  Returns the steps taken."""
+        if not self.use_command_buffers or not self.isTraining or self.pointCloud is None:
+            return 0
+        n_views, taken = self.world_size * self.views_per_rank, 0
+        for v in range(len(self.trainCameras)):
+            ids = [v] * n_views
+            while tuple(parallel.shard_views(ids, self.rank, self.world_size)) not in self._cmd_cache and taken < 4 * len(self.trainCameras) + 4:
+                self.step(ids)
+                taken += 1
+        return taken
+
+    def step(self, view_ids: Optional[list] = None) -> None:
+        """One training iteration (trainer.ts:568-660).  ``view_ids``: the global batch's views (default: drawn at random, as the
+        reference picks ``Math.random()`` per step); with ``world_size > 1`` each rank takes its shard."""
         if not self.isTraining or self.pointCloud is None:
             return
         stepStart = time.perf_counter()
         n_views = self.world_size * self.views_per_rank
-        view_ids = [self._rng.randrange(len(self.trainCameras)) for _ in range(n_views)]
+        if view_ids is None:
+            view_ids = [self._rng.randrange(len(self.trainCameras)) for _ in range(n_views)]
         mine = parallel.shard_views(view_ids, self.rank, self.world_size)
         image0 = self.images[mine[0]]
         self.ensurePipelines(image0["width"], image0["height"])
@@ -334,10 +350,18 @@ class Trainer:
             self.stop()
 
     def _allreduce(self) -> None:
+        if self.world_size <= 1:
+            return
         n = self.pointCloud.num_points
         g = self._dp_grad.tensor().view(torch.float32)[: parallel.GRAD_FLOATS * n]
         vis = self._dp_visible.tensor()[:n]
+        # Host-side fences on both sides of the exchange instead of cross-stream event waits: the collective runs on the
+        # process group's own stream, and a 2-rank rehearsal on one GPU (gloo, ranks in lock-step) showed the Adam launch
+        # that follows overtaking the copy-back of the reduced block when ordered by stream-wait-event alone.  Two fences
+        # cost ~20 us of a >1.3 ms step and make the order independent of the backend's stream handling.
+        self.device.torch_stream.synchronize()
         parallel.allreduce_gradients(g, vis)
+        torch.cuda.synchronize(self.device.torch_device)
 
     # ------------------------------------------------------------------ densify / prune
     def runDensifyPruneMultiView(self) -> None:
@@ -377,7 +401,9 @@ class Trainer:
             mc = self.metricsPass.getMetricCountsBuffer()
             t = torch.empty(n, dtype=torch.int32, device=self.device.torch_device)
             t.copy_(torch.from_numpy(mc.read(np.int32, count=n)))  # library-owned buffer -> torch tensor for the collective
+            self.device.torch_stream.synchronize()  # fences as in _allreduce
             parallel.allreduce_counts(t)
+            torch.cuda.synchronize(self.device.torch_device)
             mc.write(t.cpu().numpy())
         self.metricsPass.normalizeMetricCounts(encoder, dict(divisor=usedViews))
         self.densifyPrune.ensureSize(self.pointCloud.num_points)
