@@ -189,6 +189,13 @@ def main() -> None:
             fl = fwd_flops if dom == "rasterize" else bwd_flops
             roofline.update(valu_achieved_tflops=round(fl / dur_s / 1e12, 3), valu_peak_tflops=157.3, valu_frac=round(fl / dur_s / 157.3e12, 5))
 
+    # every stage against the HBM roof (algorithmic bytes / live duration): the streaming stages are the ones it binds
+    hbm_by_stage = {}
+    for k, ms in per_step.items():
+        ab = algorithmic_bytes(k, n, v_visible, e_entries, p_pix, tiles, k_coef, passes)
+        if ab > 0 and ms > 0:
+            hbm_by_stage[k] = dict(GBps=round(ab / (ms / 1e3) / 1e9, 1), frac=round(ab / (ms / 1e3) / 8.0e12, 4))
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
 
@@ -209,7 +216,7 @@ def main() -> None:
                        "densify_schedule": "reference defaults (warm-up 500): not reached in this run",
                        "iter_definition": "one training view (fwd+bwd); a global step = n_gpus views + 1 gradient all-reduce + 1 Adam"},
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "hbm_roofline_by_stage": hbm_by_stage, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
 

@@ -48,7 +48,7 @@ WD_DEV int fold16(int a, int b) {
     return (int)(r[0] + r[1]);
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));  // maps to v_pk_{add,mul}_f32: two IEEE binary32 operations per instruction
+typedef wd_pair f2;  // component-wise scalar arithmetic (dmath.h)
 
 constexpr float FIXED_SCALE = 1000000.0f;  // common.wgsl:113-116
 WD_DEV int cvt_fixed(float scaled) {
@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     float T = 0.0f;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pix_n > 0u) { T = final_T[p]; g = loss_grad[p]; }
-    const f2 pxy = (f2){(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
-    const f2 g_rg = (f2){g.x, g.y};
+    const f2 pxy = f2{(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
+    const f2 g_rg = f2{g.x, g.y};
     const float g_b = g.z;
-    f2 ar_rg = (f2){0.f, 0.f}, lc_rg = (f2){0.f, 0.f};
+    f2 ar_rg = f2{0.f, 0.f}, lc_rg = f2{0.f, 0.f};
     float ar_b = 0.f, lc_b = 0.f, la = 0.f;
 
     // chunk [lo, hi) of the tile list, lane j <-> entry lo + j; software pipeline: index two chunks ahead, Splat one ahead
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
         for (u32 i = n_list; i-- > 0u;) {  // back to front
             const float4 geo = s_geo[i];
             const float4 aux = s_aux[i];  // entry position (bits), 2*conic.x, 2*conic.y, 2*conic.z
-            const f2 d = pxy - (f2){geo.x, geo.y};
+            const f2 d = pxy - f2{geo.x, geo.y};
             // (bitwise, not short-circuit: one LDS round trip and no branches for the three tests)
             const bool cand = ((int)(__float_as_uint(aux.x) < pix_n) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
             if (!__any(cand)) continue;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
             const float4 col = s_col[i];
             int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
             if (act) {
-                // Two-wide (v_pk_*_f32) where the reference has the same operation on two components; every product and sum
-                // below is the reference's own, in its order (tiled-backward-rasterize.wgsl:108-160).
+                // Pairs (f2) are plain component-wise scalar arithmetic; every product and sum below is the reference's own, in its
+                // order (tiled-backward-rasterize.wgsl:108-160).
                 T = wd_div(T, 1.0f - alpha);
                 const float oml = 1.0f - la;
                 ar_rg = la * lc_rg + oml * ar_rg;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
                 f_r = cvt_fixed(frg.x);
                 f_g = cvt_fixed(frg.y);
                 f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
-                const f2 col_rg = (f2){col.x, col.y};
+                const f2 col_rg = f2{col.x, col.y};
                 const f2 p_rg = (col_rg - ar_rg) * g_rg;
                 // (the reference starts this sum from 0.0; that only decides the sign of an all-zero sum, which the fixed-point
                 // conversion of every product it feeds maps to 0 either way)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
                 la = alpha; lc_rg = col_rg; lc_b = col.z;
                 const float dL_dG = con.w * dL_dalpha;
                 f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
-                const f2 dpow = (f2){aux.y, aux.w} * d + (f2){aux.z, aux.z} * (f2){d.y, d.x};  // (dpow/ddx, dpow/ddy)
+                const f2 dpow = f2{aux.y, aux.w} * d + f2{aux.z, aux.z} * f2{d.y, d.x};  // (dpow/ddx, dpow/ddy)
                 const float mhG = -0.5f * G;
                 const f2 dG = mhG * dpow;
                 const f2 fm = (dL_dG * (-dG)) * FIXED_SCALE;

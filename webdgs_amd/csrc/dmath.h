@@ -36,6 +36,20 @@ WD_DEV float wd_exp(float x) {
     return res;
 }
 
+// Two-component float value with component-wise IEEE operations, written out as scalar instructions.  (On gfx950 a wave64 VALU
+// instruction issues at 32 lanes/cycle; v_pk_*_f32 costs two issue slots plus hazard nops, so packing two fp32 operations into
+// one instruction gains nothing -- measured: the same kernels run 2-16 % faster with scalar code and -fno-slp-vectorize.)
+struct wd_pair {
+    float x, y;
+};
+WD_DEV wd_pair operator+(wd_pair a, wd_pair b) { return {a.x + b.x, a.y + b.y}; }
+WD_DEV wd_pair operator-(wd_pair a, wd_pair b) { return {a.x - b.x, a.y - b.y}; }
+WD_DEV wd_pair operator*(wd_pair a, wd_pair b) { return {a.x * b.x, a.y * b.y}; }
+WD_DEV wd_pair operator*(float s, wd_pair b) { return {s * b.x, s * b.y}; }
+WD_DEV wd_pair operator*(wd_pair a, float s) { return {a.x * s, a.y * s}; }
+WD_DEV wd_pair operator-(wd_pair a) { return {-a.x, -a.y}; }
+WD_DEV wd_pair& operator+=(wd_pair& a, wd_pair b) { a.x += b.x; a.y += b.y; return a; }
+
 WD_DEV float wd_log(float x) {
     if (x != x) return x;
     if (x < 0.0f) return __builtin_nanf("");
@@ -90,7 +104,14 @@ WD_DEV int32_t wd_to_i32(float v) {
 }
 
 // fp16 pack/unpack (round to nearest even, subnormals kept, overflow to inf).
-WD_DEV uint32_t wd_f16bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+// f32 -> f16, round to nearest even, of the ROUNDED f32 value.  The empty asm makes that value opaque: otherwise the compiler
+// may fold a preceding f32 multiply into v_fma_mixlo_f16, which rounds the exact product once, straight to f16 -- not what the
+// reference's f32 arithmetic followed by pack2x16float does (seen in K17: a product that is an exact f16 tie after its f32
+// rounding packed to the other neighbour).
+WD_DEV uint32_t wd_f16bits(float f) {
+    asm("" : "+v"(f));
+    return (uint32_t)__half_as_ushort(__float2half_rn(f));
+}
 WD_DEV uint32_t wd_pack2(float x, float y) { return wd_f16bits(x) | (wd_f16bits(y) << 16); }
 WD_DEV float wd_unpack_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))); }
 WD_DEV float wd_unpack_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }

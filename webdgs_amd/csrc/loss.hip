@@ -11,7 +11,7 @@
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+typedef wd_pair f2;  // component-wise scalar arithmetic (dmath.h)
 
 WD_DEV float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
     const float n = 25.0f;
     float mx[PPT][3], my[PPT][3], sx2[PPT][3], sy2[PPT][3], sxy[PPT][3];
     if (dssim) {
-        // two channels per instruction (v_pk_add/mul_f32 on (r,g) and (b,0)): each half is the reference's scalar operation
+        // channel pairs (r,g) and (b,-) as f2: component-wise scalar arithmetic, each the reference's own operation
         f2 mxa[PPT], mxb[PPT], mya[PPT], myb[PPT];
 #pragma unroll
-        for (u32 k = 0; k < PPT; k++) mxa[k] = mxb[k] = mya[k] = myb[k] = (f2){0.f, 0.f};
+        for (u32 k = 0; k < PPT; k++) mxa[k] = mxb[k] = mya[k] = myb[k] = f2{0.f, 0.f};
 #pragma unroll
         for (u32 r = 0; r < PPT + 4u; r++) {
 #pragma unroll
@@ -62,22 +62,23 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
 #pragma unroll
                 for (u32 k = 0; k < PPT; k++)
                     if (r >= k && r <= k + 4u) {
-                        mxa[k] += (f2){a.x, a.y}; mxb[k] += (f2){a.z, a.w};
-                        mya[k] += (f2){b.x, b.y}; myb[k] += (f2){b.z, b.w};
+                        mxa[k] += f2{a.x, a.y}; mxb[k] += f2{a.z, a.w};
+                        mya[k] += f2{b.x, b.y}; myb[k] += f2{b.z, b.w};
                     }
             }
             // pin the running sums here: otherwise the adds are sunk to their use and every loaded texel stays live (500 VGPRs)
 #pragma unroll
-            for (u32 k = 0; k < PPT; k++) asm volatile("" : "+v"(mxa[k]), "+v"(mxb[k]), "+v"(mya[k]), "+v"(myb[k]));
+            for (u32 k = 0; k < PPT; k++)
+                asm volatile("" : "+v"(mxa[k].x), "+v"(mxa[k].y), "+v"(mxb[k].x), "+v"(mya[k].x), "+v"(mya[k].y), "+v"(myb[k].x));
         }
         f2 sx2a[PPT], sx2b[PPT], sy2a[PPT], sy2b[PPT], sxya[PPT], sxyb[PPT], ma[PPT], mb[PPT], na[PPT], nb[PPT];
 #pragma unroll
         for (u32 k = 0; k < PPT; k++) {
             mx[k][0] = wd_div(mxa[k].x, n); mx[k][1] = wd_div(mxa[k].y, n); mx[k][2] = wd_div(mxb[k].x, n);
             my[k][0] = wd_div(mya[k].x, n); my[k][1] = wd_div(mya[k].y, n); my[k][2] = wd_div(myb[k].x, n);
-            ma[k] = (f2){mx[k][0], mx[k][1]}; mb[k] = (f2){mx[k][2], 0.f};
-            na[k] = (f2){my[k][0], my[k][1]}; nb[k] = (f2){my[k][2], 0.f};
-            sx2a[k] = sx2b[k] = sy2a[k] = sy2b[k] = sxya[k] = sxyb[k] = (f2){0.f, 0.f};
+            ma[k] = f2{mx[k][0], mx[k][1]}; mb[k] = f2{mx[k][2], 0.f};
+            na[k] = f2{my[k][0], my[k][1]}; nb[k] = f2{my[k][2], 0.f};
+            sx2a[k] = sx2b[k] = sy2a[k] = sy2b[k] = sxya[k] = sxyb[k] = f2{0.f, 0.f};
         }
 #pragma unroll
         for (u32 r = 0; r < PPT + 4u; r++) {
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
 #pragma unroll
                 for (u32 k = 0; k < PPT; k++)
                     if (r >= k && r <= k + 4u) {
-                        const f2 daa = (f2){a.x, a.y} - ma[k], dab = (f2){a.z, a.w} - mb[k];
-                        const f2 dba = (f2){b.x, b.y} - na[k], dbb = (f2){b.z, b.w} - nb[k];
+                        const f2 daa = f2{a.x, a.y} - ma[k], dab = f2{a.z, a.w} - mb[k];
+                        const f2 dba = f2{b.x, b.y} - na[k], dbb = f2{b.z, b.w} - nb[k];
                         sx2a[k] += daa * daa; sx2b[k] += dab * dab;
                         sy2a[k] += dba * dba; sy2b[k] += dbb * dbb;
                         sxya[k] += daa * dba; sxyb[k] += dab * dbb;
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
             }
 #pragma unroll
             for (u32 k = 0; k < PPT; k++)
-                asm volatile("" : "+v"(sx2a[k]), "+v"(sx2b[k]), "+v"(sy2a[k]), "+v"(sy2b[k]), "+v"(sxya[k]), "+v"(sxyb[k]));
+                asm volatile("" : "+v"(sx2a[k].x), "+v"(sx2a[k].y), "+v"(sx2b[k].x), "+v"(sy2a[k].x), "+v"(sy2a[k].y), "+v"(sy2b[k].x), "+v"(sxya[k].x),
+                             "+v"(sxya[k].y), "+v"(sxyb[k].x));
         }
 #pragma unroll
         for (u32 k = 0; k < PPT; k++) {
