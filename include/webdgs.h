@@ -248,6 +248,11 @@ int wdgs_downsample_rgba8(wdgs_device* dev, const void* src_dev, uint32_t src_w,
  * The reference has no scalar loss (it only visualises the gradient image, trainer.ts:695-768); PSNR = 10 log10(255^2 * 3P / SSE). */
 int wdgs_image_sse_rgb8(wdgs_device* dev, const void* a_rgba8_dev, const void* b_rgba8_dev, uint32_t num_pixels, void* out_u64_dev);
 
+/* Test hook, not part of the reference's surface: evaluates one pinned arithmetic primitive of the kernels elementwise over
+ * `count` 32-bit patterns (0 exp, 1 log, 2 f32->f16 bits, 3 f16 bits->f32, 4 saturating f32->i32, 5 saturating f32->u32,
+ * 6 sqrt, 7 1/x), so that a parity suite can compare them with its oracle directly. */
+int wdgs_debug_eval_math(wdgs_device* dev, uint32_t which, uint32_t count, const void* in_u32_dev, void* out_u32_dev);
+
 /* ---------------------------------------------------------------- Optimizer
  * Replaces allocateOptimizerStateBuffers (renderers/optimizer.ts:27-38), `new Optimizer(device, pointCloud, params?,
  * initialState?)` (71-88), .step (295-350), hyperparameter accessors (256-278), .destroy (352). */

@@ -434,4 +434,8 @@ void orc_test_exp(u32 n, const f32* in, f32* out) { for (u32 i = 0; i < n; i++) 
 void orc_test_log(u32 n, const f32* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = wd_log(in[i]); }
 void orc_test_f32_to_f16(u32 n, const f32* in, uint16_t* out) { for (u32 i = 0; i < n; i++) out[i] = f32_to_f16(in[i]); }
 void orc_test_f16_to_f32(u32 n, const uint16_t* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = f16_to_f32(in[i]); }
+void orc_test_to_i32(u32 n, const f32* in, i32* out) { for (u32 i = 0; i < n; i++) out[i] = to_i32(in[i]); }
+void orc_test_to_u32(u32 n, const f32* in, u32* out) { for (u32 i = 0; i < n; i++) out[i] = to_u32(in[i]); }
+void orc_test_sqrt(u32 n, const f32* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = wd_sqrt(in[i]); }
+void orc_test_rcp(u32 n, const f32* in, f32* out) { for (u32 i = 0; i < n; i++) out[i] = 1.0f / in[i]; }
 }

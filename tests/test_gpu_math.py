@@ -1,0 +1,74 @@
+"""GPU: the kernels' pinned arithmetic primitives ("dmath", webdgs_amd/csrc/dmath.h) against the oracle's independent
+implementations (oracle/wgsl_shim.hpp), bit for bit, over edge cases and millions of random bit patterns -- the foundation of
+every `==` comparison in the other parity tests."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from webdgs_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _device(hip_device, which, bits):
+    src = hip_device.bufferFrom(bits.astype(np.uint32))
+    dst = hip_device.createBuffer(4 * bits.size)
+    _lib.check(hip_device.lib.wdgs_debug_eval_math(hip_device.handle, which, bits.size, src.ptr, dst.ptr))
+    return dst.read(np.uint32, bits.size)
+
+
+def _oracle(orc, name, arr, out_dtype):
+    out = np.zeros(arr.shape[0], out_dtype)
+    getattr(orc.lib(), name)(ctypes.c_uint32(arr.shape[0]), arr.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def _patterns(seed, n=3_000_000):
+    rng = np.random.default_rng(seed)
+    special = np.array([0x00000000, 0x80000000, 0x00000001, 0x80000001, 0x007FFFFF, 0x00800000, 0x3F800000, 0xBF800000, 0x7F7FFFFF, 0xFF7FFFFF,
+                        0x7F800000, 0xFF800000, 0x7FC00000, 0xFFC00001, 0x4F000000, 0xCF000000, 0x4F800000, 0x4EFFFFFF, 0xC2AC0000, 0x42B00000,
+                        0xC2AC0001, 0x42B00001, 0x33800000, 0x477FE000, 0x477FF000, 0x38800000, 0x387FC000, 0x33000000, 0x33000001], np.uint32)
+    return np.concatenate([special, rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32),
+                           rng.uniform(-100, 100, n // 4).astype(np.float32).view(np.uint32), rng.uniform(-2, 2, n // 4).astype(np.float32).view(np.uint32)])
+
+
+def _same(got, ref_bits, what, bits):
+    ref_bits = ref_bits.view(np.uint32)
+    nan_ok = np.ones(got.shape, bool)
+    bad = np.flatnonzero(got != ref_bits)
+    assert bad.size == 0, f"{what}: {bad.size} of {got.size} differ; first input bits {int(bits[bad[0]]):#010x}: device {int(got[bad[0]]):#010x} oracle {int(ref_bits[bad[0]]):#010x}"
+
+
+def test_exp_log_sqrt_rcp_bit_exact(hip_device, orc):
+    bits = _patterns(11)
+    x = bits.view(np.float32)
+    for which, name in ((0, "orc_test_exp"), (1, "orc_test_log"), (6, "orc_test_sqrt"), (7, "orc_test_rcp")):
+        got = _device(hip_device, which, bits)
+        ref = _oracle(orc, name, x, np.float32).view(np.uint32)
+        # NaN results: any NaN payload is a NaN (the two sides may differ in sign/payload of a produced NaN)
+        both_nan = np.isnan(got.view(np.float32)) & np.isnan(ref.view(np.float32))
+        got, ref = np.where(both_nan, 0x7FC00000, got).astype(np.uint32), np.where(both_nan, 0x7FC00000, ref).astype(np.uint32)
+        _same(got, ref, name, bits)
+
+
+def test_f16_conversions_bit_exact(hip_device, orc):
+    bits = _patterns(12)
+    got = _device(hip_device, 2, bits)
+    ref = _oracle(orc, "orc_test_f32_to_f16", bits.view(np.float32), np.uint16).astype(np.uint32)
+    nan = np.isnan(bits.view(np.float32))
+    assert np.array_equal(got[~nan], ref[~nan]), "f32 -> f16 (RNE)"
+    assert ((got[nan] & 0x7C00) == 0x7C00).all() and ((got[nan] & 0x03FF) != 0).all(), "NaN must stay NaN in f16"
+    halves = np.arange(1 << 16, dtype=np.uint32)
+    got = _device(hip_device, 3, halves)
+    ref = _oracle(orc, "orc_test_f16_to_f32", halves.astype(np.uint16), np.float32).view(np.uint32)
+    nanh = np.isnan(ref.view(np.float32))
+    assert np.array_equal(got[~nanh], ref[~nanh]), "f16 -> f32"
+    assert np.isnan(got[nanh].view(np.float32)).all()
+
+
+def test_saturating_casts_bit_exact(hip_device, orc):
+    bits = _patterns(13)
+    x = bits.view(np.float32)
+    _same(_device(hip_device, 4, bits), _oracle(orc, "orc_test_to_i32", x, np.int32), "f32 -> i32 (truncate, saturate, NaN -> 0)", bits)
+    _same(_device(hip_device, 5, bits), _oracle(orc, "orc_test_to_u32", x, np.uint32), "f32 -> u32 (truncate, saturate, NaN -> 0)", bits)

@@ -112,6 +112,7 @@ SIGNATURES = {
     "wdgs_densify_prune_encode_total_out": (_I, [_P, _U]),
     "wdgs_densify_prune_compute_max_out_points": (_I, [_P, _U, C.POINTER(_U)]),
     "wdgs_densify_prune_get_buffers": (_I, [_P, C.POINTER(DensifyPrepared)]),
+    "wdgs_debug_eval_math": (_I, [_P, _U, _U, _P, _P]),
     "wdgs_comm_get_unique_id": (_I, [C.POINTER(C.c_uint8)]),
     "wdgs_comm_create": (_I, [_P, C.POINTER(C.c_uint8), _I, _I, C.POINTER(_P)]),
     "wdgs_comm_destroy": (_I, [_P]),

@@ -28,14 +28,14 @@ WD_DEV float wd_exp(float x) {
     p = __builtin_fmaf(p, r, C2);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
-    // The range cases are folded into the power-of-two factor: x < -86 -> factor 0, x > 88 -> factor +inf (p is in (0.7, 1.5), so
-    // p*0 = 0 and p*inf = inf; NaN stays NaN).  Same values as selecting on the product, but the compares and selects depend only
-    // on x and n and schedule beside the Horner chain instead of stalling on the v_cmp -> v_cndmask hazard after it.
-    float nc = fminf(fmaxf(n, -126.0f), 127.0f);  // clamped, so out-of-range x cannot build an invalid bit pattern
-    uint32_t scale = (uint32_t)((int)nc + 127) << 23;
-    scale = (x < -86.0f) ? 0u : scale;
-    scale = (x > 88.0f) ? 0x7F800000u : scale;
-    return p * wd_bits2f(scale);
+    // clamp the exponent so out-of-range x cannot build an invalid bit pattern before the selects below.  (The selects must act
+    // on the product: for |x| far outside the range r is no longer small and p may be inf or NaN, so folding the range cases into
+    // the power-of-two factor -- p*0, p*inf -- is NOT equivalent; tests/test_gpu_math.py holds the cases.)
+    float nc = fminf(fmaxf(n, -126.0f), 127.0f);
+    float res = p * wd_bits2f((uint32_t)((int)nc + 127) << 23);
+    res = (x < -86.0f) ? 0.0f : res;
+    res = (x > 88.0f) ? __builtin_inff() : res;
+    return res;
 }
 
 // Two-component float value with component-wise IEEE operations, written out as scalar instructions.  (On gfx950 a wave64 VALU
