@@ -3,7 +3,7 @@ const path = require('path');
 const addon = require(path.join(__dirname, 'webdgs_napi.node'));
 if (addon.abiVersion() !== 1) { console.error('bad ABI version'); process.exit(1); }
 const names = Object.keys(addon);
-if (names.length < 25) { console.error('missing exports', names); process.exit(1); }
+if (names.length < 56) { console.error('missing exports', names); process.exit(1); }
 if (process.argv[2] === 'gpu') {
   const dev = addon.deviceCreate(0);
   const n = 64, W = 64, H = 48;
@@ -27,7 +27,42 @@ if (process.argv[2] === 'gpu') {
   const stats = new Uint32Array(addon.copyToHost(dev, addon.tiledForwardGetResources(fwd).statsBuffer, 16));
   console.log(`napi gpu smoke: E=${stats[0]} visible=${stats[1]} lit pixels=${lit}`);
   if (stats[1] !== n || lit === 0) process.exit(1);
-  addon.tiledRasterizerDestroy(rast); addon.tiledForwardDestroy(fwd);
-  [gb, sb, cb].forEach((b) => addon.bufferDestroy(b.handle)); addon.deviceDestroy(dev);
+  // ---- one training step through the addon: backward + Adam, eager then as a recorded command buffer, awaited as a Promise
+  const target = addon.bufferCreate(dev, W * H * 4);
+  addon.tiledRasterizerBlit(rast, target.ptr, W, H);                       // blitToTexture: a copy of the render is the "ground truth"
+  const half = addon.bufferCreate(dev, (W / 2) * (H / 2) * 4);
+  addon.tiledRasterizerBlit(rast, half.ptr, W / 2, H / 2);                 // linear-sampler blit to another size
+  const bwd = addon.tiledBackwardCreate(dev, { numPoints: n, shDeg: 0, viewportWidth: W, viewportHeight: H });
+  const opt = addon.optimizerCreate(dev, n, gb.ptr, sb.ptr);
+  const encodeStep = () => {
+    addon.tiledForwardEncode(fwd, gb.ptr, sb.ptr, cb.ptr, 0);
+    addon.tiledRasterizerEncode(rast, W, H);
+    const r = addon.tiledForwardGetResources(fwd);
+    addon.tiledBackwardEncode(bwd, addon.tiledRasterizerGet(rast, 0), target.ptr, {
+      splatBuffer: r.splatBuffer, tileOffsetsBuffer: addon.tiledRasterizerGet(rast, 3), tileIndicesBuffer: r.tileIndicesBuffer, cameraBuffer: cb.ptr,
+      alphaTexture: addon.tiledRasterizerGet(rast, 1), nContribTexture: addon.tiledRasterizerGet(rast, 2) }, gb.ptr);
+    addon.optimizerStep(opt, gb.ptr, sb.ptr, addon.tiledBackwardGet(bwd, 0), r.tileCountsBuffer);
+  };
+  encodeStep();                                                            // eager (allocates on first use)
+  addon.deviceSynchronize(dev);
+  addon.encoderBegin(dev); encodeStep(); const cmd = addon.encoderFinish(dev);   // recorded: GPUCommandBuffer
+  addon.optimizerAdvanceIteration(opt, 0);
+  addon.queueSubmit(dev, cmd); addon.queueSubmit(dev, cmd);
+  addon.optimizerAdvanceIteration(opt, 1);
+  const hp = addon.optimizerHyperparameters(opt, { lr_pos: 0.001 });
+  const st = addon.tiledForwardCheck(fwd);
+  const dens = addon.densifyCreate(dev, { numViews: 1, cloneThreshold: 1, splitThreshold: 0.5, pruneThreshold: 0.01, maxNewPointsPerStep: 16 });
+  const prep = addon.densifyEncodePrepare(dens, n, gb.ptr, addon.tiledBackwardGet(bwd, 1));
+  const total = addon.densifyReadTotal(dens);
+  const state = addon.optimizerState(opt, 0);
+  addon.queueOnSubmittedWorkDone(dev).then(() => {
+    console.log(`napi gpu train: iteration=${addon.optimizerGetIteration(opt)} visible=${st.visibleCount} lr_pos=${hp.lr_pos.toFixed(4)} densify total=${total}/${prep.maxOutPoints} state=${typeof state.optPosBuffer}`);
+    if (addon.optimizerGetIteration(opt) !== 3 || total === 0 || total > prep.maxOutPoints) process.exit(1);
+    addon.commandBufferDestroy(cmd); addon.densifyDestroy(dens); addon.optimizerDestroy(opt); addon.tiledBackwardDestroy(bwd);
+    addon.tiledRasterizerDestroy(rast); addon.tiledForwardDestroy(fwd);
+    [gb, sb, cb, target, half].forEach((b) => addon.bufferDestroy(b.handle)); addon.deviceDestroy(dev);
+    console.log('napi smoke ok:', names.length, 'exports');
+  }).catch((e) => { console.error(e); process.exit(1); });
+} else {
+  console.log('napi smoke ok:', names.length, 'exports');
 }
-console.log('napi smoke ok:', names.length, 'exports');

@@ -236,6 +236,274 @@ static napi_value optimizerStep(napi_env env, napi_callback_info info) {  // (op
 static napi_value optimizerGetIteration(napi_env env, napi_callback_info info) { ARGS(1); return make_u32(env, wdgs_optimizer_get_iteration((wdgs_optimizer*)get_ptr(env, argv[0]))); }
 static napi_value optimizerDestroy(napi_env env, napi_callback_info info) { ARGS(1); wdgs_optimizer_destroy((wdgs_optimizer*)get_ptr(env, argv[0])); return js_undefined(env); }
 
+// ---- remaining surface: setters, blit, recorded command buffers, completion Promise, metric path, densify, DP ----------------
+static napi_value tiledForwardSet(napi_env env, napi_callback_info info) {  // (op, what: 'renderMode'|'pointSize'|'gaussianScale' as 0|1|2, value)
+    ARGS(3);
+    wdgs_tiled_forward* op = (wdgs_tiled_forward*)get_ptr(env, argv[0]);
+    switch (get_u32(env, argv[1])) {
+        case 0: WDGS_OK_OR_THROW(wdgs_tiled_forward_set_render_mode(op, get_u32(env, argv[2]))); break;
+        case 1: WDGS_OK_OR_THROW(wdgs_tiled_forward_set_point_size(op, (float)get_f64(env, argv[2]))); break;
+        default: WDGS_OK_OR_THROW(wdgs_tiled_forward_set_gaussian_scale(op, (float)get_f64(env, argv[2]))); break;
+    }
+    return js_undefined(env);
+}
+static napi_value tiledForwardCheck(napi_env env, napi_callback_info info) {  // -> {totalTileEntries, visibleCount}; throws WDGS_E_CAPACITY on overflow
+    ARGS(1);
+    uint32_t st[4] = {0, 0, 0, 0};
+    WDGS_OK_OR_THROW(wdgs_tiled_forward_check((wdgs_tiled_forward*)get_ptr(env, argv[0]), st));
+    napi_value o; napi_create_object(env, &o);
+    set_prop(env, o, "totalTileEntries", make_u32(env, st[0]));
+    set_prop(env, o, "visibleCount", make_u32(env, st[1]));
+    return o;
+}
+static napi_value tiledRasterizerBlit(napi_env env, napi_callback_info info) {  // (op, targetPtr, width, height): blitToTexture
+    ARGS(4);
+    WDGS_OK_OR_THROW(wdgs_tiled_rasterizer_blit((wdgs_tiled_rasterizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value bufferClear(napi_env env, napi_callback_info info) {  // encoder.clearBuffer: (device, ptr, byteLength)
+    ARGS(3);
+    WDGS_OK_OR_THROW(wdgs_memset((wdgs_device*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), 0, (size_t)get_f64(env, argv[2])));
+    return js_undefined(env);
+}
+static napi_value encoderBegin(napi_env env, napi_callback_info info) { ARGS(1); WDGS_OK_OR_THROW(wdgs_encoder_begin((wdgs_device*)get_ptr(env, argv[0]))); return js_undefined(env); }
+static napi_value encoderFinish(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    wdgs_command_buffer* c = nullptr;
+    WDGS_OK_OR_THROW(wdgs_encoder_finish((wdgs_device*)get_ptr(env, argv[0]), &c));
+    return make_ptr(env, c);
+}
+static napi_value queueSubmit(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_queue_submit((wdgs_device*)get_ptr(env, argv[0]), (wdgs_command_buffer*)get_ptr(env, argv[1])));
+    return js_undefined(env);
+}
+static napi_value commandBufferDestroy(napi_env env, napi_callback_info info) { ARGS(1); wdgs_command_buffer_destroy((wdgs_command_buffer*)get_ptr(env, argv[0])); return js_undefined(env); }
+
+// queue.onSubmittedWorkDone(): Promise<void> resolved from the HIP runtime thread through a thread-safe function.
+struct DoneCtx { napi_deferred deferred; napi_threadsafe_function tsfn; };
+static void done_call_js(napi_env env, napi_value, void* context, void*) {
+    DoneCtx* c = static_cast<DoneCtx*>(context);
+    if (env) { napi_value u; napi_get_undefined(env, &u); napi_resolve_deferred(env, c->deferred, u); }
+    napi_release_threadsafe_function(c->tsfn, napi_tsfn_release);
+    delete c;
+}
+static void done_from_runtime_thread(void* user) {
+    DoneCtx* c = static_cast<DoneCtx*>(user);
+    napi_call_threadsafe_function(c->tsfn, nullptr, napi_tsfn_blocking);
+}
+static napi_value queueOnSubmittedWorkDone(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    DoneCtx* c = new DoneCtx();
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &c->deferred, &promise));
+    napi_create_string_utf8(env, "wdgs onSubmittedWorkDone", NAPI_AUTO_LENGTH, &name);
+    NAPI_OK(napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, c, done_call_js, &c->tsfn));
+    int rc = wdgs_queue_on_done((wdgs_device*)get_ptr(env, argv[0]), done_from_runtime_thread, c);
+    if (rc != WDGS_OK) { napi_release_threadsafe_function(c->tsfn, napi_tsfn_abort); delete c; return throw_wdgs(env, rc); }
+    return promise;
+}
+
+static void read_backward_resources(napi_env env, napi_value o, wdgs_tiled_backward_resources* r) {
+    r->splat_buffer = prop_ptr(env, o, "splatBuffer");
+    r->tile_offsets_buffer = prop_ptr(env, o, "tileOffsetsBuffer");
+    r->tile_indices_buffer = prop_ptr(env, o, "tileIndicesBuffer");
+    r->camera_buffer = prop_ptr(env, o, "cameraBuffer");
+    r->alpha_texture = prop_ptr(env, o, "alphaTexture");
+    r->n_contrib_texture = prop_ptr(env, o, "nContribTexture");
+}
+static napi_value tiledBackwardMetric(napi_env env, napi_callback_info info) {
+    // (op, stage, a, b, c): 0 computeLossOnly(pred, target) | 1 computeMetricMap(pred, target, threshold) |
+    //                       2 computeMetricCounts(resources, numInstances, clear) | 3 normalizeMetricCounts(divisor) | 4 setViewport(w, h)
+    ARGS(5);
+    wdgs_tiled_backward* op = (wdgs_tiled_backward*)get_ptr(env, argv[0]);
+    switch (get_u32(env, argv[1])) {
+        case 0: WDGS_OK_OR_THROW(wdgs_tiled_backward_compute_loss_only(op, get_ptr(env, argv[2]), get_ptr(env, argv[3]))); break;
+        case 1: WDGS_OK_OR_THROW(wdgs_tiled_backward_compute_metric_map(op, get_ptr(env, argv[2]), get_ptr(env, argv[3]), (float)get_f64(env, argv[4]))); break;
+        case 2: {
+            wdgs_tiled_backward_resources r;
+            read_backward_resources(env, argv[2], &r);
+            WDGS_OK_OR_THROW(wdgs_tiled_backward_compute_metric_counts(op, &r, get_u32(env, argv[3]), (int)get_u32(env, argv[4])));
+            break;
+        }
+        case 3: WDGS_OK_OR_THROW(wdgs_tiled_backward_normalize_metric_counts(op, get_u32(env, argv[2]))); break;
+        default: WDGS_OK_OR_THROW(wdgs_tiled_backward_set_viewport(op, get_u32(env, argv[2]), get_u32(env, argv[3]))); break;
+    }
+    return js_undefined(env);
+}
+static napi_value tiledBackwardGet(napi_env env, napi_callback_info info) {  // (op, which: 0 gradients, 1 metricCounts, 2 lossImage, 3 metricMap)
+    ARGS(2);
+    wdgs_tiled_backward* op = (wdgs_tiled_backward*)get_ptr(env, argv[0]);
+    switch (get_u32(env, argv[1])) {
+        case 0: return make_ptr(env, wdgs_tiled_backward_gradients(op));
+        case 1: return make_ptr(env, wdgs_tiled_backward_metric_counts(op));
+        case 2: return make_ptr(env, wdgs_tiled_backward_loss_image(op));
+        default: return make_ptr(env, wdgs_tiled_backward_metric_map(op));
+    }
+}
+static napi_value downsampleRGBA8(napi_env env, napi_callback_info info) {  // (device, srcPtr, srcW, srcH, dstPtr, dstW, dstH)
+    ARGS(7);
+    WDGS_OK_OR_THROW(wdgs_downsample_rgba8((wdgs_device*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3]),
+                                           get_ptr(env, argv[4]), get_u32(env, argv[5]), get_u32(env, argv[6])));
+    return js_undefined(env);
+}
+static napi_value imageSSE(napi_env env, napi_callback_info info) {  // (device, aPtr, bPtr, numPixels, outU64Ptr)
+    ARGS(5);
+    WDGS_OK_OR_THROW(wdgs_image_sse_rgb8((wdgs_device*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), get_u32(env, argv[3]), get_ptr(env, argv[4])));
+    return js_undefined(env);
+}
+
+static bool read_state(napi_env env, napi_value o, wdgs_optimizer_state* s) {
+    napi_valuetype t; napi_typeof(env, o, &t);
+    if (t != napi_object) return false;
+    s->opt_pos = prop_ptr(env, o, "optPosBuffer"); s->opt_rot = prop_ptr(env, o, "optRotBuffer"); s->opt_scale = prop_ptr(env, o, "optScaleBuffer");
+    s->opt_opacity = prop_ptr(env, o, "optOpacityBuffer"); s->param_sh = prop_ptr(env, o, "paramSH"); s->state_sh = prop_ptr(env, o, "stateSH");
+    return true;
+}
+static napi_value make_state(napi_env env, const wdgs_optimizer_state& s) {
+    napi_value o; napi_create_object(env, &o);
+    set_prop(env, o, "optPosBuffer", make_ptr(env, s.opt_pos)); set_prop(env, o, "optRotBuffer", make_ptr(env, s.opt_rot));
+    set_prop(env, o, "optScaleBuffer", make_ptr(env, s.opt_scale)); set_prop(env, o, "optOpacityBuffer", make_ptr(env, s.opt_opacity));
+    set_prop(env, o, "paramSH", make_ptr(env, s.param_sh)); set_prop(env, o, "stateSH", make_ptr(env, s.state_sh));
+    return o;
+}
+static napi_value optimizerStateSizes(napi_env env, napi_callback_info info) {  // allocateOptimizerStateBuffers: byte sizes of the six arrays
+    ARGS(1);
+    size_t sz[6];
+    WDGS_OK_OR_THROW(wdgs_optimizer_state_sizes(get_u32(env, argv[0]), sz));
+    napi_value arr; napi_create_array_with_length(env, 6, &arr);
+    for (uint32_t i = 0; i < 6; i++) { napi_value v; napi_create_double(env, (double)sz[i], &v); napi_set_element(env, arr, i, v); }
+    return arr;
+}
+static napi_value optimizerCreateWithState(napi_env env, napi_callback_info info) {
+    // (device, numPoints, gaussiansPtr, shPtr, initialState{...Ptr} (adopted), ownsState, initialIteration)
+    ARGS(7);
+    wdgs_optimizer_state st; std::memset(&st, 0, sizeof(st));
+    const bool has = read_state(env, argv[4], &st);
+    wdgs_optimizer* op = nullptr;
+    WDGS_OK_OR_THROW(wdgs_optimizer_create((wdgs_device*)get_ptr(env, argv[0]), get_u32(env, argv[1]), nullptr, get_ptr(env, argv[2]), get_ptr(env, argv[3]),
+                                           has ? &st : nullptr, (int)get_u32(env, argv[5]), get_u32(env, argv[6]), &op));
+    return make_ptr(env, op);
+}
+static napi_value optimizerState(napi_env env, napi_callback_info info) {  // (op, release: 0 getStateBuffers | 1 detach for a densify swap)
+    ARGS(2);
+    wdgs_optimizer_state st;
+    if (get_u32(env, argv[1])) WDGS_OK_OR_THROW(wdgs_optimizer_release_state((wdgs_optimizer*)get_ptr(env, argv[0]), &st));
+    else WDGS_OK_OR_THROW(wdgs_optimizer_get_state((wdgs_optimizer*)get_ptr(env, argv[0]), &st));
+    return make_state(env, st);
+}
+static napi_value optimizerHyperparameters(napi_env env, napi_callback_info info) {  // (op, next?) -> current (after applying `next`)
+    ARGS(2);
+    wdgs_optimizer* op = (wdgs_optimizer*)get_ptr(env, argv[0]);
+    wdgs_adam_hyperparameters h;
+    WDGS_OK_OR_THROW(wdgs_optimizer_get_hyperparameters(op, &h));
+    napi_valuetype t; napi_typeof(env, argv[1], &t);
+    if (t == napi_object) {
+        h.lr_pos = (float)prop_f64(env, argv[1], "lr_pos", h.lr_pos); h.lr_color = (float)prop_f64(env, argv[1], "lr_color", h.lr_color);
+        h.lr_opacity = (float)prop_f64(env, argv[1], "lr_opacity", h.lr_opacity); h.lr_scale = (float)prop_f64(env, argv[1], "lr_scale", h.lr_scale);
+        h.lr_rot = (float)prop_f64(env, argv[1], "lr_rot", h.lr_rot); h.beta1 = (float)prop_f64(env, argv[1], "beta1", h.beta1);
+        h.beta2 = (float)prop_f64(env, argv[1], "beta2", h.beta2); h.epsilon = (float)prop_f64(env, argv[1], "epsilon", h.epsilon);
+        WDGS_OK_OR_THROW(wdgs_optimizer_set_hyperparameters(op, &h));
+    }
+    napi_value o; napi_create_object(env, &o);
+    const char* names[8] = {"lr_pos", "lr_color", "lr_opacity", "lr_scale", "lr_rot", "beta1", "beta2", "epsilon"};
+    const float vals[8] = {h.lr_pos, h.lr_color, h.lr_opacity, h.lr_scale, h.lr_rot, h.beta1, h.beta2, h.epsilon};
+    for (int i = 0; i < 8; i++) { napi_value v; napi_create_double(env, vals[i], &v); set_prop(env, o, names[i], v); }
+    return o;
+}
+static napi_value optimizerAdvanceIteration(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_optimizer_advance_iteration((wdgs_optimizer*)get_ptr(env, argv[0]), get_u32(env, argv[1])));
+    return js_undefined(env);
+}
+static napi_value optimizerStepF32(napi_env env, napi_callback_info info) {  // data-parallel step: (op, gaussiansPtr, shPtr, gradF32Ptr, visibleCountsPtr)
+    ARGS(5);
+    WDGS_OK_OR_THROW(wdgs_optimizer_step_f32((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]), get_ptr(env, argv[4])));
+    return js_undefined(env);
+}
+static napi_value accumulateGradients(napi_env env, napi_callback_info info) {  // (device, numPoints, gradientsPtr, tileCountsPtr, accF32Ptr, visiblePtr)
+    ARGS(6);
+    WDGS_OK_OR_THROW(wdgs_accumulate_gradients((wdgs_device*)get_ptr(env, argv[0]), get_u32(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]),
+                                               get_ptr(env, argv[4]), get_ptr(env, argv[5])));
+    return js_undefined(env);
+}
+
+static void read_densify_config(napi_env env, napi_value o, wdgs_densify_config* c) {
+    c->num_views = (uint32_t)prop_f64(env, o, "numViews", 1);
+    c->clone_threshold = (uint32_t)prop_f64(env, o, "cloneThreshold", 0);
+    c->split_threshold = (float)prop_f64(env, o, "splitThreshold", 1e9);
+    c->prune_threshold = (float)prop_f64(env, o, "pruneThreshold", 0.0);
+    c->max_new_points_per_step = (uint32_t)prop_f64(env, o, "maxNewPointsPerStep", 0);
+    c->max_buffer_bytes = (uint64_t)prop_f64(env, o, "maxBufferBytes", 128.0 * 1024 * 1024);
+}
+static napi_value densifyCreate(napi_env env, napi_callback_info info) {  // (device, config)
+    ARGS(2);
+    wdgs_densify_config c; read_densify_config(env, argv[1], &c);
+    wdgs_densify_prune* op = nullptr;
+    WDGS_OK_OR_THROW(wdgs_densify_prune_create((wdgs_device*)get_ptr(env, argv[0]), &c, &op));
+    return make_ptr(env, op);
+}
+static napi_value densifySetConfig(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    wdgs_densify_config c; read_densify_config(env, argv[1], &c);
+    WDGS_OK_OR_THROW(wdgs_densify_prune_set_config((wdgs_densify_prune*)get_ptr(env, argv[0]), &c));
+    return js_undefined(env);
+}
+static napi_value densifyEncodePrepare(napi_env env, napi_callback_info info) {  // (op, numPoints, gaussiansPtr, metricCountsPtr) -> DensifyPrunePrepared
+    ARGS(4);
+    wdgs_densify_prepared p;
+    WDGS_OK_OR_THROW(wdgs_densify_prune_encode_prepare((wdgs_densify_prune*)get_ptr(env, argv[0]), get_u32(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]), &p));
+    napi_value o; napi_create_object(env, &o);
+    set_prop(env, o, "actionBuffer", make_ptr(env, p.action_buffer)); set_prop(env, o, "outCountBuffer", make_ptr(env, p.out_count_buffer));
+    set_prop(env, o, "outOffsetBuffer", make_ptr(env, p.out_offset_buffer)); set_prop(env, o, "outTotalBuffer", make_ptr(env, p.out_total_buffer));
+    set_prop(env, o, "maxOutPoints", make_u32(env, p.max_out_points));
+    return o;
+}
+static napi_value densifyReadTotal(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    uint32_t t = 0;
+    WDGS_OK_OR_THROW(wdgs_densify_prune_read_total((wdgs_densify_prune*)get_ptr(env, argv[0]), &t));
+    return make_u32(env, t);
+}
+static napi_value densifyEncodeScatter(napi_env env, napi_callback_info info) {
+    // (op, inPoints, inGaussiansPtr, inShPtr, inState|null, outNumPoints, resetNewOptimizerState, outGaussiansPtr, outShPtr, outState|null)
+    ARGS(10);
+    wdgs_optimizer_state in_st, out_st;
+    const bool has_in = read_state(env, argv[4], &in_st), has_out = read_state(env, argv[9], &out_st);
+    WDGS_OK_OR_THROW(wdgs_densify_prune_encode_scatter((wdgs_densify_prune*)get_ptr(env, argv[0]), get_u32(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]),
+                                                       has_in ? &in_st : nullptr, get_u32(env, argv[5]), (int)get_u32(env, argv[6]), get_ptr(env, argv[7]),
+                                                       get_ptr(env, argv[8]), has_out ? &out_st : nullptr));
+    return js_undefined(env);
+}
+static napi_value densifyDestroy(napi_env env, napi_callback_info info) { ARGS(1); wdgs_densify_prune_destroy((wdgs_densify_prune*)get_ptr(env, argv[0])); return js_undefined(env); }
+
+static napi_value commUniqueId(napi_env env, napi_callback_info) {  // -> ArrayBuffer(128); rank 0 ships it to the other ranks
+    void* data = nullptr; napi_value ab;
+    NAPI_OK(napi_create_arraybuffer(env, WDGS_COMM_ID_BYTES, &data, &ab));
+    WDGS_OK_OR_THROW(wdgs_comm_get_unique_id((uint8_t*)data));
+    return ab;
+}
+static napi_value commCreate(napi_env env, napi_callback_info info) {  // (device, idArrayBuffer, worldSize, rank)
+    ARGS(4);
+    void* data = nullptr; size_t len = 0;
+    NAPI_OK(napi_get_arraybuffer_info(env, argv[1], &data, &len));
+    if (len != WDGS_COMM_ID_BYTES) { napi_throw_type_error(env, nullptr, "unique id must be 128 bytes"); return nullptr; }
+    wdgs_comm* c = nullptr;
+    WDGS_OK_OR_THROW(wdgs_comm_create((wdgs_device*)get_ptr(env, argv[0]), (const uint8_t*)data, (int)get_u32(env, argv[2]), (int)get_u32(env, argv[3]), &c));
+    return make_ptr(env, c);
+}
+static napi_value commAllreduceGradients(napi_env env, napi_callback_info info) {  // (comm, gradF32Ptr, visiblePtr, numPoints)
+    ARGS(4);
+    WDGS_OK_OR_THROW(wdgs_comm_allreduce_gradients((wdgs_comm*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), get_u32(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value commAllreduceCounts(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    WDGS_OK_OR_THROW(wdgs_comm_allreduce_counts((wdgs_comm*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_u32(env, argv[2])));
+    return js_undefined(env);
+}
+static napi_value commDestroy(napi_env env, napi_callback_info info) { ARGS(1); wdgs_comm_destroy((wdgs_comm*)get_ptr(env, argv[0])); return js_undefined(env); }
+
 #define EXPORT_FN(name)                                                              \
     do {                                                                             \
         napi_value fn;                                                               \
@@ -250,6 +518,14 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(tiledRasterizerCreate); EXPORT_FN(tiledRasterizerEncode); EXPORT_FN(tiledRasterizerGet); EXPORT_FN(tiledRasterizerDestroy);
     EXPORT_FN(tiledBackwardCreate); EXPORT_FN(tiledBackwardEncode); EXPORT_FN(tiledBackwardGradients); EXPORT_FN(tiledBackwardDestroy);
     EXPORT_FN(optimizerCreate); EXPORT_FN(optimizerStep); EXPORT_FN(optimizerGetIteration); EXPORT_FN(optimizerDestroy);
+    EXPORT_FN(tiledForwardSet); EXPORT_FN(tiledForwardCheck); EXPORT_FN(tiledRasterizerBlit); EXPORT_FN(bufferClear);
+    EXPORT_FN(encoderBegin); EXPORT_FN(encoderFinish); EXPORT_FN(queueSubmit); EXPORT_FN(commandBufferDestroy); EXPORT_FN(queueOnSubmittedWorkDone);
+    EXPORT_FN(tiledBackwardMetric); EXPORT_FN(tiledBackwardGet); EXPORT_FN(downsampleRGBA8); EXPORT_FN(imageSSE);
+    EXPORT_FN(optimizerStateSizes); EXPORT_FN(optimizerCreateWithState); EXPORT_FN(optimizerState); EXPORT_FN(optimizerHyperparameters);
+    EXPORT_FN(optimizerAdvanceIteration); EXPORT_FN(optimizerStepF32); EXPORT_FN(accumulateGradients);
+    EXPORT_FN(densifyCreate); EXPORT_FN(densifySetConfig); EXPORT_FN(densifyEncodePrepare); EXPORT_FN(densifyReadTotal); EXPORT_FN(densifyEncodeScatter);
+    EXPORT_FN(densifyDestroy);
+    EXPORT_FN(commUniqueId); EXPORT_FN(commCreate); EXPORT_FN(commAllreduceGradients); EXPORT_FN(commAllreduceCounts); EXPORT_FN(commDestroy);
     return exports;
 }
 NAPI_MODULE(webdgs_napi, Init)
