@@ -7,7 +7,7 @@
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
 int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*);
-int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*, void*);
+int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*, void*, void*);
 int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
 int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
@@ -69,6 +69,7 @@ struct wdgs_tiled_forward {
     RenderSettings settings;
     TileInfo tile_info;
     u32* stats;   // {total_tile_entries, visible_gaussians, overflow (0 or requested total), pad} + 64 visible-count shards
+    u32* host_stats;  // pinned, device-visible copy of stats[0..3] written by update_stats: the per-step overflow check reads host memory
     u32* splats;
     u32* depths;
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
@@ -173,8 +174,7 @@ int wdgs_device_synchronize(wdgs_device* d) {
     collect_profile(d);
     for (wdgs_tiled_forward* f : d->forwards) {
         if (!f->encoded) continue;
-        u32 st[4];
-        WDGS_CHECK_HIP(hipMemcpy(st, f->stats, sizeof(st), hipMemcpyDeviceToHost));
+        const volatile u32* st = f->host_stats;  // written by update_stats before the stream drained (no device round trip here)
         WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)",
                      st[2], f->tile_info.max_tile_entries);
     }
@@ -407,6 +407,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->dev = d;
     op->cfg = *cfg;
     op->stats = op->splats = op->depths = nullptr;
+    op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;
     op->encoded = false;
@@ -428,6 +429,8 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->tile_info.max_tile_entries = (u32)cap;
     forward_set_viewport(op, cfg->viewport_width, cfg->viewport_height);
     int r = wdgs_alloc((void**)&op->stats, 16 + 64 * 4, true, d->stream);
+    if (r == WDGS_OK && hipHostMalloc((void**)&op->host_stats, 16, hipHostMallocDefault) != hipSuccess) { wdgs_set_error("hipHostMalloc(16) failed"); r = WDGS_E_HIP; }
+    if (r == WDGS_OK) std::memset(op->host_stats, 0, 16);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->splats, (size_t)24 * std::max(n, 1u), true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * std::max(n, 1u), true, d->stream);
     if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, std::max(n, 1u), &op->scanner);
@@ -444,6 +447,7 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     v.erase(std::remove(v.begin(), v.end(), op), v.end());
     (void)hipStreamSynchronize(op->dev->stream);
     free_dev(op->stats);
+    if (op->host_stats) (void)hipHostFree(op->host_stats);
     free_dev(op->splats);
     free_dev(op->depths);
     wdgs_prefix_scanner_destroy(op->scanner);
@@ -465,7 +469,7 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16, d->stream));  // clearBuffer(pipelineStatsBuffer), tiled-forward-pass.ts:345
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4));
     WDGS_TRY(scan_exclusive_u32(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr));
-    WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4));
+    WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4, op->host_stats));
     WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->settings, op->tile_info, wdgs_sorter_keys(op->sorter, 0),
                          wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
     if (!skip_sort) {
@@ -519,8 +523,10 @@ int wdgs_tiled_forward_get_resources(wdgs_tiled_forward* op, wdgs_tiled_forward_
 
 int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_tiled_forward_check while recording a command buffer");
+    WDGS_CHECK_HIP(hipStreamSynchronize(op->dev->stream));
     u32 st[4];
-    WDGS_TRY(wdgs_copy_to_host(op->dev, st, op->stats, sizeof(st)));
+    for (int i = 0; i < 4; i++) st[i] = ((const volatile u32*)op->host_stats)[i];
     if (stats_out) std::memcpy(stats_out, st, sizeof(st));
     WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u", st[2], op->tile_info.max_tile_entries);
     return WDGS_OK;

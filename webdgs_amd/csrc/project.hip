@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
 
 // stats[0] = total tile entries (update_stats, src/shaders/update-stats.wgsl:19-35); stats[2] = overflow flag.
 __global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, const u32* __restrict__ counts, u32 capacity, u32* __restrict__ stats,
-                                    u32* __restrict__ visible_shards) {
+                                    u32* __restrict__ visible_shards, u32* __restrict__ host_mirror) {
     // 64 threads: fold the visible-count shards (and clear them for the next encode)
     u32 v = visible_shards[threadIdx.x];
     visible_shards[threadIdx.x] = 0u;
@@ -188,6 +188,12 @@ __global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, cons
         const u32 total = (n == 0u) ? 0u : offsets[n - 1] + counts[n - 1];
         stats[0] = min(total, capacity);  // consumers only ever touch [0, capacity)
         stats[2] = (total > capacity) ? total : 0u;
+        if (host_mirror) {  // pinned host memory: the host's per-step overflow check and stats read need no copy
+            host_mirror[0] = min(total, capacity);
+            host_mirror[1] = v;
+            host_mirror[2] = (total > capacity) ? total : 0u;
+            host_mirror[3] = 0u;
+        }
         // a wrapped scan (sum >= 2^32) also shows as an offset going backwards; tile counts are <= 2048 each, so
         // N * 2048 < 2^32 for N < 2^21; beyond that the forward pass sizes its capacity from a 64-bit bound (api).
     }
@@ -235,9 +241,9 @@ int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const v
     return WDGS_OK;
 }
 
-int launch_update_stats(wdgs_device* dev, u32 n, const void* offsets, const void* counts, u32 capacity, void* stats, void* visible_shards) {
+int launch_update_stats(wdgs_device* dev, u32 n, const void* offsets, const void* counts, u32 capacity, void* stats, void* visible_shards, void* host_mirror) {
     WDGS_LAUNCH(dev, "update_stats", update_stats_kernel, dim3(1), dim3(64), 0, n, (const u32*)offsets, (const u32*)counts, capacity, (u32*)stats,
-                (u32*)visible_shards);
+                (u32*)visible_shards, (u32*)host_mirror);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -292,10 +292,10 @@ class Trainer:
         warmup, interval, stop = s["warmupIterations"], max(1, s["interval"]), s["stopIterations"]
         shouldDensify = s["enabled"] and warmup <= nextIteration <= stop and (nextIteration == warmup or (nextIteration - warmup) % interval == 0)
 
-        tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
         key = tuple(mine)
         cmds = self._cmd_cache.get(key)
         if cmds is None:
+            tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
             # the first steps run eagerly (they allocate textures); afterwards each view set is recorded once and replayed
             record = self.use_command_buffers and self._eager_steps >= 1
             encoder = self.device.createCommandEncoder("trainer-step", record=record)
