@@ -466,7 +466,8 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     WDGS_REQUIRE(op && gaussians && sh && camera, WDGS_E_INVALID, "wdgs_tiled_forward_encode: null argument");
     wdgs_device* d = op->dev;
     const u32 n = op->cfg.num_points;
-    WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16, d->stream));  // clearBuffer(pipelineStatsBuffer), tiled-forward-pass.ts:345
+    // clearBuffer(pipelineStatsBuffer) (tiled-forward-pass.ts:345) needs no launch here: update_stats overwrites words 0..2, word 3
+    // stays 0, and the visible count is accumulated in shard words that update_stats clears after folding them.
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4));
     WDGS_TRY(scan_exclusive_u32(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr));
     WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4, op->host_stats));

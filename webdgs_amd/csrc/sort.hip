@@ -8,7 +8,7 @@
 // E ~ 6 M all ~1500 partitions are co-resident and every one walks hundreds of unfinished predecessors):
 //   sort_hist      per-partition digit counts: 16-byte key loads, wave-private LDS bins -> counts[digit][partition]
 //   sort_scan_rows one workgroup per digit: exclusive scan of its row over the ACTIVE partitions (count read on device)
-//   sort_scan_base exclusive scan of the 256 row totals
+//   (the exclusive scan of the 256 row totals is done by every scatter block itself)
 //   sort_scatter   ranks by wave64 ballot match (stable: order = wave, round, lane = input order) and scatters
 // HBM traffic per pass: 4E (hist) + 16E (scatter); ranges: 4E + 4(T+1).  Only digits that can be non-zero are sorted.
 #include "common.h"
@@ -87,28 +87,10 @@ __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ c
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(RADIX) void sort_scan_base_kernel(u32* __restrict__ totals) {
-    __shared__ u32 s_w[4];
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 v = totals[threadIdx.x];
-    u32 inc = v;
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-        const u32 t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63u) s_w[wave] = inc;
-    __syncthreads();
-    u32 woff = 0;
-#pragma unroll
-    for (u32 w = 0; w < 4; w++) if (w < wave) woff += s_w[w];
-    totals[threadIdx.x] = woff + inc - v;
-}
-
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                     u32* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                                     const u32* __restrict__ count_ptr, u32 shift, u32 num_parts,
-                                                                    const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_base) {
+                                                                    const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals) {
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
@@ -175,7 +157,22 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) if (w < wave) woff += s_wsum[w];
         const u32 local_start = woff + inc - cnt_d;
-        s_gdelta[d] = digit_base[d] + offsets[(size_t)d * num_parts + part] - local_start;
+        // global base of digit d = exclusive scan of the 256 digit totals, done here by every block (a dozen instructions)
+        // rather than by a 1-block kernel between the row scan and the scatter (a 4.5 us bubble per pass)
+        const u32 tot_d = digit_totals[d];
+        u32 tinc = tot_d;
+#pragma unroll
+        for (u32 s = 1; s < 64; s <<= 1) {
+            const u32 t = __shfl_up(tinc, s, 64);
+            if (lane >= s) tinc += t;
+        }
+        __syncthreads();  // s_wsum is re-used
+        if (lane == 63u) s_wsum[wave] = tinc;
+        __syncthreads();
+        u32 tbase = tinc - tot_d;
+#pragma unroll
+        for (u32 w = 0; w < SORT_THREADS / 64; w++) if (w < wave) tbase += s_wsum[w];
+        s_gdelta[d] = tbase + offsets[(size_t)d * num_parts + part] - local_start;
         u32 run = local_start;   // per-wave start of digit d inside the partition's sorted order
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) {
@@ -206,21 +203,22 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     }
 }
 
-// ranges[t] = first index whose key>>16 == t+1, 0xFFFFFFFF for empty tiles, ranges[T] = E.
-__global__ void tile_ranges_init_kernel(u32* __restrict__ ranges, u32 total_tiles, const u32* __restrict__ count_ptr) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total_tiles) ranges[i] = 0xFFFFFFFFu;
-    if (i == total_tiles) ranges[i] = *count_ptr;
-}
-
+// ranges[t] = first index whose key>>16 == t+1, 0xFFFFFFFF for empty tiles, ranges[T] = E  (tile-ranges.wgsl:34-76 writes the same
+// table with an init pass + one atomicMin per entry).  The keys are sorted, so each tile finds its start by a lower-bound search
+// (23 probes at 6 M entries): one launch over T+1 threads instead of an init launch plus a pass over all E keys.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 total_tiles,
                                                            u32* __restrict__ ranges) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > total_tiles) return;
     const u32 count = *count_ptr;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const u32 t = keys[i] >> 16u;
-        const u32 prev = (i > 0u) ? (keys[i - 1] >> 16u) : 0u;
-        if (t != prev && t >= 1u && t - 1u < total_tiles) ranges[t - 1u] = i;
+    if (t == total_tiles) { ranges[t] = count; return; }
+    const u32 want = t + 1u;  // tile field of the key is 1-based
+    u32 lo = 0u, hi = count;  // first index with (key >> 16) >= want
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if ((keys[mid] >> 16u) < want) lo = mid + 1u; else hi = mid;
     }
+    ranges[t] = (lo < count && (keys[lo] >> 16u) == want) ? lo : 0xFFFFFFFFu;
 }
 
 }  // namespace
@@ -290,7 +288,6 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
         const u32 shift = p * 8u;
         WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->counts);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
-        WDGS_LAUNCH(dev, "sort_scan_base", sort_scan_base_kernel, dim3(1), dim3(RADIX), 0, s->totals);
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
                     s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->counts, s->totals);
         src ^= 1;
@@ -303,10 +300,8 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
 }  // extern "C"
 
 int launch_tile_ranges(wdgs_device* dev, const void* sorted_keys, const void* count_ptr, u32 total_tiles, void* ranges) {
-    WDGS_LAUNCH(dev, "tile_ranges_init", tile_ranges_init_kernel, dim3(ceil_div(total_tiles + 1, 256)), dim3(256), 0, (u32*)ranges, total_tiles,
-                (const u32*)count_ptr);
-    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(dev->num_cus * 8), dim3(256), 0, (const u32*)sorted_keys, (const u32*)count_ptr, total_tiles,
-                (u32*)ranges);
+    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(total_tiles + 1, 256)), dim3(256), 0, (const u32*)sorted_keys, (const u32*)count_ptr,
+                total_tiles, (u32*)ranges);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
