@@ -199,33 +199,69 @@ __global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, cons
     }
 }
 
+// K6 emit_main (tiled-forward.wgsl:297-354): every visible splat writes one (key, index) entry per covered tile at its scanned
+// offset.  The reference (and a thread-per-splat port) runs a divergent double loop with stores 24 B apart across lanes.  Here a
+// wave expands its 64 splats cooperatively: their ranges are adjacent in the output (offsets are an exclusive scan), so the wave
+// owns one contiguous run of T entries; lane j of each 64-entry slice finds the owning splat by a 6-step search over the wave's
+// count prefix (wave-private LDS) and derives its tile from the entry's rank inside that splat's box.  Stores are coalesced and
+// every lane does the same work regardless of the box sizes.
 __global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict__ splats, const u32* __restrict__ depths,
                                                     const u32* __restrict__ tile_counts, const u32* __restrict__ tile_offsets,
                                                     RenderSettings settings, TileInfo ti, u32* __restrict__ keys, u32* __restrict__ values,
                                                     u32 capacity) {
+    __shared__ u32 s_pre[4][64], s_org[4][64], s_w[4][64], s_inv[4][64], s_dep[4][64];
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const u32 num_tiles = tile_counts[idx];
-    if (num_tiles == 0u) return;
-    const u32 start = tile_offsets[idx];
-    const uint2 w01 = *reinterpret_cast<const uint2*>(splats + (size_t)idx * 6);
-    const vec2 ndc = V2(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x));
-    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
-    const vec2 ext = V2(wd_min(wd_unpack_lo(w01.y), cap), wd_min(wd_unpack_hi(w01.y), cap));
-    const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
-    const TileBox tb = tile_box(ndc, ext, viewport, ti.num_tiles_x, ti.num_tiles_y, false);
-    if (!tb.valid) return;
-    const u32 depth16 = depths[idx] >> 16u;
-    u32 offset = 0u;
-    for (u32 ty = tb.min_y; ty <= tb.max_y; ty++) {
-        for (u32 tx = tb.min_x; tx <= tb.max_x; tx++) {
-            const u32 tile_id = ty * ti.num_tiles_x + tx;
-            const u32 key_idx = start + offset;
-            if (key_idx < capacity) {
-                keys[key_idx] = ((tile_id + 1u) << 16u) | depth16;
-                values[key_idx] = idx;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32 cnt = 0u, org = 0u, width = 1u, depth16 = 0u;
+    if (idx < n) {
+        const u32 num_tiles = tile_counts[idx];
+        if (num_tiles != 0u) {
+            const uint2 w01 = *reinterpret_cast<const uint2*>(splats + (size_t)idx * 6);
+            const vec2 ndc = V2(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x));
+            const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+            const vec2 ext = V2(wd_min(wd_unpack_lo(w01.y), cap), wd_min(wd_unpack_hi(w01.y), cap));
+            const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+            const TileBox tb = tile_box(ndc, ext, viewport, ti.num_tiles_x, ti.num_tiles_y, false);
+            if (tb.valid) {
+                // the same box project_count counted (it keeps splats with 1..2048 tiles), row-major as the reference's double loop
+                width = tb.max_x - tb.min_x + 1u;
+                cnt = width * (tb.max_y - tb.min_y + 1u);
+                org = tb.min_y * ti.num_tiles_x + tb.min_x;
+                depth16 = depths[idx] >> 16u;
             }
-            offset++;
+        }
+    }
+    // exclusive prefix of the counts over the wave
+    u32 inc = cnt;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    const u32 total = (u32)__shfl((int)inc, 63, 64);
+    if (total == 0u) return;
+    const u32 wave_first = idx - lane;  // Gaussian of lane 0 (< n, or total would be 0)
+    const u32 start0 = tile_offsets[wave_first];
+    s_pre[wave][lane] = inc - cnt;
+    s_org[wave][lane] = org;
+    s_w[wave][lane] = width;
+    s_inv[wave][lane] = 0xFFFFFFFFu / width + 1u;  // floor(k / width) == umulhi(k, inv) for k * width < 2^32 (k <= 2048 here)
+    s_dep[wave][lane] = depth16;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32* pre = s_pre[wave];
+    for (u32 e = lane; e < total; e += 64u) {
+        u32 o = 0u;  // last lane whose prefix is <= e: the splat that owns entry e
+#pragma unroll
+        for (u32 step = 32u; step >= 1u; step >>= 1) o += (pre[o + step] <= e) ? step : 0u;
+        const u32 k = e - pre[o];
+        const u32 w = s_w[wave][o];
+        const u32 row = (w == 1u) ? k : __umulhi(k, s_inv[wave][o]);  // (the reciprocal of 1 does not fit 32 bits)
+        const u32 tile_id = s_org[wave][o] + row * ti.num_tiles_x + (k - row * w);
+        const u32 key_idx = start0 + e;
+        if (key_idx < capacity) {
+            keys[key_idx] = ((tile_id + 1u) << 16u) | s_dep[wave][o];
+            values[key_idx] = wave_first + o;
         }
     }
 }
