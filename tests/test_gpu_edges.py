@@ -1,0 +1,139 @@
+"""GPU: degenerate and boundary inputs through the whole path against the oracle -- nothing visible, a single Gaussian, viewports
+smaller than a tile and not multiples of 16, splats larger than the image with the radius cap lifted (incl. the > 2048-tile cull
+of tiled-forward.wgsl), saturated pixels, and an empty point cloud."""
+import numpy as np
+import pytest
+
+from webdgs_amd import ops, synth
+
+import harness
+from harness import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _full_step_matches_oracle(orc, dev, cfg, g, sh, cam, target, steps=2, max_radius=None):
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    if max_radius is not None:
+        st[6] = max_radius
+    ref_g, ref_sh = g.copy(), sh.copy()
+    ref_state = orc.unpack(ref_g, ref_sh)
+    pipe = harness.HipPipeline(dev, cfg, g, sh, cam) if max_radius is None else _pipeline_with_radius(dev, cfg, g, sh, cam, max_radius)
+    tbuf = dev.bufferFrom(target)
+    try:
+        for step in range(steps):
+            ref = orc.train_step(ref_g, ref_sh, ref_state, cam, st, ti, target)
+            pipe.train_step(tbuf)
+            dev.synchronize()
+            got = pipe.collect_forward()
+            n = cfg.num_points
+            assert int(got["stats"][0]) == ref["total_entries"], f"E, step {step}"
+            assert_bits_equal(got["rgba8"], ref["rgba8"], f"image, step {step}")
+            assert_bits_equal(got["final_T"], ref["final_T"], f"final T, step {step}")
+            assert_bits_equal(got["n_contrib"], ref["n_contrib"], f"n_contrib, step {step}")
+            assert_bits_equal(pipe.bwd.getGradientsBuffer().read(np.uint32).reshape(-1, 8)[:n], ref["gradients"], f"packed gradients, step {step}")
+            assert_bits_equal(pipe.pc.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6)[:n], ref_g, f"re-packed Gaussians, step {step}")
+            assert_bits_equal(pipe.pc.sh_buffer.read(np.uint32).reshape(-1, 24)[:n], ref_sh, f"re-packed SH, step {step}")
+        return got
+    finally:
+        pipe.destroy()
+
+
+def _pipeline_with_radius(dev, cfg, g, sh, cam, max_radius):
+    p = harness.HipPipeline.__new__(harness.HipPipeline)
+    p.dev, p.cfg = dev, cfg
+    p.pc = ops.createPointCloud(dev, g, sh, cfg.sh_deg)
+    p.camera = dev.bufferFrom(cam)
+    p.fwd = ops.TiledForwardPass(dev, p.pc, p.camera, dict(viewportWidth=cfg.width, viewportHeight=cfg.height, renderMode="gaussian", maxSplatRadiusPx=max_radius))
+    p.rast = ops.TiledRasterizer(dict(device=dev, forwardPass=p.fwd, format="rgba8unorm"))
+    p.bwd = ops.TiledBackwardPass(dev, p.pc, dict(viewportWidth=cfg.width, viewportHeight=cfg.height, trainingConfig={}, maxSplatRadiusPx=max_radius))
+    p.opt = None
+    return p
+
+
+def _f16(x):
+    return np.float16(x).view(np.uint16)
+
+
+def _gaussians(rows):
+    """rows: (x, y, z, opacity_raw, log_sigma) -> packed Gaussian words + SH (DC only, grey 0.5 + 0.28*1.5)."""
+    g = np.zeros((len(rows), 12), np.uint16)
+    sh = np.zeros((len(rows), 48), np.uint16)
+    for i, (x, y, z, o, ls) in enumerate(rows):
+        g[i, 0:4] = [_f16(x), _f16(y), _f16(z), _f16(o)]
+        g[i, 4] = _f16(1.0)  # identity rotation (w, x, y, z)
+        g[i, 8:11] = _f16(ls)
+        sh[i, 0:3] = [_f16(1.5), _f16(0.3), _f16(-0.7)]
+    return g.view(np.uint32).reshape(len(rows), 6), sh.view(np.uint32).reshape(len(rows), 24)
+
+
+def test_nothing_visible_leaves_everything_untouched(hip_device, orc):
+    cfg = harness.small_config("c1", num_points=500, width=64, height=48)
+    g, sh, cam = harness.scene(cfg)
+    gh = g.view(np.uint16).reshape(-1, 12).copy()
+    gh[:, 2] = _f16(-5.0)  # behind the camera
+    g = gh.view(np.uint32).reshape(-1, 6)
+    target = np.full((cfg.height, cfg.width, 4), 90, np.uint8)
+    got = _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target)
+    assert int(got["stats"][0]) == 0 and int(got["stats"][1]) == 0
+    assert (got["rgba8"][..., :3] == 0).all() and (got["final_T"] == 1.0).all() and (got["n_contrib"] == 0).all()
+    assert (got["tile_ranges"][:-1] == 0xFFFFFFFF).all() and got["tile_ranges"][-1] == 0
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (16, 16), (17, 33)])
+def test_single_gaussian_and_tiny_viewports(hip_device, orc, w, h):
+    cfg = harness.small_config("c1", num_points=1, width=w, height=h, fy=20.0)
+    g, sh = _gaussians([(0.0, 0.0, 3.0, 2.0, -1.5)])
+    cam = synth.identity_camera(cfg)
+    target = np.full((h, w, 4), 200, np.uint8)
+    got = _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target)
+    assert int(got["stats"][1]) == 1 and got["n_contrib"].max() >= 1
+
+
+def test_huge_splats_without_the_radius_cap_and_the_2048_tile_cull(hip_device, orc):
+    """max_splat_radius_px < 0 lifts the cap: a splat covering the whole 640x480 image is binned into all 1200 tiles; on a
+    1280x720 grid (3600 tiles) the same splat exceeds 2048 tiles and is dropped by the projection, as in the reference."""
+    rows = [(0.0, 0.0, 2.0, 3.0, 0.5), (0.3, -0.2, 2.5, 1.0, -2.0), (-0.4, 0.1, 3.0, 0.5, -0.5)]
+    g, sh = _gaussians(rows)
+    for (w, h, expect_big) in ((640, 480, True), (1280, 720, False)):
+        cfg = harness.small_config("c2", num_points=len(rows), width=w, height=h, fy=400.0, sh_deg=0)
+        cam = synth.identity_camera(cfg)
+        target = np.full((h, w, 4), 128, np.uint8)
+        got = _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target, steps=1, max_radius=-1.0)
+        counts = got["tile_counts"]
+        tiles = ((w + 15) // 16) * ((h + 15) // 16)
+        assert (counts[0] == tiles) == expect_big, (counts, tiles)
+        if not expect_big:
+            assert counts[0] == 0  # > 2048 tiles: culled (tiled-forward.wgsl num_tiles guard)
+
+
+def test_saturated_pixels_stop_early_but_match(hip_device, orc):
+    """Hundreds of opaque splats stacked on the same pixels: every wave saturates (A > 0.99) long before its list ends."""
+    rng = np.random.default_rng(4)
+    rows = [(float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.05, 0.05)), float(2.0 + 0.01 * i), 6.0, -2.2) for i in range(600)]
+    g, sh = _gaussians(rows)
+    cfg = harness.small_config("c1", num_points=len(rows), width=48, height=48, fy=120.0, sh_deg=0)
+    cam = synth.identity_camera(cfg)
+    target = np.zeros((48, 48, 4), np.uint8)
+    got = _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target)
+    centre = got["final_T"][20:28, 20:28]
+    assert (centre < 0.011).all() and got["n_contrib"][24, 24] < 600
+
+
+def test_empty_point_cloud(hip_device):
+    dev = hip_device
+    pc = ops.createPointCloud(dev, np.zeros((0, 6), np.uint32), np.zeros((0, 24), np.uint32), 0)
+    cam = dev.bufferFrom(synth.identity_camera(harness.small_config("c1", num_points=1, width=40, height=24)))
+    fwd = ops.TiledForwardPass(dev, pc, cam, dict(viewportWidth=40, viewportHeight=24, renderMode="gaussian"))
+    rast = ops.TiledRasterizer(dict(device=dev, forwardPass=fwd, format="rgba8unorm"))
+    try:
+        fwd.encode(None)
+        rast.encode(None, 40, 24)
+        st = fwd.check()
+        assert int(st[0]) == 0 and int(st[1]) == 0
+        img = rast.getOutputTextureView().read(np.uint8).reshape(24, 40, 4)
+        assert (img[..., :3] == 0).all() and (img[..., 3] == 255).all()
+        assert (rast.getAlphaTextureView().read(np.float32) == 1.0).all()
+    finally:
+        rast.destroy()
+        fwd.destroy()

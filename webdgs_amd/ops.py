@@ -150,6 +150,9 @@ class HipDevice:
 
     def bufferFrom(self, array: np.ndarray, label: str = "") -> HipBuffer:
         a = np.ascontiguousarray(array)
+        if a.nbytes == 0:  # an empty point cloud still needs a valid (never dereferenced) device address
+            t = torch.zeros(4, dtype=torch.uint8, device=self.torch_device)
+            return HipBuffer(self, t.data_ptr(), 0, t, label)
         t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self.torch_device)
         return HipBuffer(self, t.data_ptr(), a.nbytes, t, label)
 
