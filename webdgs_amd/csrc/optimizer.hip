@@ -98,11 +98,13 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
     *reinterpret_cast<uint2*>(gp) = make_uint2(wd_pack2(P.x, P.y), wd_pack2(P.z, op));
     *reinterpret_cast<uint2*>(gp + 2) = make_uint2(wd_pack2(R.x, R.y), wd_pack2(R.z, R.w));
     *reinterpret_cast<uint2*>(gp + 4) = make_uint2(wd_pack2(S.x, S.y), wd_pack2(S.z, 0.0f));
+    // SH word 0 and the LOW half of word 1 (the third DC coefficient) as a 4-byte and a 2-byte store.  The reference writes
+    // pack2x16float(c2, unpack2x16float(old).y): the neighbouring coefficient survives that round trip bit for bit (only a NaN
+    // payload could change, which WGSL leaves implementation-defined), so not touching it is the same result -- without fetching
+    // the 96-byte row's cache line just to copy 2 bytes back (it was 19 % of this kernel's HBM traffic).
     u32* shp = sh_buffer + (size_t)idx * 24;
-    const u32 old1 = shp[1];
-    // pack(c2, unpack(old).y): the high half survives the fp16 round trip bit for bit unless it is a NaN payload
-    const u32 hi = wd_f16bits(wd_unpack_hi(old1));
-    *reinterpret_cast<uint2*>(shp) = make_uint2(wd_pack2(c0, c1), wd_f16bits(c2) | (hi << 16));
+    shp[0] = wd_pack2(c0, c1);
+    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)wd_f16bits(c2);
 }
 
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
