@@ -103,3 +103,47 @@ def test_napi_addon_renders_on_the_gpu():
     out = subprocess.run(["node", os.path.join(ROOT, "bindings", "napi", "smoke.js"), "gpu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "napi gpu smoke: E=" in out.stdout and "visible=64" in out.stdout
+
+
+def test_c3_full_size_train_step_equals_the_oracle(hip_device, orc):
+    """BASELINE config c3 at full size -- 1 M Gaussians, 1920x1080, SH 3, ~6 M tile entries -- one complete training step
+    (project, scan, emit, sort, ranges, composite, loss, backward raster, geometry backward, Adam, re-pack) compared with the
+    oracle bit for bit.  (The oracle needs a few seconds per step on the GPU box's host cores.)"""
+    cfg = synth.CONFIGS["c3"]
+    g, sh = synth.make_gaussians(cfg)
+    cam = synth.circle_cameras(cfg, 8)[5]
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    tg, tsh = synth.make_target_scene(g, sh)
+    tp = harness.HipPipeline(hip_device, cfg, tg, tsh, cam)
+    tp.forward()
+    target = tp.rast.getOutputTextureView().read(np.uint8).reshape(cfg.height, cfg.width, 4).copy()
+    tp.destroy()
+    ref_g, ref_sh = g.copy(), sh.copy()
+    ref_state = orc.unpack(ref_g, ref_sh)
+    ref = orc.train_step(ref_g, ref_sh, ref_state, cam, st, ti, target)
+    assert ref["total_entries"] > 5_000_000
+    pipe = harness.HipPipeline(hip_device, cfg, g, sh, cam)
+    try:
+        pipe.train_step(hip_device.bufferFrom(target))
+        hip_device.synchronize()
+        got = pipe.collect_forward()
+        n = cfg.num_points
+        assert int(got["stats"][0]) == ref["total_entries"]
+        harness.assert_bits_equal(got["sorted_values"], ref["sorted_values"][:ref["total_entries"]], "c3 sort order")
+        harness.assert_bits_equal(got["rgba8"], ref["rgba8"], "c3 image")
+        harness.assert_bits_equal(got["final_T"], ref["final_T"], "c3 final T")
+        harness.assert_bits_equal(got["n_contrib"], ref["n_contrib"], "c3 n_contrib")
+        harness.assert_bits_equal(pipe.bwd.getLossTextureView().read(np.float32).reshape(cfg.height, cfg.width, 4), ref["loss_grad"], "c3 loss gradient image")
+        gm, gc, go, gcol = harness.acc_to_reference_layout(pipe.bwd.getAccumulatorsBuffer().read(np.int32), n)
+        harness.assert_bits_equal(gm, ref["grad_means"], "c3 mean accumulators")
+        harness.assert_bits_equal(gc, ref["grad_conics"], "c3 conic accumulators")
+        harness.assert_bits_equal(go, ref["grad_opacity"], "c3 opacity accumulators")
+        harness.assert_bits_equal(gcol, ref["grad_colors"], "c3 colour accumulators")
+        harness.assert_bits_equal(pipe.bwd.getGradientsBuffer().read(np.uint32).reshape(-1, 8)[:n], ref["gradients"], "c3 packed gradients")
+        state = pipe.read_state()
+        for k in ref_state:
+            harness.assert_bits_equal(state[k], ref_state[k], "c3 optimizer state " + k)
+        harness.assert_bits_equal(pipe.pc.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6), ref_g, "c3 re-packed Gaussians")
+        harness.assert_bits_equal(pipe.pc.sh_buffer.read(np.uint32).reshape(-1, 24), ref_sh, "c3 re-packed SH")
+    finally:
+        pipe.destroy()
