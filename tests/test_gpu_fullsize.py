@@ -147,3 +147,76 @@ def test_c3_full_size_train_step_equals_the_oracle(hip_device, orc):
         harness.assert_bits_equal(pipe.pc.sh_buffer.read(np.uint32).reshape(-1, 24), ref_sh, "c3 re-packed SH")
     finally:
         pipe.destroy()
+
+
+def test_c3_full_size_densify_equals_the_oracle(hip_device, orc):
+    """The densify/prune rebuild at BASELINE size: half-resolution metric view of 1 M Gaussians, metric map + counts,
+    decide / cap (maxNewPointsPerStep = 50 000 as in config c5) / scans / total, and the fused scatter of the point cloud and all
+    optimizer state -- every array equal to the oracle's."""
+    cfg = synth.CONFIGS["c3"]
+    g, sh = synth.make_gaussians(cfg)
+    cam = synth.circle_cameras(cfg, 8)[2]
+    n = cfg.num_points
+    mw, mh = cfg.width // 2, cfg.height // 2
+    mst, mti = synth.render_settings(cfg, mw, mh), synth.tile_info(mw, mh, 0)
+    mcam = synth.camera_block(cam[0:16].reshape(4, 4).T.astype(np.float64), mw, mh, cfg.fy * mh / cfg.height)
+    tg, tsh = synth.make_target_scene(g, sh)
+    # oracle side
+    target = orc.forward(tg, tsh, cam, synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0))["rgba8"]
+    mfw = orc.forward(g, sh, mcam, mst, mti)
+    gt_small = orc.downsample_bilinear(target, mw, mh)
+    err, mm, flags = orc.metric_map(mfw["rgba8"], gt_small, 0.5)
+    counts = np.zeros(n, np.uint32)
+    bst = mst.copy(); bst[5] = 0.0
+    cap = max(int(mfw["total_entries"]), 1)
+    orc.metric_count(bst, mfw["tile_ranges"], mfw["sorted_values"][:cap].copy(), cap, mfw["splats"], flags, mfw["n_contrib"], counts)
+    counts_raw = counts.copy()
+    orc.metric_normalize(counts, 1)
+    max_out = n + 50_000
+    prep = orc.densify_prepare(g, counts, max_out, clone_threshold=40, prune_opacity=0.12, split_scale=0.012)
+    a = prep["actions"]
+    assert min((a == i).sum() for i in range(4)) > 100, "the case must exercise keep, clone, split and prune"
+    out_n = min(prep["total"], max_out)
+    state = orc.unpack(g.copy(), sh.copy())
+    og, osh, ost = orc.densify_scatter(g, sh, state, prep, out_n)
+    # HIP side
+    dev = hip_device
+    pc = ops.createPointCloud(dev, g, sh, cfg.sh_deg)
+    fwd = ops.TiledForwardPass(dev, pc, dev.bufferFrom(mcam), dict(viewportWidth=mw, viewportHeight=mh, renderMode="gaussian"))
+    rast = ops.TiledRasterizer(dict(device=dev, forwardPass=fwd, format="rgba8unorm"))
+    mp = ops.TiledBackwardPass(dev, pc, dict(viewportWidth=mw, viewportHeight=mh, trainingConfig={}))
+    dp = ops.DensifyPrunePass(dev, dict(strategy="gpu_rebuild", numViews=1, cloneThreshold=40, splitThreshold=0.012, pruneThreshold=0.12,
+                                        maxNewPointsPerStep=50_000, maxBufferBytes=0))
+    opt = ops.Optimizer(dev, pc)
+    try:
+        small = dev.createBuffer(4 * mw * mh)
+        ops.downsampleRGBA8(dev, dev.bufferFrom(target), cfg.width, cfg.height, small, mw, mh)
+        harness.assert_bits_equal(small.read(np.uint8).reshape(mh, mw, 4), gt_small, "down-sampled ground truth")
+        fwd.encode(None)
+        rast.encode(None, mw, mh)
+        harness.assert_bits_equal(rast.getOutputTextureView().read(np.uint8).reshape(mh, mw, 4), mfw["rgba8"], "metric render")
+        mp.getMetricCountsBuffer().clear()
+        mp.computeMetricMap(None, rast.getOutputTextureView(), small, dict(threshold=0.5))
+        harness.assert_bits_equal(mp.getMetricMapTextureView().read(np.uint32).reshape(mh, mw), flags, "metric flags")
+        mp.computeMetricCounts(None, dict(splatBuffer=fwd.getResources()["splatBuffer"], tileOffsetsBuffer=rast.getTileOffsetsBuffer(),
+                                          tileIndicesBuffer=fwd.getSortedIndicesBuffer(), nContribTexture=rast.getNContribTextureView()), dict(clear=False))
+        harness.assert_bits_equal(mp.getMetricCountsBuffer().read(np.uint32)[:n], counts_raw, "metric counts")
+        mp.normalizeMetricCounts(None, dict(divisor=1))
+        p = dp.encodePrepare(None, dict(pointCloud=pc, metricCountsBuffer=mp.getMetricCountsBuffer()))
+        assert p["maxOutPoints"] == max_out and dp.readTotal() == prep["total"]
+        harness.assert_bits_equal(p["actionBuffer"].read(np.uint32)[:n], prep["actions"], "actions")
+        harness.assert_bits_equal(p["outCountBuffer"].read(np.uint32)[:n], prep["counts"], "out counts")
+        harness.assert_bits_equal(p["outOffsetBuffer"].read(np.uint32)[:n], prep["offsets"], "out offsets")
+        out_pc = ops.allocatePointCloudLike(dev, pc, dict(numPoints=out_n))
+        out_state = ops.allocateOptimizerStateBuffers(dev, out_n)
+        dp.encodeScatter(None, dict(pointCloud=pc, optimizerState=opt.getStateBuffers(), outOffsetBuffer=p["outOffsetBuffer"], outNumPoints=out_n,
+                                    resetNewOptimizerState=True), dict(outPointCloud=out_pc, outOptimizerState=out_state))
+        dev.synchronize()
+        harness.assert_bits_equal(out_pc.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6), og, "scattered gaussians")
+        harness.assert_bits_equal(out_pc.sh_buffer.read(np.uint32).reshape(-1, 24), osh, "scattered sh")
+        names = dict(optPosBuffer="opt_pos", optRotBuffer="opt_rot", optScaleBuffer="opt_scale", optOpacityBuffer="opt_opacity", paramSH="param_sh", stateSH="state_sh")
+        for k, v in names.items():
+            harness.assert_bits_equal(out_state[k].read(np.float32).reshape(ost[v].shape), ost[v], "scattered " + v)
+    finally:
+        for o in (opt, dp, mp, rast, fwd):
+            o.destroy()
