@@ -220,3 +220,33 @@ def test_c3_full_size_densify_equals_the_oracle(hip_device, orc):
     finally:
         for o in (opt, dp, mp, rast, fwd):
             o.destroy()
+
+
+def test_c5_full_size_forward_and_train_step_equal_the_oracle(hip_device, orc):
+    """BASELINE config c5's shape -- 5 M Gaussians at 3840x2160, SH 3, ~38 M tile entries (beyond every capacity cap of the
+    reference) -- one complete training step against the oracle, bit for bit."""
+    cfg = synth.CONFIGS["c5"]
+    g, sh = synth.make_gaussians(cfg)
+    cam = synth.identity_camera(cfg)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    target = np.full((cfg.height, cfg.width, 4), 255, np.uint8)
+    target[..., :3] = (np.add.outer(np.arange(cfg.height), np.arange(cfg.width)) % 251).astype(np.uint8)[..., None]
+    ref_g, ref_sh = g.copy(), sh.copy()
+    ref_state = orc.unpack(ref_g, ref_sh)
+    ref = orc.train_step(ref_g, ref_sh, ref_state, cam, st, ti, target)
+    assert ref["total_entries"] > 30_000_000
+    pipe = harness.HipPipeline(hip_device, cfg, g, sh, cam)
+    try:
+        pipe.train_step(hip_device.bufferFrom(target))
+        hip_device.synchronize()
+        got = pipe.collect_forward()
+        n = cfg.num_points
+        assert int(got["stats"][0]) == ref["total_entries"]
+        harness.assert_bits_equal(got["sorted_values"], ref["sorted_values"][:ref["total_entries"]], "c5 sort order")
+        harness.assert_bits_equal(got["rgba8"], ref["rgba8"], "c5 image")
+        harness.assert_bits_equal(got["n_contrib"], ref["n_contrib"], "c5 n_contrib")
+        harness.assert_bits_equal(pipe.bwd.getGradientsBuffer().read(np.uint32).reshape(-1, 8)[:n], ref["gradients"], "c5 packed gradients")
+        harness.assert_bits_equal(pipe.pc.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6), ref_g, "c5 re-packed Gaussians")
+        harness.assert_bits_equal(pipe.pc.sh_buffer.read(np.uint32).reshape(-1, 24), ref_sh, "c5 re-packed SH")
+    finally:
+        pipe.destroy()
