@@ -12,7 +12,7 @@
 //   * the 9 per-pixel contributions are summed across the wave in registers by a halving butterfly
 //     (v_permlane32_swap, v_permlane16_swap, DPP row reduce: 28 VALU ops for all nine sums instead of 9 full reductions)
 //     and land in nine lanes that issue ONE atomic instruction per (wave, splat) -- instead of 9 per (pixel, splat);
-//   * a tile's four waves run on one XCD (see raster.hip) so its entries and splats come from that XCD's L2.
+//   * a tile's four waves share a workgroup (one CU, one XCD), so its entries and splats come from that XCD's L2 (raster.hip).
 // The contributions keep the reference's semantics exactly: each is truncated to i32 at x1e6 per pixel
 // (common.wgsl:113-116) and integer addition is order-free, so the result is bit-reproducible and equal to the oracle's.
 // Bound: fp32 VALU issue (exp, one IEEE division, about 45 further lane-ops per contributing pair).
@@ -56,11 +56,6 @@ WD_DEV int cvt_fixed(float scaled) {
     int r;
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(scaled));
     return r;
-}
-
-__device__ __forceinline__ u32 xcd_contiguous_id(u32 b, u32 nblocks) {
-    const u32 q = nblocks / 8u, r = nblocks % 8u, xcd = b % 8u, local = b / 8u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
 }
 
 __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,

@@ -11,20 +11,15 @@
 //     end -- after saturation the reference's loop `continue`s without touching C, A or last_contributor (lines 224-226),
 //     so stopping cannot change an output.  (A 256-thread version spent half its wave-cycles waiting at barriers for the
 //     slowest of its four waves: profiles/r01a_pmc_summary.txt.)
-//   * the four waves of a tile are mapped to one XCD (blockIdx is dealt round-robin over the 8 XCDs), so the tile's
-//     entries and splats are fetched from HBM once and served to the other three waves by that XCD's L2.
+//   * the four waves of a tile share a workgroup (hence a CU and an XCD), so the tile's entries and splats are fetched once and
+//     served to the other three waves by L1/L2; tiles are dealt to the 8 XCDs round-robin (blockIdx order) -- giving each XCD one
+//     contiguous band of the image instead was measured 15-30 % slower (the bands' loads differ, the XCDs finish apart).
 // Bound: fp32 VALU issue (about 40 lane-ops per accepted pixel-splat pair incl. the deterministic exp), not HBM.
 // Arithmetic is the pinned contraction of DESIGN.md "raster math", bit-identical to the parity oracle.
 #include "common.h"
 #include "dmath.h"
 
 namespace {
-
-// Logical workgroup id such that ids 4t..4t+3 (one tile) run on one XCD: hardware deals blockIdx b to XCD b % 8.
-__device__ __forceinline__ u32 xcd_contiguous_id(u32 b, u32 nblocks) {
-    const u32 q = nblocks / 8u, r = nblocks % 8u, xcd = b % 8u, local = b / 8u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
-}
 
 template <bool GAUSSIAN_MODE>
 __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
