@@ -218,7 +218,12 @@ def main() -> None:
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
             "roofline": roofline, "hbm_roofline_by_stage": hbm_by_stage, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if world > 1:  # orderly shutdown: every rank has finished its collectives before any communicator is torn down
+        import torch.distributed as dist
+        parallel.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
 
 
 def run_cpu_baseline(cfg, g, sh, cam, points: int) -> dict:
