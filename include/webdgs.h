@@ -286,6 +286,10 @@ int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians_dev, void* sh_de
 /* acc_f32[N*14] += unpack(GaussianGradient[N]) where tile_counts > 0; visible[N] += (tile_counts > 0). */
 int wdgs_accumulate_gradients(wdgs_device* dev, uint32_t num_points, const void* gradients_dev, const void* tile_counts_dev,
                               void* acc_f32_dev, void* visible_counts_dev);
+/* Overwrite form for the first view of a batch: acc_f32[N*14] = unpack(GaussianGradient[N]) (zeros where tile_counts == 0),
+ * visible[N] = (tile_counts > 0).  Spares the batch a clearing pass over the 60 B/Gaussian block. */
+int wdgs_store_gradients(wdgs_device* dev, uint32_t num_points, const void* gradients_dev, const void* tile_counts_dev,
+                         void* acc_f32_dev, void* visible_counts_dev);
 uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op);
 /* Host-side counter only (optimizer.ts:301): call when a recorded command buffer containing step() is re-submitted. */
 int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count);

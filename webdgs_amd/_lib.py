@@ -183,6 +183,7 @@ SIGNATURES = {
     "wdgs_optimizer_step": (_I, [_P, _P, _P, _P, _P]),
     "wdgs_optimizer_step_f32": (_I, [_P, _P, _P, _P, _P]),
     "wdgs_accumulate_gradients": (_I, [_P, _U, _P, _P, _P, _P]),
+    "wdgs_store_gradients": (_I, [_P, _U, _P, _P, _P, _P]),
     "wdgs_optimizer_get_iteration": (_U, [_P]),
     "wdgs_optimizer_advance_iteration": (_I, [_P, _U]),
     "wdgs_optimizer_get_hyperparameters": (_I, [_P, C.POINTER(AdamHyperparameters)]),

@@ -21,6 +21,7 @@ int launch_adam_repack_f32(wdgs_device*, u32, const wdgs_adam_hyperparameters&, 
 int launch_dc_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
 int launch_dc_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
 int launch_accumulate_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
+int launch_store_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
 int launch_unpack(wdgs_device*, u32, const void*, const void*, const wdgs_optimizer_state&);
 int launch_metric_map(wdgs_device*, u32, u32, const void*, const void*, float, float, void*, void*, void*, void*);
 int launch_metric_count(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, u32, const void*, u32, const void*, const void*, void*, u32);
@@ -800,6 +801,10 @@ int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const
 int wdgs_accumulate_gradients(wdgs_device* d, uint32_t n, const void* gradients, const void* tile_counts, void* acc, void* visible) {
     WDGS_REQUIRE(d && gradients && tile_counts && acc && visible, WDGS_E_INVALID, "wdgs_accumulate_gradients: null argument");
     return launch_accumulate_gradients(d, n, gradients, tile_counts, acc, visible);
+}
+int wdgs_store_gradients(wdgs_device* d, uint32_t n, const void* gradients, const void* tile_counts, void* acc, void* visible) {
+    WDGS_REQUIRE(d && gradients && tile_counts && acc && visible, WDGS_E_INVALID, "wdgs_store_gradients: null argument");
+    return launch_store_gradients(d, n, gradients, tile_counts, acc, visible);
 }
 uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op) { return op ? op->iteration : 0; }
 int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count) {

@@ -175,6 +175,26 @@ __global__ __launch_bounds__(256) void accumulate_gradients_kernel(u32 n, const 
     visible[idx] += 1u;
 }
 
+// First view of a batch: acc = unpack(GaussianGradient) (zeros where the Gaussian touched no tile), visible = 0 or 1 -- the
+// overwrite form of accumulate_gradients, so the 60 B/Gaussian block needs no clearing pass before it.
+__global__ __launch_bounds__(256) void store_gradients_kernel(u32 n, const u32* __restrict__ gradients, const u32* __restrict__ tile_counts,
+                                                               float* __restrict__ acc, u32* __restrict__ visible) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const bool vis = tile_counts[idx] != 0u;
+    Grad14 g = {};
+    if (vis) g = unpack_gradient(gradients, idx);
+    float* a = acc + (size_t)idx * 14;  // 56-byte rows: 8-byte aligned
+    reinterpret_cast<float2*>(a)[0] = make_float2(g.pos[0], g.pos[1]);
+    reinterpret_cast<float2*>(a)[1] = make_float2(g.pos[2], g.opac);
+    reinterpret_cast<float2*>(a)[2] = make_float2(g.rot[0], g.rot[1]);
+    reinterpret_cast<float2*>(a)[3] = make_float2(g.rot[2], g.rot[3]);
+    reinterpret_cast<float2*>(a)[4] = make_float2(g.scale[0], g.scale[1]);
+    reinterpret_cast<float2*>(a)[5] = make_float2(g.scale[2], g.color[0]);
+    reinterpret_cast<float2*>(a)[6] = make_float2(g.color[1], g.color[2]);
+    visible[idx] = vis ? 1u : 0u;
+}
+
 __global__ __launch_bounds__(256) void unpack_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer, float4* opt_pos,
                                                       float4* opt_rot, float4* opt_scale, float* opt_opacity, float* param_sh) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,6 +253,14 @@ int launch_accumulate_gradients(wdgs_device* dev, u32 n, const void* gradients, 
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "accumulate_gradients", accumulate_gradients_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gradients,
                 (const u32*)tile_counts, (float*)acc, (u32*)visible);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_store_gradients(wdgs_device* dev, u32 n, const void* gradients, const void* tile_counts, void* acc, void* visible) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "store_gradients", store_gradients_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gradients, (const u32*)tile_counts,
+                (float*)acc, (u32*)visible);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

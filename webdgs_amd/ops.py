@@ -575,6 +575,11 @@ def accumulateGradients(device: HipDevice, numPoints: int, gradientsBuffer: HipB
     check(device.lib.wdgs_accumulate_gradients(device.handle, int(numPoints), gradientsBuffer.ptr, tileCountsBuffer.ptr, accF32.ptr, visibleCounts.ptr))
 
 
+def storeGradients(device: HipDevice, numPoints: int, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer, accF32: HipBuffer, visibleCounts: HipBuffer) -> None:
+    """Overwrite form of ``accumulateGradients`` for the first view of a batch (no clearing pass needed before it)."""
+    check(device.lib.wdgs_store_gradients(device.handle, int(numPoints), gradientsBuffer.ptr, tileCountsBuffer.ptr, accF32.ptr, visibleCounts.ptr))
+
+
 # ----------------------------------------------------------------------------- DensifyPrunePass
 class DensifyPrunePass:
     """``DensifyPrunePass`` (``src/renderers/densify-prune.ts:75-687``), strategy ``gpu_rebuild``."""

@@ -312,11 +312,10 @@ class Trainer:
                     if record:  # allocation happened inside an open recording: restart it cleanly
                         encoder.finish().destroy()
                         encoder = self.device.createCommandEncoder("trainer-step", record=True)
-                encoder.clearBuffer(self._dp_grad)
-                encoder.clearBuffer(self._dp_visible)
-                for v in mine:
+                for k, v in enumerate(mine):  # the first view overwrites the fp32 block (no clearing pass), the others add to it
                     self._encode_view(encoder, v)
-                    ops.accumulateGradients(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts, self._dp_grad, self._dp_visible)
+                    (ops.storeGradients if k == 0 else ops.accumulateGradients)(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts,
+                                                                                self._dp_grad, self._dp_visible)
                 first = encoder.finish()
                 self.device.queue.submit([first])
                 self._allreduce()
