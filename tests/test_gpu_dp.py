@@ -53,3 +53,11 @@ def test_two_rank_training_equals_single_process_batch_of_two(hip_device, tmp_pa
     assert_bits_equal(t.pointCloud.sh_buffer.read(np.uint32), ranks[0]["sh"], "2 ranks x 1 view vs 1 rank x 2 views: sh")
     assert int(ranks[0]["iteration"][0]) == t.optimizer.getIteration() == steps
     assert not np.array_equal(ranks[0]["gaussians"], g.reshape(ranks[0]["gaussians"].shape)), "training did not move the parameters"
+
+
+def test_rccl_backend_through_the_trainer(tmp_path):
+    """The `nccl` backend itself (RCCL), which the multi-GPU bench uses, exercised through the Trainer on this one GPU with a
+    process group of size one (see tests/nccl_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "nccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
