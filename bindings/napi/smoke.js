@@ -3,7 +3,7 @@ const path = require('path');
 const addon = require(path.join(__dirname, 'webdgs_napi.node'));
 if (addon.abiVersion() !== 1) { console.error('bad ABI version'); process.exit(1); }
 const names = Object.keys(addon);
-if (names.length < 56) { console.error('missing exports', names); process.exit(1); }
+if (names.length < 57) { console.error('missing exports', names); process.exit(1); }
 if (process.argv[2] === 'gpu') {
   const dev = addon.deviceCreate(0);
   const n = 64, W = 64, H = 48;
@@ -54,6 +54,13 @@ if (process.argv[2] === 'gpu') {
   const dens = addon.densifyCreate(dev, { numViews: 1, cloneThreshold: 1, splitThreshold: 0.5, pruneThreshold: 0.01, maxNewPointsPerStep: 16 });
   const prep = addon.densifyEncodePrepare(dens, n, gb.ptr, addon.tiledBackwardGet(bwd, 1));
   const total = addon.densifyReadTotal(dens);
+  // the same through the staged encoders (encodeDecision / encodePrefixSum / encodeCapToMax / encodePrefixSum / encodeTotalOut)
+  const dens2 = addon.densifyCreate(dev, { numViews: 1, cloneThreshold: 1, splitThreshold: 0.5, pruneThreshold: 0.01, maxNewPointsPerStep: 16 });
+  const maxOut = addon.densifyStage(dens2, 4, n, 0, 0).maxOutPoints;
+  addon.densifyStage(dens2, 0, n, gb.ptr, addon.tiledBackwardGet(bwd, 1));
+  addon.densifyStage(dens2, 1, n, 0, 0); addon.densifyStage(dens2, 2, n, maxOut, 0); addon.densifyStage(dens2, 1, n, 0, 0); addon.densifyStage(dens2, 3, n, 0, 0);
+  if (addon.densifyReadTotal(dens2) !== total || maxOut !== prep.maxOutPoints) { console.error('staged densify differs from encodePrepare'); process.exit(1); }
+  addon.densifyDestroy(dens2);
   const state = addon.optimizerState(opt, 0);
   addon.queueOnSubmittedWorkDone(dev).then(() => {
     console.log(`napi gpu train: iteration=${addon.optimizerGetIteration(opt)} visible=${st.visibleCount} lr_pos=${hp.lr_pos.toFixed(4)} densify total=${total}/${prep.maxOutPoints} state=${typeof state.optPosBuffer}`);

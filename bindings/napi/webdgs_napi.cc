@@ -459,6 +459,29 @@ static napi_value densifyEncodePrepare(napi_env env, napi_callback_info info) { 
     set_prop(env, o, "maxOutPoints", make_u32(env, p.max_out_points));
     return o;
 }
+static napi_value densifyStage(napi_env env, napi_callback_info info) {
+    // (op, stage, numPoints, a, b): 0 encodeDecision(gaussiansPtr, metricCountsPtr) | 1 encodePrefixSum | 2 encodeCapToMax(maxOutPoints) |
+    //                               3 encodeTotalOut | 4 ensureSize;  returns the pass's work buffers (DensifyPrunePrepared shape)
+    ARGS(5);
+    wdgs_densify_prune* op = (wdgs_densify_prune*)get_ptr(env, argv[0]);
+    const uint32_t n = get_u32(env, argv[2]);
+    switch (get_u32(env, argv[1])) {
+        case 0: WDGS_OK_OR_THROW(wdgs_densify_prune_encode_decision(op, n, get_ptr(env, argv[3]), get_ptr(env, argv[4]))); break;
+        case 1: WDGS_OK_OR_THROW(wdgs_densify_prune_encode_prefix_sum(op, n)); break;
+        case 2: WDGS_OK_OR_THROW(wdgs_densify_prune_encode_cap_to_max(op, n, get_u32(env, argv[3]))); break;
+        case 3: WDGS_OK_OR_THROW(wdgs_densify_prune_encode_total_out(op, n)); break;
+        default: WDGS_OK_OR_THROW(wdgs_densify_prune_ensure_size(op, n)); break;
+    }
+    wdgs_densify_prepared p;
+    WDGS_OK_OR_THROW(wdgs_densify_prune_get_buffers(op, &p));
+    uint32_t max_out = 0;
+    WDGS_OK_OR_THROW(wdgs_densify_prune_compute_max_out_points(op, n, &max_out));
+    napi_value o; napi_create_object(env, &o);
+    set_prop(env, o, "actionBuffer", make_ptr(env, p.action_buffer)); set_prop(env, o, "outCountBuffer", make_ptr(env, p.out_count_buffer));
+    set_prop(env, o, "outOffsetBuffer", make_ptr(env, p.out_offset_buffer)); set_prop(env, o, "outTotalBuffer", make_ptr(env, p.out_total_buffer));
+    set_prop(env, o, "maxOutPoints", make_u32(env, max_out));
+    return o;
+}
 static napi_value densifyReadTotal(napi_env env, napi_callback_info info) {
     ARGS(1);
     uint32_t t = 0;
@@ -524,6 +547,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(optimizerStateSizes); EXPORT_FN(optimizerCreateWithState); EXPORT_FN(optimizerState); EXPORT_FN(optimizerHyperparameters);
     EXPORT_FN(optimizerAdvanceIteration); EXPORT_FN(optimizerStepF32); EXPORT_FN(accumulateGradients);
     EXPORT_FN(densifyCreate); EXPORT_FN(densifySetConfig); EXPORT_FN(densifyEncodePrepare); EXPORT_FN(densifyReadTotal); EXPORT_FN(densifyEncodeScatter);
+    EXPORT_FN(densifyStage);
     EXPORT_FN(densifyDestroy);
     EXPORT_FN(commUniqueId); EXPORT_FN(commCreate); EXPORT_FN(commAllreduceGradients); EXPORT_FN(commAllreduceCounts); EXPORT_FN(commDestroy);
     return exports;

@@ -228,6 +228,23 @@ export class DensifyPrunePass {          // densify-prune.ts:75
     return { actionBuffer: d.view(p.actionBuffer, 4 * n), outCountBuffer: d.view(p.outCountBuffer, 4 * n), outOffsetBuffer: d.view(p.outOffsetBuffer, 4 * n),
       outTotalBuffer: d.view(p.outTotalBuffer, 4), maxOutPoints: p.maxOutPoints };
   }
+  // ---- the stages encodePrepare is made of (densify-prune.ts:327-456), individually recordable as in the reference
+  private numPoints = 0;
+  private stage(stage: number, n: number, a: unknown = 0, b: unknown = 0): DensifyPrunePrepared {
+    const p = addon.densifyStage(this.handle, stage, n, a, b); const d = this.device; const m = Math.max(1, n);
+    return { actionBuffer: d.view(p.actionBuffer, 4 * m), outCountBuffer: d.view(p.outCountBuffer, 4 * m), outOffsetBuffer: d.view(p.outOffsetBuffer, 4 * m),
+      outTotalBuffer: d.view(p.outTotalBuffer, 4), maxOutPoints: p.maxOutPoints };
+  }
+  ensureSize(numPoints: number): void { this.numPoints = numPoints; this.stage(4, numPoints); }
+  computeMaxOutPoints(pointCloud: PointCloud): number { return this.stage(4, pointCloud.num_points).maxOutPoints; }
+  encodeDecision(_encoder: HipEncoder, inputs: { pointCloud: PointCloud; metricCountsBuffer?: HipBuffer }): { actionBuffer: HipBuffer; outCountBuffer: HipBuffer } {
+    this.numPoints = inputs.pointCloud.num_points;
+    const p = this.stage(0, this.numPoints, inputs.pointCloud.gaussian_3d_buffer.ptr, inputs.metricCountsBuffer?.ptr ?? null);
+    return { actionBuffer: p.actionBuffer, outCountBuffer: p.outCountBuffer };
+  }
+  encodePrefixSum(_encoder: HipEncoder): HipBuffer { return this.stage(1, this.numPoints).outOffsetBuffer; }
+  encodeCapToMax(_encoder: HipEncoder, _outOffsetBuffer: HipBuffer, maxOutPoints: number): void { this.stage(2, this.numPoints, Math.max(0, Math.floor(maxOutPoints))); }
+  encodeTotalOut(_encoder: HipEncoder, _outOffsetBuffer?: HipBuffer): HipBuffer { return this.stage(3, this.numPoints).outTotalBuffer; }
   /** The one 4-byte read-back of the densify path (trainer.ts:440-458, mapAsync on outTotalBuffer). */
   readTotal(): number { return addon.densifyReadTotal(this.handle); }
   encodeScatter(_encoder: HipEncoder,
