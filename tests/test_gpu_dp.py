@@ -20,6 +20,18 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _run_with_fresh_port(make_cmd_env, timeout=600):
+    """Launches a rendezvous-based child; a failed rendezvous (port taken between probing and binding) is retried once on another
+    port.  A child that ran and reported a mismatch is never retried."""
+    last = None
+    for _ in range(2):
+        cmd, env = make_cmd_env(_free_port())
+        last = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        if last.returncode == 0 or "MISMATCH" in last.stdout or "AssertionError" in last.stderr:
+            break
+    return last
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -32,9 +44,8 @@ def _free_port():
 def test_two_rank_training_equals_single_process_batch_of_two(hip_device, tmp_path, use_cb):
     steps = 7
     env = dict(os.environ, WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(HERE, "dp_worker.py"), str(tmp_path), str(steps), "1" if use_cb else "0"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), str(steps), "1" if use_cb else "0"], env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
     assert_bits_equal(ranks[0]["gaussians"], ranks[1]["gaussians"], "replica gaussians")
@@ -58,6 +69,6 @@ def test_two_rank_training_equals_single_process_batch_of_two(hip_device, tmp_pa
 def test_rccl_backend_through_the_trainer(tmp_path):
     """The `nccl` backend itself (RCCL), which the multi-GPU bench uses, exercised through the Trainer on this one GPU with a
     process group of size one (see tests/nccl_worker.py)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(HERE, "nccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    r = _run_with_fresh_port(lambda port: ([sys.executable, os.path.join(HERE, "nccl_worker.py")],
+                                           dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))))
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -470,8 +470,12 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     // clearBuffer(pipelineStatsBuffer) (tiled-forward-pass.ts:345) needs no launch here: update_stats overwrites words 0..2, word 3
     // stays 0, and the visible count is accumulated in shard words that update_stats clears after folding them.
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4));
-    WDGS_TRY(scan_exclusive_u32(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr));
-    WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4, op->host_stats));
+    if (n > 0) {  // the scan's single-block middle kernel publishes the stats block (update_stats, K5) as its epilogue
+        WDGS_TRY(scan_exclusive_u32_stats(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr,
+                                          ScanStatsEpilogue{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries}));
+    } else {
+        WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4, op->host_stats));
+    }
     WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->settings, op->tile_info, wdgs_sorter_keys(op->sorter, 0),
                          wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
     if (!skip_sort) {

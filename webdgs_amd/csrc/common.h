@@ -93,6 +93,9 @@ int scan_scratch_create(ScanScratch* s, u32 max_elements);
 void scan_scratch_destroy(ScanScratch* s);
 // Exclusive u32 scan of `count` (host-known) elements.  If total_out != nullptr, writes the grand total there.
 int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out);
+// Same, with the forward pass's stats epilogue folded into the single-block middle kernel (count must be > 0 for it to run).
+struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u32 capacity; };
+int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep);
 
 struct RenderSettings { float gaussian_scaling, sh_deg, viewport_x, viewport_y, point_size_px, gaussian_mode, max_splat_radius_px; };
 struct TileInfo { u32 num_tiles_x, num_tiles_y, total_tiles, max_tile_entries; };

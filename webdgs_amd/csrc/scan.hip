@@ -65,7 +65,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const u32* __
 }
 
 // One block scans the block sums in place (exclusive), 256 at a time with a running carry.
-__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ total_out) {
+// The optional epilogue is the reference's update_stats (src/shaders/update-stats.wgsl:19-35) for the tile-count scan of the
+// forward pass: the grand total IS the number of tile entries, so the same single-block kernel publishes the stats block
+// {entries (clamped to the capacity), visible splats (folded from the shard words, which it clears), overflow} and mirrors it
+// into pinned host memory -- one launch less between the projection and the emit.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ total_out,
+                                                                       ScanStatsEpilogue ep) {
     __shared__ u32 lds[4];
     u32 carry = 0;
     for (u32 base = 0; base < num_blocks; base += SCAN_THREADS) {
@@ -77,6 +82,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __re
         carry += total;
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;
+    if (ep.stats) {
+        u32 vis = 0u;
+        if (threadIdx.x < 64u) {  // wave 0 folds the 64 visible-count shards
+            vis = ep.visible_shards[threadIdx.x];
+            ep.visible_shards[threadIdx.x] = 0u;
+#pragma unroll
+            for (u32 d = 32; d >= 1; d >>= 1) vis += (u32)__shfl_xor((int)vis, (int)d, 64);
+        }
+        if (threadIdx.x == 0) {
+            const u32 entries = min(carry, ep.capacity), overflow = (carry > ep.capacity) ? carry : 0u;  // consumers only touch [0, capacity)
+            ep.stats[0] = entries; ep.stats[1] = vis; ep.stats[2] = overflow;
+            if (ep.host_mirror) { ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u; }
+        }
+    }
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const u32* __restrict__ in, u32* __restrict__ out, u32 count,
@@ -119,6 +138,10 @@ void scan_scratch_destroy(ScanScratch* s) {
 }
 
 int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out) {
+    return scan_exclusive_u32_stats(dev, s, in, out, count, total_out, ScanStatsEpilogue{nullptr, nullptr, nullptr, 0u});
+}
+
+int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep) {
     if (count == 0) {
         if (total_out) WDGS_CHECK_HIP(hipMemsetAsync(total_out, 0, 4, dev->stream));
         return WDGS_OK;
@@ -126,7 +149,7 @@ int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out
     const u32 blocks = ceil_div(count, SCAN_TILE);
     WDGS_REQUIRE(blocks <= s->capacity_blocks, WDGS_E_CAPACITY, "scan: %u elements exceed the scanner's capacity (%u blocks)", count, s->capacity_blocks);
     WDGS_LAUNCH(dev, "scan_reduce", scan_reduce_kernel, dim3(blocks), dim3(SCAN_THREADS), 0, in, count, s->block_sums);
-    WDGS_LAUNCH(dev, "scan_block_sums", scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s->block_sums, blocks, total_out);
+    WDGS_LAUNCH(dev, "scan_block_sums", scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s->block_sums, blocks, total_out, ep);
     WDGS_LAUNCH(dev, "scan_downsweep", scan_downsweep_kernel, dim3(blocks), dim3(SCAN_THREADS), 0, in, out, count, s->block_sums);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
