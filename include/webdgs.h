@@ -17,7 +17,10 @@
  *   - sizes that the reference derives on the GPU (total tile entries) stay on the GPU: no host read-back
  *     inside a step.  Capacity overflow is a hard error reported by *_check / wdgs_device_synchronize
  *     (the reference silently overruns: SURVEY Q1, Q2);
- *   - handles are not thread-safe; use one host thread per wdgs_device.
+ *   - handles are not thread-safe; use one host thread per wdgs_device;
+ *   - teardown order: destroy command buffers and ops, then wdgs_comm, then the device.  An op destroyed AFTER its device
+ *     (a host finalising objects in arbitrary order at exit) only releases its memory and never touches the dead device;
+ *     wdgs_device_destroy is idempotent.
  *
  * Data layouts (byte-exact with the reference unless marked INTERNAL):
  *   Gaussian        6 x u32 = 12 fp16: x y z opacity_raw | rot w x y z | log-sigma x y z, pad   shaders/common.wgsl:20-24
@@ -88,6 +91,10 @@ int wdgs_device_reset_kernel_times(wdgs_device* dev);
  * recording: run one eager step first.  Per-kernel profiling is suspended inside a recording. */
 int wdgs_encoder_begin(wdgs_device* dev);
 int wdgs_encoder_finish(wdgs_device* dev, wdgs_command_buffer** out);
+/* Drops an open recording (an encode between begin and finish failed, or the host threw): ends the capture, discards the partial
+ * graph and returns the device to eager mode.  A no-op when nothing is being recorded, so error paths may call it unconditionally.
+ * The reference has no counterpart: an encoder that is never finished is simply garbage-collected. */
+int wdgs_encoder_abort(wdgs_device* dev);
 int wdgs_queue_submit(wdgs_device* dev, wdgs_command_buffer* cmd);
 int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd);
 /* queue.onSubmittedWorkDone() as a completion callback (trainer.ts:639-645): `fn(user)` runs on a runtime thread once everything

@@ -166,9 +166,41 @@ def adam(cfg, tile_counts, grads, st):
                    _p(st["opt_opacity"]), _p(st["param_sh"]), _p(st["state_sh"]))
 
 
+def adam_f32(cfg, visible_counts, grad_f32, st):
+    """The view-batched Adam this repo adds: fp32 gradient sums [N,14] + u32 visibility counts."""
+    n = visible_counts.shape[0]
+    lib().orc_adam_f32(_u32(n), _p(cfg), _p(visible_counts), _p(grad_f32), _p(st["opt_pos"]), _p(st["opt_rot"]), _p(st["opt_scale"]),
+                       _p(st["opt_opacity"]), _p(st["param_sh"]), _p(st["state_sh"]))
+
+
+def set_literal_order(on: bool) -> None:
+    """Evaluate q / power / C += c*alpha*vis as the WGSL source is parenthesised (no FMA) instead of the pinned FMA order."""
+    lib().orc_set_literal_order(ctypes.c_int(1 if on else 0))
+
+
+def unpack_gradients_f32(grads):
+    """GaussianGradient[N] (8 u32 of fp16 pairs) -> f32[N,14] in component order pos3, opacity, rot4, log-sigma3, rgb3 (exact)."""
+    h = np.ascontiguousarray(grads).view(np.float16).reshape(-1, 16).astype(np.float32)
+    return np.ascontiguousarray(h[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14]])
+
+
 def repack(st, gaussians, sh):
     n = gaussians.shape[0]
     lib().orc_repack(_u32(n), _p(st["opt_pos"]), _p(st["opt_rot"]), _p(st["opt_scale"]), _p(st["opt_opacity"]), _p(st["param_sh"]), _p(gaussians), _p(sh))
+
+
+def view_gradients(gaussians, sh, camera, settings, tinfo, target_rgba8, tcfg=None, max_batches=0):
+    """K1..K17 of one view (trainer.ts:606-628): every forward stage plus the packed GaussianGradients; nothing is updated."""
+    tcfg = training_config() if tcfg is None else tcfg
+    fw = forward(gaussians, sh, camera, settings, tinfo, max_batches=max_batches)
+    lg = loss_grad(fw["rgba8"], target_rgba8, tcfg)
+    bsettings = settings.copy()
+    bsettings[5] = 0.0
+    n = gaussians.shape[0]
+    gm, gc, go, gcol = backward_rasterize(bsettings, n, fw["tile_ranges"], fw["sorted_values"], fw["splats"], fw["final_T"], fw["n_contrib"], lg)
+    grads = geometry_backward(camera, bsettings, gaussians, gm, gc, go, gcol)
+    fw.update(loss_grad=lg, grad_means=gm, grad_conics=gc, grad_opacity=go, grad_colors=gcol, gradients=grads)
+    return fw
 
 
 def train_step(gaussians, sh, st, camera, settings, tinfo, target_rgba8, tcfg=None, acfg=None, max_batches=0):

@@ -122,17 +122,32 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
     const u32 BLOCK_SIZE = 16u;
     const u32 num_tiles_x = (width + BLOCK_SIZE - 1u) / BLOCK_SIZE;
     const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
-#pragma omp parallel for schedule(dynamic, 8)
-    for (u32 py = 0; py < height; py++) {
-        for (u32 px = 0; px < width; px++) {
-            const u32 tile_x = px / 16u, tile_y = py / 16u;
-            const u32 tile_idx = tile_y * num_tiles_x + tile_x;
-            const u32 range_start = tile_offsets[tile_idx];
-            const u32 range_end = tile_offsets[tile_idx + 1];
+    // The reference runs one invocation per pixel and adds every contribution to the global accumulators with atomicAdd.  Integer
+    // addition is associative and commutative (wrapping), so the sums do not depend on the order or grouping of the adds: here the
+    // pixels of one 16x16 tile (one workgroup of the reference) first add into a tile-local table indexed by the entry's position
+    // in the tile list (no atomics, thread-private), and the table is added to the global arrays once per (tile, entry).  The
+    // per-pixel body is the reference's, statement for statement.
+    const u32 num_tiles_y = (height + BLOCK_SIZE - 1u) / BLOCK_SIZE;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (u32 tile_idx = 0; tile_idx < num_tiles_x * num_tiles_y; tile_idx++) {
+        const u32 tile_x = tile_idx % num_tiles_x, tile_y = tile_idx / num_tiles_x;
+        const u32 range_start = tile_offsets[tile_idx];
+        const u32 range_end = tile_offsets[tile_idx + 1];
+        const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
+        u32 max_n = 0u;
+        for (u32 ly = 0; ly < 16u; ly++)
+            for (u32 lx = 0; lx < 16u; lx++) {
+                const u32 px = tile_x * 16u + lx, py = tile_y * 16u + ly;
+                if (px < width && py < height) max_n = std::max(max_n, std::min(n_contrib_tex[(size_t)py * width + px], tile_entries));
+            }
+        if (max_n == 0u) continue;
+        std::vector<u32> local((size_t)max_n * 9u, 0u);  // per entry: mean.x, mean.y, conic.x, conic.y, conic.z, opacity, r, g, b
+        for (u32 lpix = 0; lpix < 256u; lpix++) {
+            const u32 px = tile_x * 16u + (lpix & 15u), py = tile_y * 16u + (lpix >> 4);
+            if (px >= width || py >= height) continue;
             const size_t p = (size_t)py * width + px;
             const u32 n_contrib_val = n_contrib_tex[p];
             if (n_contrib_val == 0u) continue;
-            const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
             const u32 pix_n_contrib = std::min(n_contrib_val, tile_entries);
             f32 T = final_Ts[p];
             const f32* dL_dpixel = loss_gradient + p * 4;
@@ -142,6 +157,7 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
             for (u32 i = pix_n_contrib; i > 0u; i--) {
                 const u32 idx_in_tile = i - 1u;
                 const u32 g = tile_instances[range_start + idx_in_tile];
+                u32* const L = &local[(size_t)idx_in_tile * 9u];
                 const u32* s = splats + (size_t)g * 6;
                 const vec2 pos_ndc = unpack2x16float(s[0]);
                 const vec2 conic_xy = unpack2x16float(s[2]);
@@ -157,8 +173,13 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
                 const vec2 extents = min(extents_raw, V2(cap));
                 const vec2 delta = pixf - center_px;
                 if (std::fabs(delta.x) > extents.x || std::fabs(delta.y) > extents.y) continue;
-                const f32 t1 = std::fmaf(conic.x, delta.x, (2.0f * conic.y) * delta.y);
-                const f32 power = std::fmaf(t1, delta.x, (conic.z * delta.y) * delta.y);
+                f32 power;
+                if (g_literal_order) {
+                    power = (conic.x * delta.x * delta.x) + (2.0f * conic.y * delta.x * delta.y) + (conic.z * delta.y * delta.y);
+                } else {
+                    const f32 t1 = std::fmaf(conic.x, delta.x, (2.0f * conic.y) * delta.y);
+                    power = std::fmaf(t1, delta.x, (conic.z * delta.y) * delta.y);
+                }
                 const f32 G = wd_exp(-0.5f * power);
                 const f32 alpha = wmin(0.99f, opacity * G);
                 if (alpha < 1.0f / 255.0f) continue;
@@ -169,7 +190,7 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
                     const f32 grad_pix = dL_dpixel[ch];
                     const f32 dchannel_dcolor = alpha * T;
                     const f32 dL_dc = dchannel_dcolor * grad_pix;
-                    acc_add(&grad_colors[(size_t)g * 3u + ch], to_fixed(dL_dc));
+                    L[6u + ch] += (u32)to_fixed(dL_dc);
                     dL_dalpha += (color[ch] - accum_rec[ch]) * grad_pix;
                 }
                 dL_dalpha *= T;
@@ -186,13 +207,25 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
                 const f32 dL_dconic_x = dL_dG * (-0.5f * G * delta.x * delta.x);
                 const f32 dL_dconic_y = dL_dG * (-0.5f * G * 2.0f * delta.x * delta.y);
                 const f32 dL_dconic_z = dL_dG * (-0.5f * G * delta.y * delta.y);
-                acc_add(&grad_opacity[g], to_fixed(dL_dopacity));
-                acc_add(&grad_means_2d[(size_t)g * 2u + 0u], to_fixed(dL_dmean_x));
-                acc_add(&grad_means_2d[(size_t)g * 2u + 1u], to_fixed(dL_dmean_y));
-                acc_add(&grad_conics[(size_t)g * 4u + 0u], to_fixed(dL_dconic_x));
-                acc_add(&grad_conics[(size_t)g * 4u + 1u], to_fixed(dL_dconic_y));
-                acc_add(&grad_conics[(size_t)g * 4u + 3u], to_fixed(dL_dconic_z));
+                L[5] += (u32)to_fixed(dL_dopacity);
+                L[0] += (u32)to_fixed(dL_dmean_x);
+                L[1] += (u32)to_fixed(dL_dmean_y);
+                L[2] += (u32)to_fixed(dL_dconic_x);
+                L[3] += (u32)to_fixed(dL_dconic_y);
+                L[4] += (u32)to_fixed(dL_dconic_z);
             }
+        }
+        for (u32 e = 0; e < max_n; e++) {
+            const u32* L = &local[(size_t)e * 9u];
+            const u32 g = tile_instances[range_start + e];
+            if (L[0]) acc_add(&grad_means_2d[(size_t)g * 2u + 0u], (i32)L[0]);
+            if (L[1]) acc_add(&grad_means_2d[(size_t)g * 2u + 1u], (i32)L[1]);
+            if (L[2]) acc_add(&grad_conics[(size_t)g * 4u + 0u], (i32)L[2]);
+            if (L[3]) acc_add(&grad_conics[(size_t)g * 4u + 1u], (i32)L[3]);
+            if (L[4]) acc_add(&grad_conics[(size_t)g * 4u + 3u], (i32)L[4]);
+            if (L[5]) acc_add(&grad_opacity[g], (i32)L[5]);
+            for (u32 ch = 0; ch < 3u; ch++)
+                if (L[6u + ch]) acc_add(&grad_colors[(size_t)g * 3u + ch], (i32)L[6u + ch]);
         }
     }
 }
@@ -379,63 +412,81 @@ static inline vec3 adam_step(const f32* cfg, f32 param, f32 grad, f32 m, f32 v, 
 // (adam.wgsl:6-16; `iteration` is uploaded but never read).
 // State layouts (optimizer.ts:7-11): opt_pos/rot/scale = OptVec4{param,m,v : vec4f} = 12 f32 each;
 // opt_opacity = OptFloat{param,m,v} = 3 f32; param_sh 48 f32; state_sh 48 x (m,v).
+// The body of adam.wgsl:78-174 for one Gaussian, with its 14 gradient scalars already unpacked to f32.
+static inline void adam_one(u32 idx, const f32* cfg, vec3 grad_pos, f32 grad_opac, vec4 grad_rot, vec3 grad_scale, vec3 grad_color, f32* opt_pos,
+                            f32* opt_rot, f32* opt_scale, f32* opt_opacity, f32* param_sh, f32* state_sh) {
+    const f32 lr_pos = cfg[0], lr_color = cfg[1], lr_opacity = cfg[2], lr_scale = cfg[3], lr_rot = cfg[4];
+    {
+        f32* P = opt_pos + (size_t)idx * 12;
+        const vec3 rx = adam_step(cfg, P[0], grad_pos.x, P[4], P[8], lr_pos);
+        const vec3 ry = adam_step(cfg, P[1], grad_pos.y, P[5], P[9], lr_pos);
+        const vec3 rz = adam_step(cfg, P[2], grad_pos.z, P[6], P[10], lr_pos);
+        P[0] = rx.x; P[1] = ry.x; P[2] = rz.x; P[3] = 1.0f;
+        P[4] = rx.y; P[5] = ry.y; P[6] = rz.y; P[7] = 0.0f;
+        P[8] = rx.z; P[9] = ry.z; P[10] = rz.z; P[11] = 0.0f;
+    }
+    {
+        f32* P = opt_rot + (size_t)idx * 12;
+        const vec3 rx = adam_step(cfg, P[0], grad_rot.x, P[4], P[8], lr_rot);
+        const vec3 ry = adam_step(cfg, P[1], grad_rot.y, P[5], P[9], lr_rot);
+        const vec3 rz = adam_step(cfg, P[2], grad_rot.z, P[6], P[10], lr_rot);
+        const vec3 rw = adam_step(cfg, P[3], grad_rot.w, P[7], P[11], lr_rot);
+        const vec4 new_rot = normalize(V4(rx.x, ry.x, rz.x, rw.x));
+        P[0] = new_rot.x; P[1] = new_rot.y; P[2] = new_rot.z; P[3] = new_rot.w;
+        P[4] = rx.y; P[5] = ry.y; P[6] = rz.y; P[7] = rw.y;
+        P[8] = rx.z; P[9] = ry.z; P[10] = rz.z; P[11] = rw.z;
+    }
+    {
+        f32* P = opt_scale + (size_t)idx * 12;
+        const vec3 rx = adam_step(cfg, P[0], grad_scale.x, P[4], P[8], lr_scale);
+        const vec3 ry = adam_step(cfg, P[1], grad_scale.y, P[5], P[9], lr_scale);
+        const vec3 rz = adam_step(cfg, P[2], grad_scale.z, P[6], P[10], lr_scale);
+        P[0] = rx.x; P[1] = ry.x; P[2] = rz.x; P[3] = 0.0f;
+        P[4] = rx.y; P[5] = ry.y; P[6] = rz.y; P[7] = 0.0f;
+        P[8] = rx.z; P[9] = ry.z; P[10] = rz.z; P[11] = 0.0f;
+    }
+    {
+        f32* P = opt_opacity + (size_t)idx * 3;
+        const vec3 res = adam_step(cfg, P[0], grad_opac, P[1], P[2], lr_opacity);
+        P[0] = res.x; P[1] = res.y; P[2] = res.z;
+    }
+    for (u32 c = 0; c < 3u; c++) {
+        const size_t sh_idx = (size_t)idx * 48u + c;
+        const vec3 res = adam_step(cfg, param_sh[sh_idx], grad_color[c], state_sh[sh_idx * 2], state_sh[sh_idx * 2 + 1], lr_color);
+        param_sh[sh_idx] = res.x;
+        state_sh[sh_idx * 2] = res.y;
+        state_sh[sh_idx * 2 + 1] = res.z;
+    }
+}
+
 void orc_adam(u32 n, const f32* cfg, const u32* tile_counts, const u32* gradients, f32* opt_pos, f32* opt_rot, f32* opt_scale,
               f32* opt_opacity, f32* param_sh, f32* state_sh) {
-    const f32 lr_pos = cfg[0], lr_color = cfg[1], lr_opacity = cfg[2], lr_scale = cfg[3], lr_rot = cfg[4];
 #pragma omp parallel for schedule(static)
     for (u32 idx = 0; idx < n; idx++) {
         if (tile_counts[idx] == 0u) continue;
         const u32* gp = gradients + (size_t)idx * 8;
         const vec2 g_pos_xy = unpack2x16float(gp[0]), g_pos_z_op = unpack2x16float(gp[1]);
-        const vec3 grad_pos = V3(g_pos_xy.x, g_pos_xy.y, g_pos_z_op.x);
-        const f32 grad_opac = g_pos_z_op.y;
         const vec2 g_rot_xy = unpack2x16float(gp[2]), g_rot_zw = unpack2x16float(gp[3]);
-        const vec4 grad_rot = V4(g_rot_xy.x, g_rot_xy.y, g_rot_zw.x, g_rot_zw.y);
         const vec2 g_scale_xy = unpack2x16float(gp[4]), g_scale_z_ = unpack2x16float(gp[5]);
-        const vec3 grad_scale = V3(g_scale_xy.x, g_scale_xy.y, g_scale_z_.x);
         const vec2 g_col_rg = unpack2x16float(gp[6]), g_col_b_ = unpack2x16float(gp[7]);
-        const vec3 grad_color = V3(g_col_rg.x, g_col_rg.y, g_col_b_.x);
-        {
-            f32* P = opt_pos + (size_t)idx * 12;
-            const vec3 rx = adam_step(cfg, P[0], grad_pos.x, P[4], P[8], lr_pos);
-            const vec3 ry = adam_step(cfg, P[1], grad_pos.y, P[5], P[9], lr_pos);
-            const vec3 rz = adam_step(cfg, P[2], grad_pos.z, P[6], P[10], lr_pos);
-            P[0] = rx.x; P[1] = ry.x; P[2] = rz.x; P[3] = 1.0f;
-            P[4] = rx.y; P[5] = ry.y; P[6] = rz.y; P[7] = 0.0f;
-            P[8] = rx.z; P[9] = ry.z; P[10] = rz.z; P[11] = 0.0f;
-        }
-        {
-            f32* P = opt_rot + (size_t)idx * 12;
-            const vec3 rx = adam_step(cfg, P[0], grad_rot.x, P[4], P[8], lr_rot);
-            const vec3 ry = adam_step(cfg, P[1], grad_rot.y, P[5], P[9], lr_rot);
-            const vec3 rz = adam_step(cfg, P[2], grad_rot.z, P[6], P[10], lr_rot);
-            const vec3 rw = adam_step(cfg, P[3], grad_rot.w, P[7], P[11], lr_rot);
-            const vec4 new_rot = normalize(V4(rx.x, ry.x, rz.x, rw.x));
-            P[0] = new_rot.x; P[1] = new_rot.y; P[2] = new_rot.z; P[3] = new_rot.w;
-            P[4] = rx.y; P[5] = ry.y; P[6] = rz.y; P[7] = rw.y;
-            P[8] = rx.z; P[9] = ry.z; P[10] = rz.z; P[11] = rw.z;
-        }
-        {
-            f32* P = opt_scale + (size_t)idx * 12;
-            const vec3 rx = adam_step(cfg, P[0], grad_scale.x, P[4], P[8], lr_scale);
-            const vec3 ry = adam_step(cfg, P[1], grad_scale.y, P[5], P[9], lr_scale);
-            const vec3 rz = adam_step(cfg, P[2], grad_scale.z, P[6], P[10], lr_scale);
-            P[0] = rx.x; P[1] = ry.x; P[2] = rz.x; P[3] = 0.0f;
-            P[4] = rx.y; P[5] = ry.y; P[6] = rz.y; P[7] = 0.0f;
-            P[8] = rx.z; P[9] = ry.z; P[10] = rz.z; P[11] = 0.0f;
-        }
-        {
-            f32* P = opt_opacity + (size_t)idx * 3;
-            const vec3 res = adam_step(cfg, P[0], grad_opac, P[1], P[2], lr_opacity);
-            P[0] = res.x; P[1] = res.y; P[2] = res.z;
-        }
-        for (u32 c = 0; c < 3u; c++) {
-            const size_t sh_idx = (size_t)idx * 48u + c;
-            const vec3 res = adam_step(cfg, param_sh[sh_idx], grad_color[c], state_sh[sh_idx * 2], state_sh[sh_idx * 2 + 1], lr_color);
-            param_sh[sh_idx] = res.x;
-            state_sh[sh_idx * 2] = res.y;
-            state_sh[sh_idx * 2 + 1] = res.z;
-        }
+        adam_one(idx, cfg, V3(g_pos_xy.x, g_pos_xy.y, g_pos_z_op.x), g_pos_z_op.y, V4(g_rot_xy.x, g_rot_xy.y, g_rot_zw.x, g_rot_zw.y),
+                 V3(g_scale_xy.x, g_scale_xy.y, g_scale_z_.x), V3(g_col_rg.x, g_col_rg.y, g_col_b_.x), opt_pos, opt_rot, opt_scale, opt_opacity, param_sh,
+                 state_sh);
+    }
+}
+
+// The view-batched step this repo adds on top of the reference (no counterpart there: trainer.ts:573 trains one view per step):
+// the same Adam, fed the fp32 SUM over the batch's views of the per-view GaussianGradients (14 scalars per Gaussian in
+// GaussianGradient component order: pos3, opacity, rot4, log-sigma3, rgb3) and run where the Gaussian touched a tile in at least
+// one view.  With one view it is orc_adam (fp16 -> f32 unpacking is exact).
+void orc_adam_f32(u32 n, const f32* cfg, const u32* visible_counts, const f32* grad_f32, f32* opt_pos, f32* opt_rot, f32* opt_scale,
+                  f32* opt_opacity, f32* param_sh, f32* state_sh) {
+#pragma omp parallel for schedule(static)
+    for (u32 idx = 0; idx < n; idx++) {
+        if (visible_counts[idx] == 0u) continue;
+        const f32* g = grad_f32 + (size_t)idx * 14;
+        adam_one(idx, cfg, V3(g[0], g[1], g[2]), g[3], V4(g[4], g[5], g[6], g[7]), V3(g[8], g[9], g[10]), V3(g[11], g[12], g[13]), opt_pos, opt_rot,
+                 opt_scale, opt_opacity, param_sh, state_sh);
     }
 }
 

@@ -402,16 +402,26 @@ void orc_rasterize(const f32* settings_f, const u32* tile_info, const u32* splat
                         continue;
                     }
                     if (accum_alpha > 0.99f) continue;
-                    const f32 t1 = std::fmaf(sp.conic.x, delta.x, (2.0f * sp.conic.y) * delta.y);
-                    const f32 exp_q = std::fmaf(t1, delta.x, (sp.conic.z * delta.y) * delta.y);
+                    f32 exp_q;
+                    if (g_literal_order) {
+                        exp_q = (sp.conic.x * delta.x * delta.x) + (2.0f * sp.conic.y * delta.x * delta.y) + (sp.conic.z * delta.y * delta.y);
+                    } else {
+                        const f32 t1 = std::fmaf(sp.conic.x, delta.x, (2.0f * sp.conic.y) * delta.y);
+                        exp_q = std::fmaf(t1, delta.x, (sp.conic.z * delta.y) * delta.y);
+                    }
                     const f32 gaussian_weight = wd_exp(-0.5f * exp_q);
                     const f32 alpha = clamp(gaussian_weight * sp.opacity, 0.0f, 0.99f);
                     const f32 vis = 1.0f - accum_alpha;
-                    const f32 w = alpha * vis;
-                    accum_color.x = std::fmaf(sp.color.x, w, accum_color.x);
-                    accum_color.y = std::fmaf(sp.color.y, w, accum_color.y);
-                    accum_color.z = std::fmaf(sp.color.z, w, accum_color.z);
-                    accum_alpha = accum_alpha + w;
+                    if (g_literal_order) {
+                        accum_color = accum_color + sp.color * alpha * vis;  // (color * alpha) * vis, then the add
+                        accum_alpha = accum_alpha + alpha * vis;
+                    } else {
+                        const f32 w = alpha * vis;
+                        accum_color.x = std::fmaf(sp.color.x, w, accum_color.x);
+                        accum_color.y = std::fmaf(sp.color.y, w, accum_color.y);
+                        accum_color.z = std::fmaf(sp.color.z, w, accum_color.z);
+                        accum_alpha = accum_alpha + w;
+                    }
                     if (alpha >= (1.0f / 255.0f)) last_contributor = processed_in_tile;
                 }
                 const size_t p = (size_t)pixel_y * W + pixel_x;
@@ -427,6 +437,10 @@ void orc_rasterize(const f32* settings_f, const u32* tile_info, const u32* splat
 }
 
 }  // extern "C"
+
+namespace wgsl { int g_literal_order = 0; }
+extern "C" void orc_set_literal_order(int on) { wgsl::g_literal_order = on ? 1 : 0; }
+extern "C" int orc_get_literal_order() { return wgsl::g_literal_order; }
 
 // ---- test hooks for tests/test_oracle_math.py (dmath accuracy vs libm, fp16 conversions vs numpy)
 extern "C" {

@@ -91,6 +91,11 @@ static inline f32 wd_log(f32 x) {
     return r;
 }
 
+// Evaluation-order switch for the three expressions whose contraction the oracle pins (raster q / power, C += c*alpha*vis):
+// 0 (default) = the pinned FMA order the HIP kernels reproduce bit for bit; 1 = the WGSL source read literally, left to right, one
+// rounding per operator, no FMA (tiled-rasterizer.wgsl:228-238, tiled-backward-rasterize.wgsl:108-110).  Both are legal WGSL
+// evaluations; tests/test_oracle_tolerance.py measures how far apart their results are (the "stated fp32 tolerance").
+extern int g_literal_order;
 static inline f32 wd_sqrt(f32 x) { return std::sqrt(x); }          // correctly rounded
 static inline f32 wd_inverseSqrt(f32 x) { return 1.0f / std::sqrt(x); }
 

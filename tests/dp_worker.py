@@ -33,6 +33,9 @@ def main():
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gaussians=t.pointCloud.gaussian_3d_buffer.read(np.uint32),
              sh=t.pointCloud.sh_buffer.read(np.uint32), iteration=np.array([t.optimizer.getIteration()]))
     parallel.barrier()
+    t.destroy()
+    dev.destroy()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -42,7 +42,9 @@ def run(dev, data, exchange):
     for ids in dp_common.view_schedule(7, 2):
         t.step(ids)
     dev.synchronize()
-    return t.pointCloud.gaussian_3d_buffer.read(np.uint32).copy()
+    out = t.pointCloud.gaussian_3d_buffer.read(np.uint32).copy()
+    t.destroy()  # command buffers (HIP graphs) and ops go before the device and the process group
+    return out
 
 
 def main():
@@ -57,6 +59,10 @@ def main():
     plain = run(dev, data, False)
     ok = bool(np.array_equal(with_rccl, plain)) and float(tt.item()) == 1.25
     dist.barrier()
+    # deterministic teardown: dataset buffers, the library device (drains the stream), then the process group, then exit
+    del data, tt
+    dev.destroy()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
     print("RCCL_PATH_OK" if ok else "RCCL_PATH_MISMATCH", flush=True)
     sys.exit(0 if ok else 1)

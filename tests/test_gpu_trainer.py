@@ -51,9 +51,10 @@ def test_recorded_command_buffers_equal_eager_submission(hip_device):
     assert a.getItersPerSec() > 0 and a.getLastStepMs() > 0
 
 
-def test_training_reduces_the_loss_and_densify_rebuilds(hip_device, orc):
-    """30 steps with a densify at iterations 10 and 20: the point count changes, optimizer state is carried over, the
-    L1 error against the ground truth goes down, and the rebuilt cloud equals the oracle's rebuild of the same inputs."""
+def test_training_reduces_the_loss_and_densify_rebuilds(hip_device):
+    """30 steps with a densify at iterations 10 and 20: the point count changes, optimizer state is carried over and the L1
+    error against the ground truth goes down.  (The comparison of the rebuilt cloud, state and trajectory with the oracle's
+    restatement of trainer.ts is tests/test_gpu_trainer_oracle.py.)"""
     cfg = harness.small_config("c2", num_points=5000, width=128, height=96, s0=0.01)
     g, sh, _ = harness.scene(cfg)
     dev = hip_device

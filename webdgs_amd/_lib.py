@@ -99,6 +99,7 @@ SIGNATURES = {
     "wdgs_device_reset_kernel_times": (_I, [_P]),
     "wdgs_encoder_begin": (_I, [_P]),
     "wdgs_encoder_finish": (_I, [_P, C.POINTER(_P)]),
+    "wdgs_encoder_abort": (_I, [_P]),
     "wdgs_queue_submit": (_I, [_P, _P]),
     "wdgs_command_buffer_destroy": (_I, [_P]),
     "wdgs_queue_on_done": (_I, [_P, DoneCallback, _P]),

@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
+#include <set>
 
 #include "common.h"
 
@@ -32,6 +34,20 @@ extern "C" int wdgs_sorter_final_out_index(wdgs_sorter* s);
 extern "C" uint32_t wdgs_sorter_capacity(wdgs_sorter* s);
 
 static thread_local char g_last_error[512] = "";
+
+// Devices that have been created and not yet destroyed.  Every op keeps a pointer to its device; a host that tears things down
+// in the wrong order (an interpreter finalising its objects at exit, say) may call an op's destroy after wdgs_device_destroy.
+// Destroy functions therefore ask here before they touch op->dev, and only release memory when the device is already gone.
+static std::mutex g_live_mutex;
+static std::set<const wdgs_device*> g_live_devices;
+bool wdgs_device_alive(const wdgs_device* d) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    return d && g_live_devices.count(d) != 0;
+}
+// stream of a live device that is not in the middle of a recording, else nullptr ("nothing to wait for")
+static void sync_if_alive(wdgs_device* d) {
+    if (wdgs_device_alive(d) && !d->capturing) (void)hipStreamSynchronize(d->stream);
+}
 
 void wdgs_set_error(const char* fmt, ...) {
     va_list ap;
@@ -148,6 +164,7 @@ int wdgs_device_create(int ordinal, void* external_stream, wdgs_device** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess) d->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    { std::lock_guard<std::mutex> lock(g_live_mutex); g_live_devices.insert(d); }
     *out = d;
     return WDGS_OK;
 }
@@ -184,7 +201,17 @@ int wdgs_device_synchronize(wdgs_device* d) {
 
 int wdgs_device_destroy(wdgs_device* d) {
     if (!d) return WDGS_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        if (!g_live_devices.erase(d)) return WDGS_OK;  // already destroyed (or never ours): idempotent
+    }
     (void)hipSetDevice(d->ordinal);
+    if (d->capturing) {  // an abandoned recording: end it so the stream is usable by its owner again
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(d->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        d->capturing = false;
+    }
     (void)hipStreamSynchronize(d->stream);
     collect_profile(d);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
@@ -244,6 +271,17 @@ int wdgs_encoder_finish(wdgs_device* d, wdgs_command_buffer** out) {
     *out = reinterpret_cast<wdgs_command_buffer*>(c);
     return WDGS_OK;
 }
+int wdgs_encoder_abort(wdgs_device* d) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
+    if (!d->capturing) return WDGS_OK;  // nothing open: harmless, so error paths may call it unconditionally
+    d->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(d->stream, &graph);  // an invalidated capture reports an error here and yields no graph
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();  // the failed encode's sticky error, if any, belongs to the aborted recording
+    (void)e;
+    return WDGS_OK;
+}
 int wdgs_queue_submit(wdgs_device* d, wdgs_command_buffer* cmd) {
     WDGS_REQUIRE(d && cmd, WDGS_E_INVALID, "null argument");
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_submit while recording");
@@ -287,6 +325,8 @@ int wdgs_copy_to_host(wdgs_device* d, void* dst, const void* src, size_t bytes) 
 
 int wdgs_copy_to_device(wdgs_device* d, void* dst, const void* src, size_t bytes) {
     WDGS_REQUIRE(d && (bytes == 0 || (dst && src)), WDGS_E_INVALID, "wdgs_copy_to_device: null argument");
+    // a recording would bake the (pageable, soon reused) host pointer into the graph: uploads belong before wdgs_encoder_begin
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_copy_to_device while recording a command buffer");
     if (bytes == 0) return WDGS_OK;
     // pageable source: hipMemcpyAsync stages the copy before returning, so `src` may be reused immediately
     WDGS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
@@ -296,6 +336,7 @@ int wdgs_copy_to_device(wdgs_device* d, void* dst, const void* src, size_t bytes
 int wdgs_memset(wdgs_device* d, void* dst, int value, size_t bytes) {
     WDGS_REQUIRE(d && (bytes == 0 || dst), WDGS_E_INVALID, "wdgs_memset: null argument");
     if (bytes == 0) return WDGS_OK;
+    // allowed inside a recording: it becomes a memset node of the command buffer (encoder.clearBuffer is recorded in the reference too)
     WDGS_CHECK_HIP(hipMemsetAsync(dst, value, bytes, d->stream));
     return WDGS_OK;
 }
@@ -444,9 +485,11 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
 
 int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     if (!op) return WDGS_OK;
-    auto& v = op->dev->forwards;
-    v.erase(std::remove(v.begin(), v.end(), op), v.end());
-    (void)hipStreamSynchronize(op->dev->stream);
+    if (wdgs_device_alive(op->dev)) {
+        auto& v = op->dev->forwards;
+        v.erase(std::remove(v.begin(), v.end(), op), v.end());
+    }
+    sync_if_alive(op->dev);
     free_dev(op->stats);
     if (op->host_stats) (void)hipHostFree(op->host_stats);
     free_dev(op->splats);
@@ -551,7 +594,7 @@ int wdgs_tiled_rasterizer_create(wdgs_device* d, wdgs_tiled_forward* fwd, uint32
 }
 int wdgs_tiled_rasterizer_destroy(wdgs_tiled_rasterizer* op) {
     if (!op) return WDGS_OK;
-    (void)hipStreamSynchronize(op->dev->stream);
+    sync_if_alive(op->dev);
     free_dev(op->ranges);
     free_dev(op->rgba8);
     free_dev(op->alpha);
@@ -654,7 +697,7 @@ int wdgs_tiled_backward_create(wdgs_device* d, const wdgs_tiled_backward_config*
 }
 int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op) {
     if (!op) return WDGS_OK;
-    (void)hipStreamSynchronize(op->dev->stream);
+    sync_if_alive(op->dev);
     free_dev(op->acc); free_dev(op->gradients); free_dev(op->loss_image); free_dev(op->metric_counts);
     free_dev(op->metric_err); free_dev(op->metric_flags); free_dev(op->metric_minmax);
     delete op;
@@ -777,8 +820,9 @@ int wdgs_optimizer_create(wdgs_device* d, uint32_t n, const wdgs_adam_hyperparam
 }
 int wdgs_optimizer_destroy(wdgs_optimizer* op) {
     if (!op) return WDGS_OK;
-    if (!op->owns_state) (void)optimizer_flush_dc(op);  // adopted buffers outlive the optimizer: leave them current
-    (void)hipStreamSynchronize(op->dev->stream);
+    const bool live = wdgs_device_alive(op->dev) && !op->dev->capturing;
+    if (!op->owns_state && live) (void)optimizer_flush_dc(op);  // adopted buffers outlive the optimizer: leave them current
+    sync_if_alive(op->dev);
     if (op->owns_state) optimizer_free_state(op);
     free_dev(op->dc);
     delete op;

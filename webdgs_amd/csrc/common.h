@@ -86,6 +86,8 @@ static inline u32 ceil_div(u32 a, u32 b) { return (a + b - 1u) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream);
+// true between wdgs_device_create and wdgs_device_destroy (api.hip): destroy functions check it before touching op->dev
+bool wdgs_device_alive(const wdgs_device* d);
 
 // ---- primitives implemented in scan.hip / sort.hip, used by the ops
 struct ScanScratch { u32* block_sums = nullptr; u32 capacity_blocks = 0; };

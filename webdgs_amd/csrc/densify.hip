@@ -378,7 +378,7 @@ int wdgs_densify_prune_create(wdgs_device* dev, const wdgs_densify_config* cfg, 
 
 int wdgs_densify_prune_destroy(wdgs_densify_prune* op) {
     if (!op) return WDGS_OK;
-    (void)hipStreamSynchronize(op->dev->stream);
+    if (wdgs_device_alive(op->dev) && !op->dev->capturing) (void)hipStreamSynchronize(op->dev->stream);
     densify_free(op);
     if (op->total) (void)hipFree(op->total);
     delete op;

@@ -19,6 +19,8 @@ from typing import Optional
 
 import numpy as np
 
+from . import synth
+
 C0 = 0.28209479177387814
 
 
@@ -261,8 +263,8 @@ def cameraUniforms(cam: dict, width: Optional[int] = None, height: Optional[int]
     """``Camera.set_preset`` + ``update_buffer`` (``camera/camera.ts:23-56, 138-205``): the 68-float block for a CameraData.
 
     ``width``/``height`` = canvas size (the trainer sets it to the image size, ``trainer.ts:583-584``).  Matrices are formed
-    in binary64 from Float32Array operands and stored as f32, as wgpu-matrix does; the inverses use numpy's LU instead of
-    wgpu-matrix's cofactor formula (same value before the f32 store up to ~1e-16 relative)."""
+    in binary64 from Float32Array operands and stored as f32, as wgpu-matrix does; the inverses are wgpu-matrix's cofactor formula
+    (``synth.mat4_inverse``) applied to the stored float32 matrices, as ``update_buffer`` applies ``mat4.inverse`` to them."""
     w = int(width if width is not None else cam["width"])
     h = int(height if height is not None else cam["height"])
     fov_y = 45.0 / 180.0 * math.pi
@@ -286,8 +288,8 @@ def cameraUniforms(cam: dict, width: Optional[int] = None, height: Optional[int]
     proj = proj.astype(np.float32).astype(np.float64)
     out = np.zeros(68, np.float32)
     out[0:16] = view.T.reshape(-1)
-    out[16:32] = np.linalg.inv(view).T.reshape(-1)
     out[32:48] = proj.T.reshape(-1)
-    out[48:64] = np.linalg.inv(proj).T.reshape(-1)
+    out[16:32] = synth.mat4_inverse(out[0:16])
+    out[48:64] = synth.mat4_inverse(out[32:48])
     out[64:68] = (w, h, focal, focal)
     return out

@@ -76,8 +76,26 @@ class HipEncoder:
 
     def __init__(self, device: "HipDevice", label: str = "", record: bool = False):
         self.device, self.label, self.record = device, label, record
+        self._open = False
         if record:
             check(device.lib.wdgs_encoder_begin(device.handle))
+            self._open = True
+
+    def __enter__(self) -> "HipEncoder":
+        return self
+
+    def __exit__(self, exc_type, exc, tb) -> bool:
+        """``with device.createCommandEncoder(record=True) as enc:`` -- an exception inside the block (a failed encode, a
+        Python error) drops the recording instead of leaving the device's stream in capture mode."""
+        if exc_type is not None:
+            self.abort()
+        return False
+
+    def abort(self) -> None:
+        """Discards an unfinished recording (``wdgs_encoder_abort``); a no-op for eager or finished encoders."""
+        if self._open:
+            self._open = False
+            check(self.device.lib.wdgs_encoder_abort(self.device.handle))
 
     def clearBuffer(self, buf: HipBuffer) -> None:
         buf.clear()
@@ -88,6 +106,9 @@ class HipEncoder:
     def finish(self):
         if not self.record:
             return self
+        if not self._open:
+            raise _lib.StateError(_lib.WDGS_E_STATE, "encoder already finished or aborted")
+        self._open = False  # wdgs_encoder_finish leaves capture mode whether or not it succeeds
         h = C.c_void_p()
         check(self.device.lib.wdgs_encoder_finish(self.device.handle, C.byref(h)))
         return HipCommandBuffer(self.device, h)
@@ -176,9 +197,13 @@ class HipDevice:
         return out
 
     def destroy(self) -> None:
+        """Drains the stream and frees the library-side device.  Ops and command buffers should be destroyed first; one that is
+        destroyed later only releases its memory (include/webdgs.h "teardown order").  Idempotent."""
         if self.handle:
+            self.lib.wdgs_encoder_abort(self.handle)
             self.lib.wdgs_device_destroy(self.handle)
             self.handle = None
+        self._keepalive.clear()
 
 
 @dataclasses.dataclass

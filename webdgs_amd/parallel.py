@@ -67,6 +67,14 @@ def barrier() -> None:
         dist.barrier()
 
 
+def shutdown() -> None:
+    """Tears the default process group down (after every Trainer and HipDevice of this process has been destroyed)."""
+    if dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
 class Communicator:
     """The C-ABI communicator (``wdgs_comm_*``, include/webdgs.h): RCCL driven by the library itself, for hosts that have no
     ``torch.distributed`` (the N-API addon, a C++ trainer).  ``unique_id`` is the 128-byte id of rank 0

@@ -139,16 +139,51 @@ def projection_matrix(width: int, height: int, fy: float, znear: float = 0.01, z
     return m
 
 
+def mat4_inverse(m_colmajor: np.ndarray) -> np.ndarray:
+    """``mat4.inverse`` of wgpu-matrix 3.2.0 (the reference's dependency, ``package-lock.json:695-698``; not vendored in the
+    reference tree, so its published cofactor algorithm is restated here), as called by ``Camera.update_buffer``
+    (``src/camera/camera.ts:171,187``).  ``m_colmajor``: the 16 elements in storage order (column-major), evaluated in binary64
+    exactly as JavaScript evaluates it on Float32Array operands; the caller's store to float32 is the final rounding."""
+    m = [float(v) for v in np.asarray(m_colmajor, dtype=np.float64).reshape(16)]
+    m00, m01, m02, m03, m10, m11, m12, m13, m20, m21, m22, m23, m30, m31, m32, m33 = m
+    tmp0, tmp1, tmp2, tmp3 = m22 * m33, m32 * m23, m12 * m33, m32 * m13
+    tmp4, tmp5, tmp6, tmp7 = m12 * m23, m22 * m13, m02 * m33, m32 * m03
+    tmp8, tmp9, tmp10, tmp11 = m02 * m23, m22 * m03, m02 * m13, m12 * m03
+    tmp12, tmp13, tmp14, tmp15 = m20 * m31, m30 * m21, m10 * m31, m30 * m11
+    tmp16, tmp17, tmp18, tmp19 = m10 * m21, m20 * m11, m00 * m31, m30 * m01
+    tmp20, tmp21, tmp22, tmp23 = m00 * m21, m20 * m01, m00 * m11, m10 * m01
+    t0 = (tmp0 * m11 + tmp3 * m21 + tmp4 * m31) - (tmp1 * m11 + tmp2 * m21 + tmp5 * m31)
+    t1 = (tmp1 * m01 + tmp6 * m21 + tmp9 * m31) - (tmp0 * m01 + tmp7 * m21 + tmp8 * m31)
+    t2 = (tmp2 * m01 + tmp7 * m11 + tmp10 * m31) - (tmp3 * m01 + tmp6 * m11 + tmp11 * m31)
+    t3 = (tmp5 * m01 + tmp8 * m11 + tmp11 * m21) - (tmp4 * m01 + tmp9 * m11 + tmp10 * m21)
+    d = 1.0 / (m00 * t0 + m10 * t1 + m20 * t2 + m30 * t3)
+    out = np.empty(16, dtype=np.float64)
+    out[0], out[1], out[2], out[3] = d * t0, d * t1, d * t2, d * t3
+    out[4] = d * ((tmp1 * m10 + tmp2 * m20 + tmp5 * m30) - (tmp0 * m10 + tmp3 * m20 + tmp4 * m30))
+    out[5] = d * ((tmp0 * m00 + tmp7 * m20 + tmp8 * m30) - (tmp1 * m00 + tmp6 * m20 + tmp9 * m30))
+    out[6] = d * ((tmp3 * m00 + tmp6 * m10 + tmp11 * m30) - (tmp2 * m00 + tmp7 * m10 + tmp10 * m30))
+    out[7] = d * ((tmp4 * m00 + tmp9 * m10 + tmp10 * m20) - (tmp5 * m00 + tmp8 * m10 + tmp11 * m20))
+    out[8] = d * ((tmp12 * m13 + tmp15 * m23 + tmp16 * m33) - (tmp13 * m13 + tmp14 * m23 + tmp17 * m33))
+    out[9] = d * ((tmp13 * m03 + tmp18 * m23 + tmp21 * m33) - (tmp12 * m03 + tmp19 * m23 + tmp20 * m33))
+    out[10] = d * ((tmp14 * m03 + tmp19 * m13 + tmp22 * m33) - (tmp15 * m03 + tmp18 * m13 + tmp23 * m33))
+    out[11] = d * ((tmp17 * m03 + tmp20 * m13 + tmp23 * m23) - (tmp16 * m03 + tmp21 * m13 + tmp22 * m23))
+    out[12] = d * ((tmp14 * m22 + tmp17 * m32 + tmp13 * m12) - (tmp16 * m32 + tmp12 * m12 + tmp15 * m22))
+    out[13] = d * ((tmp20 * m32 + tmp12 * m02 + tmp19 * m22) - (tmp18 * m22 + tmp21 * m32 + tmp13 * m02))
+    out[14] = d * ((tmp18 * m12 + tmp23 * m32 + tmp15 * m02) - (tmp22 * m32 + tmp14 * m02 + tmp19 * m12))
+    out[15] = d * ((tmp22 * m22 + tmp16 * m02 + tmp21 * m12) - (tmp20 * m12 + tmp23 * m22 + tmp17 * m02))
+    return out
+
+
 def camera_block(view_rowmajor: np.ndarray, width: int, height: int, fy: float) -> np.ndarray:
     """Packs the 272-byte ``CameraUniforms`` block (``src/shaders/common.wgsl:1-8``) from a 4x4 world->view matrix."""
     view = np.asarray(view_rowmajor, dtype=np.float64).reshape(4, 4)
     proj_cm = projection_matrix(width, height, fy)
-    proj = proj_cm.reshape(4, 4).T
     out = np.zeros(68, dtype=np.float32)
     out[0:16] = view.T.reshape(-1)
-    out[16:32] = np.linalg.inv(view).T.reshape(-1)
     out[32:48] = proj_cm
-    out[48:64] = np.linalg.inv(proj).T.reshape(-1)
+    # the inverses are taken of the float32 matrices the uniform block stores, by wgpu-matrix's cofactor formula (camera.ts:171,187)
+    out[16:32] = mat4_inverse(out[0:16])
+    out[48:64] = mat4_inverse(out[32:48])
     out[64:66] = (width, height)
     out[66:68] = (fy, fy)
     return out

@@ -240,14 +240,25 @@ class Trainer:
 
     @staticmethod
     def metrics_camera(camera: np.ndarray, width: int, height: int) -> np.ndarray:
-        """The metrics camera of ``trainer.ts:399-401`` + ``camera.ts:138-147,196-205``: same pose and fovY as the training view,
-        canvas resized to the metrics resolution, so focal = 0.5*h/tan(fovY/2) and the projection is rebuilt."""
+        """The metrics camera of ``trainer.ts:399-401``: ``set_preset`` keeps the view's pose and derives
+        ``fovY = 2 atan(height / (2 fy))`` from the view's own height and fy (``camera.ts:196-205``), ``on_update_canvas`` turns
+        it into ``focal = 0.5 canvasHeight / tan(fovY / 2)`` for the metrics canvas (``camera.ts:138-147``) and ``update_buffer``
+        rebuilds projection and inverses.  The atan/tan round trip is kept: it is what the reference evaluates."""
         from . import synth
-        cam = np.asarray(camera, np.float32).copy()
-        base_h, fy = float(cam[65]), float(cam[67])
-        new_fy = fy * height / base_h
-        view = cam[0:16].reshape(4, 4).T.astype(np.float64)
-        return synth.camera_block(view, width, height, new_fy)
+        cam = np.asarray(camera, np.float32)
+        fov_y = 2.0 * math.atan(float(cam[65]) / (2.0 * float(cam[67])))
+        focal = 0.5 * height / math.tan(fov_y * 0.5)
+        fov_x = 2.0 * math.atan(width / (2.0 * focal))
+        znear, zfar = 0.01, 100.0
+        top, right = math.tan(fov_y / 2.0) * znear, math.tan(fov_x / 2.0) * znear
+        out = np.zeros(68, np.float32)
+        out[0:16] = cam[0:16]
+        out[32], out[37] = 2.0 * znear / (2.0 * right), -2.0 * znear / (2.0 * top)   # camera.ts:29-56, column-major
+        out[42], out[43], out[46] = zfar / (zfar - znear), 1.0, -(zfar * znear) / (zfar - znear)
+        out[16:32] = synth.mat4_inverse(out[0:16])
+        out[48:64] = synth.mat4_inverse(out[32:48])
+        out[64:68] = (width, height, focal, focal)
+        return out
 
     # ------------------------------------------------------------------ one training step
     def _encode_view(self, encoder, index: int) -> None:
@@ -295,35 +306,16 @@ class Trainer:
         key = tuple(mine)
         cmds = self._cmd_cache.get(key)
         if cmds is None:
-            tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
             # the first steps run eagerly (they allocate textures); afterwards each view set is recorded once and replayed
             record = self.use_command_buffers and self._eager_steps >= 1
-            encoder = self.device.createCommandEncoder("trainer-step", record=record)
-            if n_views == 1:
-                self._encode_view(encoder, mine[0])
-                self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
-                cmds = [encoder.finish()]
-                self.device.queue.submit(cmds)
-            else:
-                n = self.pointCloud.num_points
-                if self._dp_grad is None:
-                    self._dp_grad = self.device.createBuffer(4 * parallel.GRAD_FLOATS * n, "dp-grad-f32")
-                    self._dp_visible = self.device.createBuffer(4 * n, "dp-visible")
-                    if record:  # allocation happened inside an open recording: restart it cleanly
-                        encoder.finish().destroy()
-                        encoder = self.device.createCommandEncoder("trainer-step", record=True)
-                for k, v in enumerate(mine):  # the first view overwrites the fp32 block (no clearing pass), the others add to it
-                    self._encode_view(encoder, v)
-                    (ops.storeGradients if k == 0 else ops.accumulateGradients)(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts,
-                                                                                self._dp_grad, self._dp_visible)
-                first = encoder.finish()
-                self.device.queue.submit([first])
-                self._allreduce()
-                encoder2 = self.device.createCommandEncoder("trainer-step-adam", record=record)
-                self.optimizer.stepF32(encoder2, self.pointCloud, self._dp_grad, self._dp_visible)
-                second = encoder2.finish()
-                self.device.queue.submit([second])
-                cmds = [first, second]
+            try:
+                cmds = self._encode_and_submit_step(mine, n_views, record)
+            except BaseException:
+                # a failed encode (capacity, first-use allocation inside a recording, a Python error) must not leave the stream in
+                # capture mode or half-recorded command buffers behind: drop the recording and fall back to a clean eager state
+                self.device.lib.wdgs_encoder_abort(self.device.handle)
+                self._invalidate_command_buffers()
+                raise
             if record:
                 self._cmd_cache[key] = cmds
             else:
@@ -347,6 +339,51 @@ class Trainer:
                 self.applyPointCloudSwap(req)
         if self.iteration >= self.maxIterations:
             self.stop()
+
+    def _encode_and_submit_step(self, mine: list, n_views: int, record: bool) -> list:
+        """Encodes (eagerly, or into command buffers when ``record``) and submits one global step; returns the command buffers."""
+        tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
+        if n_views == 1:
+            with self.device.createCommandEncoder("trainer-step", record=record) as encoder:
+                self._encode_view(encoder, mine[0])
+                self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
+                cmds = [encoder.finish()]
+            self.device.queue.submit(cmds)
+            return cmds
+        n = self.pointCloud.num_points
+        if self._dp_grad is None:  # (allocated before any recording is opened)
+            self._dp_grad = self.device.createBuffer(4 * parallel.GRAD_FLOATS * n, "dp-grad-f32")
+            self._dp_visible = self.device.createBuffer(4 * n, "dp-visible")
+        with self.device.createCommandEncoder("trainer-step", record=record) as encoder:
+            for k, v in enumerate(mine):  # the first view overwrites the fp32 block (no clearing pass), the others add to it
+                self._encode_view(encoder, v)
+                (ops.storeGradients if k == 0 else ops.accumulateGradients)(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts,
+                                                                            self._dp_grad, self._dp_visible)
+            first = encoder.finish()
+        self.device.queue.submit([first])
+        self._allreduce()
+        with self.device.createCommandEncoder("trainer-step-adam", record=record) as encoder2:
+            self.optimizer.stepF32(encoder2, self.pointCloud, self._dp_grad, self._dp_visible)
+            second = encoder2.finish()
+        self.device.queue.submit([second])
+        return [first, second]
+
+    def destroy(self) -> None:
+        """Deterministic teardown: command buffers, then every op, then the buffers this trainer allocated.  The device itself
+        belongs to the caller (``HipDevice.destroy()`` comes after this, and before ``torch.distributed.destroy_process_group``)."""
+        if self.device.handle:
+            self.device.lib.wdgs_encoder_abort(self.device.handle)
+            self.device.synchronize()
+        self._invalidate_command_buffers()
+        for name in ("forwardPass", "rasterizer", "backwardPass", "metricsForwardPass", "metricsRasterizer", "metricsPass", "optimizer", "densifyPrune"):
+            op = getattr(self, name, None)
+            if op is not None:
+                op.destroy()
+            setattr(self, name, None)
+        self._dp_grad = self._dp_visible = self.metricsTarget = None
+        self._camera_buffers = []
+        self.pointCloud = None
+        self.isTraining = False
 
     def _allreduce(self) -> None:
         if self.world_size <= 1:
