@@ -297,6 +297,23 @@ int wdgs_accumulate_gradients(wdgs_device* dev, uint32_t num_points, const void*
  * visible[N] = (tile_counts > 0).  Spares the batch a clearing pass over the 60 B/Gaussian block. */
 int wdgs_store_gradients(wdgs_device* dev, uint32_t num_points, const void* gradients_dev, const void* tile_counts_dev,
                          void* acc_f32_dev, void* visible_counts_dev);
+/* Adam + re-pack on Gaussians [first, first + count) only: the slice a data-parallel rank owns after
+ * wdgs_comm_exchange_gradients.  rows_out_dev (nullable, u32[num_points rounded up][8]) also receives each re-packed row in the
+ * 32-byte form {6 Gaussian words, SH word 0, low half of SH word 1} that wdgs_comm_allgather_rows publishes. */
+int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, const void* grad_f32_dev, const void* visible_counts_dev,
+                                  uint32_t first, uint32_t count, void* rows_out_dev);
+/* Writes the rows published by the other ranks into this replica's point cloud: every Gaussian outside [skip_first, skip_first +
+ * skip_count).  guard_dev (nullable): non-zero at execution time -> no-op. */
+int wdgs_apply_repacked_rows(wdgs_device* dev, uint32_t num_points, const void* rows_dev, uint32_t skip_first, uint32_t skip_count,
+                             const void* guard_dev, void* gaussians_dev, void* sh_dev);
+/* Guard word: while *flag_u32_dev != 0 at EXECUTION time, step / step_f32 / step_f32_range leave every buffer untouched.  Point it at
+ * TiledForwardResources.stats_buffer + 8 (the overflow word): a step whose tile-entry list was truncated -- it will be reported
+ * as WDGS_E_CAPACITY by the next wdgs_device_synchronize -- then does not corrupt the optimizer state first.  NULL removes it. */
+int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag_u32_dev);
+/* flag = (overwrite ? 0 : flag) | (*src != 0): folds the overflow words of the views of a batched step into one guard word. */
+int wdgs_guard_accumulate(wdgs_device* dev, void* flag_u32_dev, const void* src_u32_dev, int overwrite);
+/* The caller rewrote the state arrays (gathered slices from other ranks): refresh the optimizer's internal compact copies. */
+int wdgs_optimizer_state_changed(wdgs_optimizer* op);
 uint32_t wdgs_optimizer_get_iteration(const wdgs_optimizer* op);
 /* Host-side counter only (optimizer.ts:301): call when a recorded command buffer containing step() is re-submitted. */
 int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count);
@@ -371,6 +388,21 @@ int wdgs_comm_rank(const wdgs_comm* comm);
 int wdgs_comm_allreduce_gradients(wdgs_comm* comm, void* grad_f32_dev, void* visible_counts_dev, uint32_t num_points);
 /* In place u32 sum (densify metric counts, SURVEY 8(e) "Determinism"). */
 int wdgs_comm_allreduce_counts(wdgs_comm* comm, void* counts_u32_dev, uint32_t count);
+/* The bandwidth-optimal form of the same exchange: reduce-scatter -> Adam on the owned slice -> all-gather of the
+ * re-packed rows.  Gaussians are dealt to ranks in contiguous slices of slice_points = ceil(N / world_size) rounded up to 64; rank r
+ * owns [r*slice, min((r+1)*slice, N)).  grad_f32_dev and visible_counts_dev hold world_size*slice_points rows (tail zero); after the
+ * call rank r's OWN slice holds the sums over all ranks (the other slices are scratch).  flag_u32_dev (nullable, one u32) is summed
+ * over all ranks in the same RCCL group: a per-rank "tile entries overflowed" word becomes a global one, so every rank skips the
+ * step together (wdgs_optimizer_set_guard).  Then wdgs_optimizer_step_f32_range(first = r*slice, rows_out = rows) and
+ * wdgs_comm_allgather_rows(rows) (in place, world_size*slice_points rows of 32 bytes) and wdgs_apply_repacked_rows.  Per step and
+ * rank this moves (7/8)(60 + 32) B per Gaussian instead of the all-reduce's 2(7/8)60 B, and divides the Adam pass by world_size.
+ * The optimizer state of a slice lives on its owner; gather it with wdgs_comm_broadcast (one call per owner and array, optionally
+ * inside wdgs_comm_group_start/end) + wdgs_optimizer_state_changed before a densify rebuild or an export. */
+int wdgs_comm_exchange_gradients(wdgs_comm* comm, void* grad_f32_dev, void* visible_counts_dev, void* flag_u32_dev, uint32_t slice_points);
+int wdgs_comm_allgather_rows(wdgs_comm* comm, void* rows_dev, uint32_t slice_points);
+int wdgs_comm_broadcast(wdgs_comm* comm, void* ptr_dev, size_t bytes, int root);
+int wdgs_comm_group_start(void);
+int wdgs_comm_group_end(void);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,21 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def use_native_build() -> bool:
+    """Switches this process to ``liboracle_native.so`` (same sources, ``-march=native``), built on the spot: the build that
+    bench.py times as ``cpu_baseline``.  Falls back to the portable build (returns False) if the compile fails."""
+    global _lib
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_native.so"], stdout=subprocess.DEVNULL)
+        l = ctypes.CDLL(os.path.join(_HERE, "liboracle_native.so"))
+        l.orc_emit.restype = ctypes.c_uint32
+        l.orc_densify_total.restype = ctypes.c_uint32
+        _lib = l
+        return True
+    except Exception:
+        return False
+
+
 def _p(a):
     if a is None:
         return None

@@ -23,6 +23,6 @@ def dataset(dev):
     return cfg, g, sh, cameras, images
 
 
-def view_schedule(steps, world):
-    """Global view ids per step: rank r of `world` takes ids[r]; a single process with views_per_rank = world takes all."""
-    return [[(3 * s + 2 * r + 1) % 4 for r in range(world)] for s in range(steps)]
+def view_schedule(steps, world, views_per_rank=1):
+    """Global view ids per step (world * views_per_rank of them): rank r takes ids[r::world]; a single process takes all."""
+    return [[(3 * s + 2 * r + 1) % 4 for r in range(world * views_per_rank)] for s in range(steps)]

@@ -1,7 +1,9 @@
 """Worker of tests/test_gpu_dp.py::test_rccl_backend_through_the_trainer: a real `nccl` (RCCL) process group of size one, with the
-Trainer's data-parallel exchange forced on, so that every collective of the multi-GPU path -- fp32 view of the gradient block,
-int32 visibility, float64 MAX of the timing, barrier, teardown -- is issued against RCCL on this stack, interleaved with the
-recorded command buffers.  With one rank the reductions are identities: the run must equal the same run without collectives."""
+Trainer's sliced data-parallel exchange forced on through BOTH transports (torch.distributed and the library's own wdgs_comm), so
+that every collective of the multi-GPU path -- reduce-scatter of the gradient block and the visibility counts, the guard word's
+all-reduce, the all-gather of the re-packed rows, broadcast, the counts all-reduce, float64 MAX of the timing, barrier, teardown --
+is issued against RCCL on this stack, interleaved with the recorded command buffers.  With one rank the collectives are
+identities: each run must equal the same run without collectives, bit for bit."""
 import os
 import sys
 
@@ -24,25 +26,27 @@ import dp_common  # noqa: E402
 
 def run(dev, data, exchange):
     cfg, g, sh, cameras, images = data
-    t = Trainer(dev, seed=11, world_size=1, rank=0, views_per_rank=2)
+    t = Trainer(dev, seed=11, world_size=1, rank=0, views_per_rank=2, exchange=exchange)
     t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
     t.start()
-    if exchange:
-        def allreduce():  # Trainer._allreduce without its world_size == 1 shortcut
-            n = t.pointCloud.num_points
-            gr = t._dp_grad.tensor().view(torch.float32)[: parallel.GRAD_FLOATS * n]
-            vis = t._dp_visible.tensor()[:n]
-            dev.torch_stream.synchronize()
-            dist.all_reduce(gr, op=dist.ReduceOp.SUM)
-            dist.all_reduce(vis, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize(dev.torch_device)
-        t._allreduce = allreduce
     for ids in dp_common.view_schedule(7, 2):
         t.step(ids)
     dev.synchronize()
-    out = t.pointCloud.gaussian_3d_buffer.read(np.uint32).copy()
+    assert (("apply",) in t._cmd_cache) == (exchange is not None), "sliced step: views | exchange | adam | all-gather | apply"
+    if exchange is not None:
+        t._state_sliced = True
+        t.world_size = 1
+        # (state gather with one rank: every broadcast is an identity; goes through the backend all the same)
+        n = t.pointCloud.num_points
+        bufs = t.optimizer.getStateBuffers()
+        exchange.broadcast(bufs["optPosBuffer"].ptr, 48 * n, 0)
+        exchange.allreduce_counts(t.backwardPass.getMetricCountsBuffer().ptr, n)
+        t.optimizer.stateChanged()
+    dev.synchronize()
+    out = (t.pointCloud.gaussian_3d_buffer.read(np.uint32).copy(), t.pointCloud.sh_buffer.read(np.uint32).copy(),
+           t.optimizer.getStateBuffers()["optPosBuffer"].read(np.uint32).copy(), t.optimizer.getStateBuffers()["stateSH"].read(np.uint32).copy())
     t.destroy()  # command buffers (HIP graphs) and ops go before the device and the process group
     return out
 
@@ -52,12 +56,17 @@ def main():
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     dev = ops.HipDevice(0)
     data = dp_common.dataset(dev)
-    with_rccl = run(dev, data, True)
+    plain = run(dev, data, None)
+    # the two transports of the sliced exchange, forced to issue their collectives in this world of one
+    via_torch = run(dev, data, parallel.TorchExchange(dev, force=True))
+    capi = parallel.CapiExchange(dev)
+    via_capi = run(dev, data, capi)
+    capi.destroy()
     parallel.barrier()
     tt = torch.tensor([1.25], dtype=torch.float64, device=dev.torch_device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    plain = run(dev, data, False)
-    ok = bool(np.array_equal(with_rccl, plain)) and float(tt.item()) == 1.25
+    same = lambda a, b: all(np.array_equal(x, y) for x, y in zip(a, b))  # noqa: E731
+    ok = same(plain, via_torch) and same(plain, via_capi) and float(tt.item()) == 1.25
     dist.barrier()
     # deterministic teardown: dataset buffers, the library device (drains the stream), then the process group, then exit
     del data, tt

@@ -85,3 +85,101 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     assert np.array_equal(r0["g"].view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(r0["c"], b[0][1] + b[1][1] + b[2][1] + b[3][1])
     assert (r0["c"] > 0).sum() > 100
+
+
+# ----------------------------------------------------------------------------- the sliced exchange, views_per_rank > 1
+def _sliced_worker(rank, world, port, steps, out_dir):
+    """One rank of the sliced protocol (parallel.py): 2 views per rank per step, fp32 accumulation in view order, reduce-scatter
+    (all-reduce on gloo), Adam on the OWNED slice only, all-gather of the re-packed rows, apply.  The oracle stands in for the HIP
+    kernels; partitioning and sequencing are the product's (parallel.shard_views / slice_points / owned_range)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle import oracle as orc
+    parallel.init_from_env(backend="gloo")
+    cfg, g, sh, cams, imgs, st, ti = _dp_scene()
+    g, sh = g.copy(), sh.copy()
+    state = orc.unpack(g, sh)
+    n = g.shape[0]
+    sl = parallel.slice_points(n, world)
+    first, count = parallel.owned_range(n, world, rank)
+    for ids in steps:
+        acc = np.zeros((world * sl, 14), np.float32)
+        vis = np.zeros(world * sl, np.int32)
+        for k, v in enumerate(parallel.shard_views(ids, rank, world)):
+            fw = orc.view_gradients(g, sh, cams[v], st, ti, imgs[v])
+            m = fw["tile_counts"] > 0
+            gf = orc.unpack_gradients_f32(fw["gradients"])
+            gf[~m] = 0
+            if k == 0:
+                acc[:n] = gf
+                vis[:n] = m
+            else:
+                acc[:n][m] += gf[m]
+                vis[:n] += m
+        ta, tv = torch.from_numpy(acc.reshape(-1)), torch.from_numpy(vis)
+        dist.all_reduce(ta)  # (gloo has no reduce-scatter; only the owned slice is consumed below)
+        dist.all_reduce(tv)
+        own_vis = np.zeros(n, np.uint32)
+        own_vis[first:first + count] = vis[first:first + count]
+        orc.adam_f32(orc.ADAM_DEFAULT, own_vis, np.ascontiguousarray(acc[:n]), state)  # Adam touches the owned slice only
+        g2, sh2 = g.copy(), sh.copy()
+        orc.repack(state, g2, sh2)
+        rows = np.zeros((world * sl, 8), np.uint32)
+        rows[first:first + count, 0:6] = g2[first:first + count]
+        rows[first:first + count, 6] = sh2[first:first + count, 0]
+        rows[first:first + count, 7] = sh2[first:first + count, 1] & 0xFFFF
+        tr = torch.from_numpy(rows.view(np.int32).reshape(-1))
+        parts = [tr[i * sl * 8:(i + 1) * sl * 8] for i in range(world)]
+        dist.all_gather(parts, parts[rank].clone())
+        g[:] = rows[:n, 0:6]  # apply (own slice included: it holds the same values)
+        sh[:, 0] = rows[:n, 6]
+        sh[:, 1] = (sh[:, 1] & 0xFFFF0000) | (rows[:n, 7] & 0xFFFF)
+    np.savez(os.path.join(out_dir, f"sliced{rank}.npz"), g=g, sh=sh, pos=state["opt_pos"], own=np.array([first, count]))
+    dist.destroy_process_group()
+
+
+def _dp_scene():
+    from oracle import oracle as orc
+    cfg = synth.SceneConfig(9, 1500, 96, 64, 1, 110.0, 0.02, "dp")
+    g, sh = synth.make_gaussians(cfg)
+    cams = synth.circle_cameras(cfg, 4)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    tg, tsh = synth.make_target_scene(g, sh)
+    imgs = [orc.forward(tg, tsh, cams[v], st, ti)["rgba8"] for v in range(4)]
+    return cfg, g, sh, cams, imgs, st, ti
+
+
+def test_slices_partition_the_gaussians():
+    for n in (0, 1, 63, 64, 65, 1500, 1_000_000):
+        for world in (1, 2, 3, 8):
+            sl = parallel.slice_points(n, world)
+            assert sl % 64 == 0 and sl * world >= n
+            owned = [parallel.owned_range(n, world, r) for r in range(world)]
+            assert sum(c for _, c in owned) == n
+            pos = 0
+            for f, c in owned:
+                assert f == min(pos, n) and c <= sl
+                pos += sl
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_two_views_each_sliced_adam_equals_the_oracle_trainer(tmp_path):
+    """views_per_rank = 2 on 2 ranks with the sliced Adam: replicas end identical to each other and to the oracle trainer's
+    batched step (per-rank fp32 sums in view order, rank sums added), and each rank's optimizer state is current exactly on the
+    slice it owns."""
+    from oracle import oracle_trainer
+    steps = [[0, 1, 2, 3], [3, 3, 1, 0], [2, 0, 0, 1]]
+    port = _free_port()
+    mp.spawn(_sliced_worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "sliced0.npz"), np.load(tmp_path / "sliced1.npz")
+    assert np.array_equal(r0["g"], r1["g"]) and np.array_equal(r0["sh"], r1["sh"])
+    cfg, g, sh, cams, imgs, _, _ = _dp_scene()
+    o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, list(cams), imgs, densify=dict(schedule=dict(enabled=False)))
+    for ids in steps:
+        o.step(ids, world=2)
+    assert np.array_equal(r0["g"], o.g) and np.array_equal(r0["sh"], o.sh)
+    assert not np.array_equal(o.g, g)
+    for r in (r0, r1):
+        f, c = (int(x) for x in r["own"])
+        assert np.array_equal(r["pos"][f:f + c].view(np.uint32), o.state["opt_pos"][f:f + c].view(np.uint32))
+    f1, c1 = (int(x) for x in r1["own"])
+    assert not np.array_equal(r0["pos"][f1:f1 + c1].view(np.uint32), o.state["opt_pos"][f1:f1 + c1].view(np.uint32)), "rank 0 does not train rank 1's slice"

@@ -83,8 +83,43 @@ def test_two_rank_training_equals_single_process_batch_of_two(hip_device, tmp_pa
     hip_device.synchronize()
     assert_bits_equal(t.pointCloud.gaussian_3d_buffer.read(np.uint32), ranks[0]["gaussians"], "2 ranks x 1 view vs 1 rank x 2 views: gaussians")
     assert_bits_equal(t.pointCloud.sh_buffer.read(np.uint32), ranks[0]["sh"], "2 ranks x 1 view vs 1 rank x 2 views: sh")
+    # optimizer state: sliced during the run (each rank trains the Gaussians it owns), identical everywhere after the gather
+    for k, b in t.optimizer.getStateBuffers().items():
+        single = b.read(np.uint32)
+        assert_bits_equal(ranks[0]["state_" + k], ranks[1]["state_" + k], f"state {k}: rank 0 vs rank 1 after syncOptimizerState")
+        assert_bits_equal(ranks[0]["state_" + k], single, f"state {k}: 2 ranks vs single process")
+    for r in range(2):
+        first, count = (int(x) for x in ranks[r]["own"])
+        assert count > 0
+        own = slice(first * 12, (first + count) * 12)
+        assert np.array_equal(ranks[r]["stale_pos"][own], ranks[r]["state_optPosBuffer"][own]), "the owned slice was current before the gather"
+        assert not np.array_equal(ranks[r]["stale_pos"], ranks[r]["state_optPosBuffer"]), "the other slice was stale before the gather"
     assert int(ranks[0]["iteration"][0]) == t.optimizer.getIteration() == steps
     assert not np.array_equal(ranks[0]["gaussians"], g.reshape(ranks[0]["gaussians"].shape)), "training did not move the parameters"
+
+
+def test_two_ranks_two_views_each_equals_the_oracle_trainer(hip_device, orc, tmp_path):
+    """c4's shape in small: several views per rank per global step.  Per-rank fp32 sums in view order, one sliced exchange, one Adam:
+    both replicas must equal the oracle trainer's batched step (world = 2) bit for bit, point cloud and gathered optimizer state."""
+    from oracle import oracle_trainer
+    steps, vpr = 5, 2
+    env = dict(os.environ, WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), str(steps), "1", str(vpr)], env))
+    assert r.returncode == 0, _verdict(r)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    cfg, g, sh, cameras, images = dp_common.dataset(hip_device)
+    imgs = [im["texture"].read(np.uint8).reshape(cfg.height, cfg.width, 4) for im in images]
+    o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, [c["camera"] for c in cameras], imgs, densify=dict(schedule=dict(enabled=False)))
+    for ids in dp_common.view_schedule(steps, 2, vpr):
+        o.step(ids, world=2)
+    n = o.num_points
+    for i in range(2):
+        assert_bits_equal(ranks[i]["gaussians"].reshape(-1, 6)[:n], o.g, f"rank {i} gaussians vs oracle trainer (2 ranks x 2 views)")
+        assert_bits_equal(ranks[i]["sh"].reshape(-1, 24)[:n], o.sh, f"rank {i} sh vs oracle trainer")
+        for k, (ok, width) in dict(optPosBuffer=("opt_pos", 12), optRotBuffer=("opt_rot", 12), optScaleBuffer=("opt_scale", 12),
+                                   optOpacityBuffer=("opt_opacity", 3), paramSH=("param_sh", 48), stateSH=("state_sh", 96)).items():
+            assert_bits_equal(ranks[i]["state_" + k].view(np.float32).reshape(-1, width)[:n], o.state[ok], f"rank {i} state {k} vs oracle trainer")
 
 
 def test_rccl_backend_through_the_trainer(tmp_path):

@@ -121,6 +121,16 @@ SIGNATURES = {
     "wdgs_comm_rank": (_I, [_P]),
     "wdgs_comm_allreduce_gradients": (_I, [_P, _P, _P, _U]),
     "wdgs_comm_allreduce_counts": (_I, [_P, _P, _U]),
+    "wdgs_comm_exchange_gradients": (_I, [_P, _P, _P, _P, _U]),
+    "wdgs_comm_allgather_rows": (_I, [_P, _P, _U]),
+    "wdgs_comm_broadcast": (_I, [_P, _P, _Z, _I]),
+    "wdgs_comm_group_start": (_I, []),
+    "wdgs_comm_group_end": (_I, []),
+    "wdgs_optimizer_step_f32_range": (_I, [_P, _P, _P, _P, _P, _U, _U, _P]),
+    "wdgs_apply_repacked_rows": (_I, [_P, _U, _P, _U, _U, _P, _P, _P]),
+    "wdgs_optimizer_set_guard": (_I, [_P, _P]),
+    "wdgs_guard_accumulate": (_I, [_P, _P, _P, _I]),
+    "wdgs_optimizer_state_changed": (_I, [_P]),
     "wdgs_copy_to_host": (_I, [_P, _P, _P, _Z]),
     "wdgs_copy_to_device": (_I, [_P, _P, _P, _Z]),
     "wdgs_memset": (_I, [_P, _P, _I, _Z]),

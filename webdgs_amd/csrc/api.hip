@@ -18,8 +18,12 @@ int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdg
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*);
-int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*);
-int launch_adam_repack_f32(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*);
+int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
+                       const void*);
+int launch_adam_repack_f32(wdgs_device*, u32, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*,
+                           void*, const void*, void*);
+int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, void*, void*);
+int launch_guard_accumulate(wdgs_device*, void*, const void*, u32);
 int launch_dc_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
 int launch_dc_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
 int launch_accumulate_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
@@ -130,6 +134,7 @@ struct wdgs_optimizer {
     u32 iteration;
     float* dc;        // compact SH-DC copy float[N][9] {param rgb, m rgb, v rgb} (optimizer.hip "HBM layout note"); always owned
     bool dc_dirty;    // dc is ahead of state.param_sh / state.state_sh
+    const void* guard;  // device word: non-zero at execution time turns step / step_f32 into a no-op (wdgs_optimizer_set_guard)
 };
 
 // Brings the reference-layout SH arrays up to date with the compact DC copy (no-op when nothing was trained since).
@@ -192,9 +197,11 @@ int wdgs_device_synchronize(wdgs_device* d) {
     collect_profile(d);
     for (wdgs_tiled_forward* f : d->forwards) {
         if (!f->encoded) continue;
-        const volatile u32* st = f->host_stats;  // written by update_stats before the stream drained (no device round trip here)
-        WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)",
-                     st[2], f->tile_info.max_tile_entries);
+        volatile u32* st = f->host_stats;  // written by update_stats before the stream drained (no device round trip here)
+        const u32 needed = st[2];          // sticky across the encodes since the last check: reading it here consumes it
+        st[2] = 0u;
+        WDGS_REQUIRE(needed == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)",
+                     needed, f->tile_info.max_tile_entries);
     }
     return WDGS_OK;
 }
@@ -576,6 +583,7 @@ int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
     WDGS_CHECK_HIP(hipStreamSynchronize(op->dev->stream));
     u32 st[4];
     for (int i = 0; i < 4; i++) st[i] = ((const volatile u32*)op->host_stats)[i];
+    ((volatile u32*)op->host_stats)[2] = 0u;  // the overflow word is sticky (set by any encode since the last check): consumed here
     if (stats_out) std::memcpy(stats_out, st, sizeof(st));
     WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u", st[2], op->tile_info.max_tile_entries);
     return WDGS_OK;
@@ -838,13 +846,41 @@ int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const voi
     WDGS_REQUIRE(op && gaussians && sh && gradients && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step: null argument");
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
-    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh);
+    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh, op->guard);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");
     op->iteration++;
     op->dc_dirty = true;
-    return launch_adam_repack_f32(op->dev, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh);
+    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, nullptr);
+}
+int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible, uint32_t first, uint32_t count,
+                                  void* rows_out) {
+    WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32_range: null argument");
+    WDGS_REQUIRE((uint64_t)first + count <= op->num_points, WDGS_E_INVALID, "wdgs_optimizer_step_f32_range: [%u, %u) exceeds %u points", first, first + count,
+                 op->num_points);
+    op->iteration++;
+    op->dc_dirty = true;
+    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, rows_out);
+}
+int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    op->guard = flag;
+    return WDGS_OK;
+}
+int wdgs_optimizer_state_changed(wdgs_optimizer* op) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
+    op->dc_dirty = false;
+    return launch_dc_load(op->dev, op->num_points, op->state, op->dc);
+}
+int wdgs_apply_repacked_rows(wdgs_device* d, uint32_t n, const void* rows, uint32_t skip_first, uint32_t skip_count, const void* guard, void* gaussians,
+                             void* sh) {
+    WDGS_REQUIRE(d && rows && gaussians && sh, WDGS_E_INVALID, "wdgs_apply_repacked_rows: null argument");
+    return launch_apply_rows(d, n, rows, skip_first, skip_count, guard, gaussians, sh);
+}
+int wdgs_guard_accumulate(wdgs_device* d, void* flag, const void* src, int overwrite) {
+    WDGS_REQUIRE(d && flag && src, WDGS_E_INVALID, "wdgs_guard_accumulate: null argument");
+    return launch_guard_accumulate(d, flag, src, overwrite ? 1u : 0u);
 }
 int wdgs_accumulate_gradients(wdgs_device* d, uint32_t n, const void* gradients, const void* tile_counts, void* acc, void* visible) {
     WDGS_REQUIRE(d && gradients && tile_counts && acc && visible, WDGS_E_INVALID, "wdgs_accumulate_gradients: null argument");

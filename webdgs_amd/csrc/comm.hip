@@ -21,7 +21,7 @@ namespace {
 struct RcclUniqueId { char internal[WDGS_COMM_ID_BYTES]; };
 typedef void* RcclComm;
 enum { RCCL_SUCCESS = 0 };
-enum { RCCL_UINT32 = 3, RCCL_FLOAT32 = 7 };  // ncclDataType_t
+enum { RCCL_UINT8 = 1, RCCL_UINT32 = 3, RCCL_FLOAT32 = 7 };  // ncclDataType_t
 enum { RCCL_SUM = 0 };                       // ncclRedOp_t
 
 struct RcclApi {
@@ -30,6 +30,9 @@ struct RcclApi {
     int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -48,10 +51,13 @@ int rccl_load() {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(h, "ncclBroadcast"));
     a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    WDGS_REQUIRE(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GroupStart && a.GroupEnd && a.GetErrorString, WDGS_E_STATE,
+    WDGS_REQUIRE(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.ReduceScatter && a.AllGather && a.Broadcast && a.GroupStart && a.GroupEnd && a.GetErrorString, WDGS_E_STATE,
                  "librccl.so.1 lacks an expected symbol");
     g_rccl = a;
     return WDGS_OK;
@@ -119,6 +125,56 @@ int wdgs_comm_allreduce_gradients(wdgs_comm* c, void* grad_f32, void* visible_co
     WDGS_CHECK_RCCL(g_rccl.GroupEnd());
     WDGS_CHECK_RCCL(e1);
     WDGS_CHECK_RCCL(e2);
+    return WDGS_OK;
+}
+
+// The bandwidth-optimal exchange: rank r ends up with the sums of rows [r*slice, (r+1)*slice) only, applies Adam to that
+// slice, and publishes the re-packed 32-byte rows with wdgs_comm_allgather_rows.  Both buffers hold world_size*slice_points rows
+// (the tail past num_points is zero); RCCL's in-place form recvbuff = sendbuff + rank*recvcount is used.  `flag` (one u32, e.g. a
+// tile-overflow word) is summed over all ranks in the same group, so that every rank takes the same "skip this step" decision.
+int wdgs_comm_exchange_gradients(wdgs_comm* c, void* grad_f32, void* visible_counts, void* flag, uint32_t slice_points) {
+    WDGS_REQUIRE(c && grad_f32 && visible_counts, WDGS_E_INVALID, "wdgs_comm_exchange_gradients: null argument");
+    if (slice_points == 0) return WDGS_OK;
+    float* g = (float*)grad_f32;
+    u32* v = (u32*)visible_counts;
+    const size_t r = (size_t)c->rank;
+    WDGS_CHECK_RCCL(g_rccl.GroupStart());
+    int e1 = g_rccl.ReduceScatter(g, g + r * slice_points * 14, (size_t)slice_points * 14, RCCL_FLOAT32, RCCL_SUM, c->comm, c->dev->stream);
+    int e2 = g_rccl.ReduceScatter(v, v + r * slice_points, (size_t)slice_points, RCCL_UINT32, RCCL_SUM, c->comm, c->dev->stream);
+    int e3 = flag ? g_rccl.AllReduce(flag, flag, 1, RCCL_UINT32, RCCL_SUM, c->comm, c->dev->stream) : RCCL_SUCCESS;
+    WDGS_CHECK_RCCL(g_rccl.GroupEnd());
+    WDGS_CHECK_RCCL(e1);
+    WDGS_CHECK_RCCL(e2);
+    WDGS_CHECK_RCCL(e3);
+    return WDGS_OK;
+}
+
+// In place: rows[world_size*slice_points][8 u32]; every rank contributes its own slice and receives the others'.
+int wdgs_comm_allgather_rows(wdgs_comm* c, void* rows, uint32_t slice_points) {
+    WDGS_REQUIRE(c && rows, WDGS_E_INVALID, "wdgs_comm_allgather_rows: null argument");
+    if (slice_points == 0) return WDGS_OK;
+    u32* p = (u32*)rows;
+    WDGS_CHECK_RCCL(g_rccl.AllGather(p + (size_t)c->rank * slice_points * 8, p, (size_t)slice_points * 8, RCCL_UINT32, c->comm, c->dev->stream));
+    return WDGS_OK;
+}
+
+// In place broadcast of `bytes` bytes at `ptr` from `root` (the slice-owned optimizer state is gathered with one call per owner
+// and array before a densify rebuild or an export).
+int wdgs_comm_broadcast(wdgs_comm* c, void* ptr, size_t bytes, int root) {
+    WDGS_REQUIRE(c && (bytes == 0 || ptr), WDGS_E_INVALID, "wdgs_comm_broadcast: null argument");
+    WDGS_REQUIRE(root >= 0 && root < c->world_size, WDGS_E_INVALID, "wdgs_comm_broadcast: root %d outside world of %d", root, c->world_size);
+    if (bytes == 0) return WDGS_OK;
+    WDGS_CHECK_RCCL(g_rccl.Broadcast(ptr, ptr, bytes, RCCL_UINT8, root, c->comm, c->dev->stream));
+    return WDGS_OK;
+}
+int wdgs_comm_group_start(void) {
+    WDGS_TRY(rccl_load());
+    WDGS_CHECK_RCCL(g_rccl.GroupStart());
+    return WDGS_OK;
+}
+int wdgs_comm_group_end(void) {
+    WDGS_TRY(rccl_load());
+    WDGS_CHECK_RCCL(g_rccl.GroupEnd());
     return WDGS_OK;
 }
 

@@ -39,9 +39,11 @@ WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
 }
 
 // Adam on one Gaussian's 14 trained scalars (SH: DC only) followed by the fp16 re-pack of that Gaussian.
+// rows_out (nullable): the re-packed row -- 6 Gaussian words, SH word 0, low half of SH word 1 -- also goes to rows_out[idx*8 ..],
+// the 32-byte form in which a data-parallel rank publishes the Gaussians it owns (wdgs_comm_allgather_rows).
 WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_pos,
                             float4* __restrict__ opt_rot, float4* __restrict__ opt_scale, float* __restrict__ opt_opacity,
-                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer) {
+                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ rows_out = nullptr) {
     float4 P = opt_pos[(size_t)idx * 3];
     float4 R = opt_rot[(size_t)idx * 3];
     float4 S = opt_scale[(size_t)idx * 3];
@@ -103,26 +105,40 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
     // payload could change, which WGSL leaves implementation-defined), so not touching it is the same result -- without fetching
     // the 96-byte row's cache line just to copy 2 bytes back (it was 19 % of this kernel's HBM traffic).
     u32* shp = sh_buffer + (size_t)idx * 24;
-    shp[0] = wd_pack2(c0, c1);
-    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)wd_f16bits(c2);
+    const u32 sh0 = wd_pack2(c0, c1), sh1lo = wd_f16bits(c2) & 0xFFFFu;
+    shp[0] = sh0;
+    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)sh1lo;
+    if (rows_out) {
+        uint4* ro = reinterpret_cast<uint4*>(rows_out + (size_t)idx * 8);
+        ro[0] = make_uint4(wd_pack2(P.x, P.y), wd_pack2(P.z, op), wd_pack2(R.x, R.y), wd_pack2(R.z, R.w));
+        ro[1] = make_uint4(wd_pack2(S.x, S.y), wd_pack2(S.z, 0.0f), sh0, sh1lo);
+    }
 }
 
+// guard (nullable): a device word that, when non-zero at execution time, turns the whole step into a no-op -- the forward pass's
+// overflow word (its tile-entry list was truncated: gradients are incomplete), so a step that is going to be reported as
+// WDGS_E_CAPACITY does not first corrupt the optimizer state.
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
                                                            const u32* __restrict__ gradients, float4* opt_pos, float4* opt_rot, float4* opt_scale,
-                                                           float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer) {
+                                                           float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer, const u32* __restrict__ guard) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
+    if (guard && *guard != 0u) return;
     const bool update = tile_counts[idx] != 0u;
     Grad14 g = {};
     if (update) g = unpack_gradient(gradients, idx);
     adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer);
 }
 
-__global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
+// Gaussians [first, first + count): the slice a data-parallel rank owns (first = 0, count = n on a single GPU).
+__global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 count, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
                                                                const float* __restrict__ grad_f32, float4* opt_pos, float4* opt_rot,
-                                                               float4* opt_scale, float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer) {
-    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+                                                               float4* opt_scale, float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer,
+                                                               const u32* __restrict__ guard, u32* __restrict__ rows_out) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    if (guard && *guard != 0u) return;
+    const u32 idx = first + t;
     const bool update = visible[idx] != 0u;
     Grad14 g = {};
     if (update) {
@@ -132,7 +148,31 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 n, wdgs_adam_h
         g.scale[0] = gp[8]; g.scale[1] = gp[9]; g.scale[2] = gp[10];
         g.color[0] = gp[11]; g.color[1] = gp[12]; g.color[2] = gp[13];
     }
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer);
+    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer, rows_out);
+}
+
+// Rows published by the other ranks (wdgs_comm_allgather_rows) -> this replica's point cloud: every Gaussian outside
+// [skip_first, skip_first + skip_count), which this rank re-packed itself.
+__global__ __launch_bounds__(256) void apply_rows_kernel(u32 n, const u32* __restrict__ rows, u32 skip_first, u32 skip_count, const u32* __restrict__ guard,
+                                                          u32* __restrict__ gaussians, u32* __restrict__ sh_buffer) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n || (idx >= skip_first && idx - skip_first < skip_count)) return;
+    if (guard && *guard != 0u) return;
+    const uint4* ri = reinterpret_cast<const uint4*>(rows + (size_t)idx * 8);
+    const uint4 a = ri[0], b = ri[1];
+    u32* gp = gaussians + (size_t)idx * 6;
+    *reinterpret_cast<uint2*>(gp) = make_uint2(a.x, a.y);
+    *reinterpret_cast<uint2*>(gp + 2) = make_uint2(a.z, a.w);
+    *reinterpret_cast<uint2*>(gp + 4) = make_uint2(b.x, b.y);
+    u32* shp = sh_buffer + (size_t)idx * 24;
+    shp[0] = b.z;
+    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)(b.w & 0xFFFFu);
+}
+
+// flag = (overwrite ? 0 : flag) | (src != 0): folds per-view overflow words into the one guard word of a batched step
+__global__ void guard_accumulate_kernel(u32* __restrict__ flag, const u32* __restrict__ src, u32 overwrite) {
+    const u32 prev = overwrite ? 0u : *flag;
+    *flag = prev | (*src != 0u ? 1u : 0u);
 }
 
 // reference layout -> compact DC copy
@@ -218,19 +258,35 @@ __global__ __launch_bounds__(256) void unpack_kernel(u32 n, const u32* __restric
 }  // namespace
 
 int launch_adam_repack(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* tile_counts, const void* gradients,
-                       const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh) {
+                       const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack", adam_repack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)tile_counts, (const u32*)gradients,
-                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh);
+                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh,
+                (const u32*)guard);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_adam_repack_f32(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
-                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh) {
+int launch_adam_repack_f32(wdgs_device* dev, u32 first, u32 count, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
+                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* rows_out) {
+    if (count == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, first, count, h, (const u32*)visible,
+                (const float*)grad_f32, (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians,
+                (u32*)sh, (const u32*)guard, (u32*)rows_out);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_apply_rows(wdgs_device* dev, u32 n, const void* rows, u32 skip_first, u32 skip_count, const void* guard, void* gaussians, void* sh) {
     if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)visible, (const float*)grad_f32,
-                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh);
+    WDGS_LAUNCH(dev, "apply_repacked_rows", apply_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)rows, skip_first, skip_count,
+                (const u32*)guard, (u32*)gaussians, (u32*)sh);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_guard_accumulate(wdgs_device* dev, void* flag, const void* src, u32 overwrite) {
+    WDGS_LAUNCH(dev, "guard_accumulate", guard_accumulate_kernel, dim3(1), dim3(1), 0, (u32*)flag, (const u32*)src, overwrite);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -191,7 +191,7 @@ __global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, cons
         if (host_mirror) {  // pinned host memory: the host's per-step overflow check and stats read need no copy
             host_mirror[0] = min(total, capacity);
             host_mirror[1] = v;
-            host_mirror[2] = (total > capacity) ? total : 0u;
+            if (total > capacity) host_mirror[2] = total;  // sticky until the host check clears it (scan.hip)
             host_mirror[3] = 0u;
         }
         // a wrapped scan (sum >= 2^32) also shows as an offset going backwards; tile counts are <= 2048 each, so

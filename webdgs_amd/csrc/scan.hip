@@ -93,7 +93,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __re
         if (threadIdx.x == 0) {
             const u32 entries = min(carry, ep.capacity), overflow = (carry > ep.capacity) ? carry : 0u;  // consumers only touch [0, capacity)
             ep.stats[0] = entries; ep.stats[1] = vis; ep.stats[2] = overflow;
-            if (ep.host_mirror) { ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u; }
+            if (ep.host_mirror) {  // word 2 is STICKY: set on overflow, cleared only by the host check, so no view of a multi-view step can hide another's overflow
+                ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; if (overflow) ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u;
+            }
         }
     }
 }

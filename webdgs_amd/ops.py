@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check
+from ._lib import CapacityError, StateError, WdgsError, check  # noqa: F401  (re-exported)
 
 
 # ----------------------------------------------------------------------------- device / buffers
@@ -588,6 +588,21 @@ class Optimizer:
         """Data-parallel step on fp32 gradients summed over views."""
         check(self.device.lib.wdgs_optimizer_step_f32(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradF32.ptr, visibleCounts.ptr))
 
+    def stepF32Range(self, encoder, coefficients: PointCloud, gradF32: HipBuffer, visibleCounts: HipBuffer, first: int, count: int,
+                     rowsOut: Optional[HipBuffer] = None) -> None:
+        """Adam + re-pack on Gaussians ``[first, first + count)`` -- the slice this rank owns after the reduce-scatter; ``rowsOut``
+        also receives the re-packed 32-byte rows for the all-gather."""
+        check(self.device.lib.wdgs_optimizer_step_f32_range(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradF32.ptr,
+                                                            visibleCounts.ptr, int(first), int(count), rowsOut.ptr if rowsOut is not None else None))
+
+    def setGuard(self, flagBuffer: Optional[HipBuffer], offset: int = 0) -> None:
+        """While the u32 at ``flagBuffer + offset`` is non-zero at execution time, ``step*`` leave every buffer untouched."""
+        check(self.device.lib.wdgs_optimizer_set_guard(self.handle, (flagBuffer.ptr + offset) if flagBuffer is not None else None))
+
+    def stateChanged(self) -> None:
+        """The state arrays were rewritten from outside (slices gathered from other ranks): refresh internal copies."""
+        check(self.device.lib.wdgs_optimizer_state_changed(self.handle))
+
     def destroy(self) -> None:
         if self.destroyed:
             return
@@ -603,6 +618,18 @@ def accumulateGradients(device: HipDevice, numPoints: int, gradientsBuffer: HipB
 def storeGradients(device: HipDevice, numPoints: int, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer, accF32: HipBuffer, visibleCounts: HipBuffer) -> None:
     """Overwrite form of ``accumulateGradients`` for the first view of a batch (no clearing pass needed before it)."""
     check(device.lib.wdgs_store_gradients(device.handle, int(numPoints), gradientsBuffer.ptr, tileCountsBuffer.ptr, accF32.ptr, visibleCounts.ptr))
+
+
+def guardAccumulate(device: HipDevice, flag: HipBuffer, src: HipBuffer, srcOffset: int = 0, overwrite: bool = False) -> None:
+    """``flag = (overwrite ? 0 : flag) | (src != 0)``: folds per-view overflow words into the guard word of a batched step."""
+    check(device.lib.wdgs_guard_accumulate(device.handle, flag.ptr, src.ptr + srcOffset, 1 if overwrite else 0))
+
+
+def applyRepackedRows(device: HipDevice, numPoints: int, rows: HipBuffer, skipFirst: int, skipCount: int, guard: Optional[HipBuffer],
+                      pointCloud: PointCloud) -> None:
+    """Writes the rows the other ranks published (all-gather) into this replica's point cloud, skipping the own slice."""
+    check(device.lib.wdgs_apply_repacked_rows(device.handle, int(numPoints), rows.ptr, int(skipFirst), int(skipCount), guard.ptr if guard is not None else None,
+                                              pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr))
 
 
 # ----------------------------------------------------------------------------- DensifyPrunePass

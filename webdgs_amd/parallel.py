@@ -1,15 +1,21 @@
 """View-sharded data parallelism over RCCL/xGMI; the reference has none (batch 1, one GPUDevice).
 
-One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm; ``gloo`` in CPU tests).  Every rank holds
-a full replica of the point cloud and optimizer state.  A global step processes ``world_size * views_per_rank`` views:
-each rank renders and back-propagates its own views, sums the per-view fp16 gradients into one fp32 block locally
-(after K17, so per-view values are exactly the reference's), then ONE all-reduce (sum) of that block plus the u32
-visibility counts precedes a single Adam step that every rank applies identically -- replicas stay bit-identical
-because all ranks consume the same reduced buffer.  Batch semantics (new; reduce to the reference at batch 1):
-``g = sum_views g_view``; Adam runs where ``sum_views (tile_counts > 0) > 0``.
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm; ``gloo`` in CPU tests and 1-GPU rehearsals).  Every
+rank holds a full replica of the point cloud.  A global step processes ``world_size * views_per_rank`` views: each rank renders and
+back-propagates its own views and sums the per-view fp16 gradients into one fp32 block locally (after K17, so per-view values are
+exactly the reference's).  Then the bandwidth-optimal exchange:
 
-Payload: 14 f32 + 1 u32 = 60 B per Gaussian (c3: 60 MB): one fp32 all-reduce of the gradient block and one int32
-all-reduce of the visibility counts (4 B per Gaussian) -- integer so the mask is exact for any number of views.
+    reduce-scatter (sum) of the block + visibility counts   -> rank r holds the sums for ITS slice of the Gaussians
+    Adam + re-pack on the owned slice only                   -> 1/world_size of the optimizer pass per rank
+    all-gather of the re-packed 32-byte rows                 -> every replica's point cloud is current again
+
+Batch semantics (new; reduce to the reference at batch 1): ``g = sum_views g_view``; Adam runs where
+``sum_views (tile_counts > 0) > 0``.  Optimizer state of a slice lives on its owner and is gathered (``Exchange.broadcast``) only
+before a densify rebuild or an export.  Per step and rank: (W-1)/W x (60 + 32) bytes per Gaussian (c3, W = 8: 80 MB) instead of
+the all-reduce's 2 (W-1)/W x 60 (105 MB).
+
+``Exchange`` is the seam: ``TorchExchange`` drives ``torch.distributed`` (stream-ordered on nccl, host-fenced on gloo),
+``CapiExchange`` drives the library's own communicator (``wdgs_comm_*``, RCCL on the kernels' stream) for hosts without torch.
 """
 from __future__ import annotations
 
@@ -73,6 +79,188 @@ def shutdown() -> None:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+def slice_points(num_points: int, world: int) -> int:
+    """Gaussians per rank: ceil(N / world) rounded up to 64 (rank r owns ``[r*slice, min((r+1)*slice, N))``)."""
+    per = (max(int(num_points), 1) + world - 1) // world
+    return (per + 63) // 64 * 64
+
+
+def owned_range(num_points: int, world: int, rank: int) -> tuple[int, int]:
+    """(first, count) of the slice ``rank`` owns."""
+    sl = slice_points(num_points, world)
+    first = min(rank * sl, num_points)
+    return first, max(0, min((rank + 1) * sl, num_points) - first)
+
+
+class _RawCuda:
+    """Zero-copy view of library-owned device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str):
+        self.__cuda_array_interface__ = dict(shape=(int(count),), typestr=typestr, data=(int(ptr), False), version=2)
+
+
+def _tensor_at(device, ptr: int, count: int, dtype: torch.dtype) -> torch.Tensor:
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+    return torch.as_tensor(_RawCuda(ptr, count, typestr), device=device.torch_device)
+
+
+class Exchange:
+    """What the Trainer needs from a communicator.  Pointers are device addresses; counts are elements."""
+
+    world_size, rank = 1, 0
+    name = "none"
+
+    def exchange_gradients(self, grad_ptr: int, visible_ptr: int, flag_ptr: int, slice_pts: int) -> None:
+        """Reduce-scatter (sum) grad f32[W*slice*14] and visible u32[W*slice] in place (rank r's slice ends up summed) and sum the
+        one-word flag over all ranks."""
+
+    def allgather_rows(self, rows_ptr: int, slice_pts: int) -> None:
+        """In-place all-gather of u32[W*slice*8]: every rank contributes its slice."""
+
+    def broadcast(self, ptr: int, nbytes: int, root: int) -> None:
+        """In-place broadcast of ``nbytes`` at ``ptr`` from ``root``."""
+
+    def allreduce_counts(self, ptr: int, count: int) -> None:
+        """In-place u32 sum."""
+
+    def barrier(self) -> None:
+        pass
+
+    def destroy(self) -> None:
+        pass
+
+
+class TorchExchange(Exchange):
+    """``torch.distributed`` as the transport.  On ``nccl`` (= RCCL) every collective is enqueued behind the work already on the
+    device's stream -- the Trainer's HIP stream IS torch's current stream (``HipDevice``), c10d orders its own stream after the
+    current one on entry and the current one after its own on exit -- so there is no host synchronisation anywhere in a step.
+    ``gloo`` (CPU tests; several ranks on one GPU) stages device tensors through the host on streams of its own: there both sides of
+    every collective are fenced on the host (``fenced``), and reduce-scatter is emulated by an all-reduce (gloo has none)."""
+
+    def __init__(self, device, group=None, force: bool = False):
+        self.device, self.group = device, group
+        self.force = bool(force)  # issue the collectives even in a world of one (identities): exercises the backend on a 1-GPU box
+        self._views: dict = {}
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.fenced = self.backend != "nccl" or os.environ.get("WDGS_DP_FENCE", "") == "1"
+        self.name = f"torch.distributed/{self.backend}" + ("+host-fences" if self.fenced else "")
+
+    def _t(self, ptr: int, count: int, dtype: torch.dtype) -> torch.Tensor:
+        key = (int(ptr), int(count), dtype)
+        t = self._views.get(key)
+        if t is None:
+            if len(self._views) > 64:
+                self._views.clear()
+            t = self._views[key] = _tensor_at(self.device, ptr, count, dtype)
+        return t
+
+    def _idle(self) -> bool:
+        return self.world_size <= 1 and not self.force
+
+    def _pre(self):
+        if self.fenced:
+            self.device.torch_stream.synchronize()
+
+    def _post(self):
+        if self.fenced:
+            torch.cuda.synchronize(self.device.torch_device)
+
+    def exchange_gradients(self, grad_ptr, visible_ptr, flag_ptr, slice_pts):
+        if self._idle():
+            return
+        w, r = self.world_size, self.rank
+        g = self._t(grad_ptr, w * slice_pts * GRAD_FLOATS, torch.float32)
+        v = self._t(visible_ptr, w * slice_pts, torch.int32)
+        f = self._t(flag_ptr, 1, torch.int32)
+        self._pre()
+        if self.backend == "nccl":
+            dist.reduce_scatter_tensor(g[r * slice_pts * GRAD_FLOATS:(r + 1) * slice_pts * GRAD_FLOATS], g, op=dist.ReduceOp.SUM, group=self.group)
+            dist.reduce_scatter_tensor(v[r * slice_pts:(r + 1) * slice_pts], v, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group)
+        self._post()
+
+    def allgather_rows(self, rows_ptr, slice_pts):
+        if self._idle():
+            return
+        w, r = self.world_size, self.rank
+        t = self._t(rows_ptr, w * slice_pts * 8, torch.int32)
+        mine = t[r * slice_pts * 8:(r + 1) * slice_pts * 8]
+        self._pre()
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(t, mine, group=self.group)
+        else:
+            dist.all_gather([t[i * slice_pts * 8:(i + 1) * slice_pts * 8] for i in range(w)], mine.clone(), group=self.group)
+        self._post()
+
+    def broadcast(self, ptr, nbytes, root):
+        if self._idle() or nbytes == 0:
+            return
+        self._pre()
+        dist.broadcast(self._t(ptr, nbytes, torch.uint8), src=root, group=self.group)
+        self._post()
+
+    def allreduce_counts(self, ptr, count):
+        if self._idle() or count == 0:
+            return
+        self._pre()
+        dist.all_reduce(self._t(ptr, count, torch.int32), op=dist.ReduceOp.SUM, group=self.group)
+        self._post()
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier(group=self.group)
+
+
+class CapiExchange(Exchange):
+    """The library's own communicator (``wdgs_comm_*``): RCCL calls queued on the device's stream by libwebdgs_hip.so itself --
+    the path a TypeScript / C++ host uses (no torch in the loop).  The unique id travels over the torch process group here."""
+
+    def __init__(self, device, group=None):
+        self.device = device
+        self.comm = Communicator.fromProcessGroup(device, group)
+        self.world_size, self.rank = self.comm.world_size, self.comm.rank
+        self.name = "wdgs_comm (RCCL on the device stream)"
+        self.force = True  # the communicator exists: its collectives run (identities in a world of one)
+        self._group = group
+
+    def exchange_gradients(self, grad_ptr, visible_ptr, flag_ptr, slice_pts):
+        from . import _lib
+        _lib.check(self.device.lib.wdgs_comm_exchange_gradients(self.comm.handle, grad_ptr, visible_ptr, flag_ptr, int(slice_pts)))
+
+    def allgather_rows(self, rows_ptr, slice_pts):
+        from . import _lib
+        _lib.check(self.device.lib.wdgs_comm_allgather_rows(self.comm.handle, rows_ptr, int(slice_pts)))
+
+    def broadcast(self, ptr, nbytes, root):
+        from . import _lib
+        _lib.check(self.device.lib.wdgs_comm_broadcast(self.comm.handle, ptr, int(nbytes), int(root)))
+
+    def allreduce_counts(self, ptr, count):
+        from . import _lib
+        _lib.check(self.device.lib.wdgs_comm_allreduce_counts(self.comm.handle, ptr, int(count)))
+
+    def barrier(self):
+        if dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            dist.barrier(group=self._group)
+
+    def destroy(self):
+        self.comm.destroy()
+
+
+def default_exchange(device, world_size: int) -> Exchange:
+    """``WDGS_COMM=capi`` selects the C-ABI communicator; otherwise torch.distributed when a process group exists."""
+    if os.environ.get("WDGS_COMM", "") == "capi":
+        return CapiExchange(device)
+    if world_size > 1 or dist.is_initialized():
+        return TorchExchange(device)
+    return Exchange()
 
 
 class Communicator:

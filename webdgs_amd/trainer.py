@@ -23,12 +23,18 @@ from . import loaders, ops, parallel
 
 class Trainer:
     def __init__(self, device: ops.HipDevice, trainingConfig: Optional[dict] = None, seed: int = 0, world_size: int = 1, rank: int = 0,
-                 views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True):
+                 views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True, exchange: Optional[parallel.Exchange] = None):
         self.device = device
         self.trainingConfig = dict(trainingConfig or dict(lambda_l1=0.8, lambda_l2=0.0, lambda_dssim=0.2))  # trainer.ts:100-104
         self.optimizerHyperparameters = dict(ops.DEFAULT_ADAM_HYPERPARAMETERS)
         self.world_size, self.rank, self.views_per_rank = int(world_size), int(rank), max(1, int(views_per_rank))
         self.maxTileEntries = int(maxTileEntries)
+        # the transport of the data-parallel exchange (parallel.Exchange); world_size == 1 needs none
+        self.exchange = exchange if exchange is not None else (parallel.default_exchange(device, self.world_size) if self.world_size > 1 else parallel.Exchange())
+        # sliced step (reduce-scatter / owned-slice Adam / all-gather): any real exchange, also a forced one in a world of one
+        self._sliced = self.world_size > 1 or bool(getattr(self.exchange, "force", False))
+        if self.world_size > 1 and (self.exchange.world_size, self.exchange.rank) != (self.world_size, self.rank):
+            raise ValueError(f"exchange is rank {self.exchange.rank} of {self.exchange.world_size}, trainer is rank {self.rank} of {self.world_size}")
         # Recorded command buffers (HIP graphs), one per view set: the reference re-records its encoder every step; here the
         # recording is kept and re-submitted, because every size the kernels need is read on the device.
         self.use_command_buffers = bool(use_command_buffers)
@@ -62,8 +68,14 @@ class Trainer:
             metricViews=10, metricDownscale=2, metricThreshold=0.5, maxBufferBytes=128 * 1024 * 1024, maxNewPointsPerStep=5000,
             pruneOpacity=0.01, cloneThresholdCount=500, splitScaleThreshold=1.0)
         self.densifyPrune = ops.DensifyPrunePass(device, self._densify_op_config())
+        # batched / data-parallel step (parallel.py): fp32 gradient block, visibility counts, re-packed rows, guard word
         self._dp_grad: Optional[ops.HipBuffer] = None
         self._dp_visible: Optional[ops.HipBuffer] = None
+        self._dp_rows: Optional[ops.HipBuffer] = None
+        self._dp_flag: Optional[ops.HipBuffer] = None
+        self._state_sliced = False  # optimizer state of non-owned slices is stale until syncOptimizerState()
+        self.exchange_timing = False  # bracket the collectives with events on the device stream (bench.py)
+        self._exchange_events: list = []
 
     # ------------------------------------------------------------------ configuration
     def _densify_op_config(self) -> dict:
@@ -102,15 +114,15 @@ class Trainer:
         if old is not None and old is not self.pointCloud:
             old.gaussian_3d_buffer.destroy()
             old.sh_buffer.destroy()
-        self._dp_grad = self._dp_visible = None
+        self._dp_grad = self._dp_visible = self._dp_rows = self._dp_flag = None
+        self._state_sliced = False
         self._invalidate_command_buffers()
         self.ensurePipelines(self.lastViewportWidth, self.lastViewportHeight)
 
     def _invalidate_command_buffers(self) -> None:
         """Recorded kernels bake pointers, viewport, hyper-parameters and loss weights: any change drops the recordings."""
-        for cmds in self._cmd_cache.values():
-            for c in cmds:
-                c.destroy()
+        for c in self._cmd_cache.values():
+            c.destroy()
         self._cmd_cache = {}
         self._eager_steps = 0
 
@@ -219,6 +231,9 @@ class Trainer:
             self.backwardPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
         else:
             self.backwardPass.setViewport(w, h)
+        if self.optimizer is not None and self.world_size * self.views_per_rank == 1:
+            # a step whose tile-entry list overflowed is skipped on the device (and reported by the next synchronize)
+            self.optimizer.setGuard(self.forwardPass.getStatsBuffer(), 8)
 
     def ensureMetricsPipelines(self, baseWidth: int, baseHeight: int) -> tuple[int, int]:
         down = max(1, int(self.densifyPruneConfig["metricDownscale"]))
@@ -278,10 +293,14 @@ class Trainer:
         if not self.use_command_buffers or not self.isTraining or self.pointCloud is None:
             return 0
         n_views, taken = self.world_size * self.views_per_rank, 0
+
+        def recorded(v: int) -> bool:
+            if n_views == 1:
+                return ("step", v) in self._cmd_cache
+            return ("view", v, True) in self._cmd_cache and (self.views_per_rank == 1 or ("view", v, False) in self._cmd_cache)
         for v in range(len(self.trainCameras)):
-            ids = [v] * n_views
-            while tuple(parallel.shard_views(ids, self.rank, self.world_size)) not in self._cmd_cache and taken < 4 * len(self.trainCameras) + 4:
-                self.step(ids)
+            while not recorded(v) and taken < 4 * len(self.trainCameras) + 4:  # (every rank walks the same list: collectives stay matched)
+                self.step([v] * n_views)
                 taken += 1
         return taken
 
@@ -303,30 +322,19 @@ class Trainer:
         warmup, interval, stop = s["warmupIterations"], max(1, s["interval"]), s["stopIterations"]
         shouldDensify = s["enabled"] and warmup <= nextIteration <= stop and (nextIteration == warmup or (nextIteration - warmup) % interval == 0)
 
-        key = tuple(mine)
-        cmds = self._cmd_cache.get(key)
-        if cmds is None:
-            # the first steps run eagerly (they allocate textures); afterwards each view set is recorded once and replayed
-            record = self.use_command_buffers and self._eager_steps >= 1
-            try:
-                cmds = self._encode_and_submit_step(mine, n_views, record)
-            except BaseException:
-                # a failed encode (capacity, first-use allocation inside a recording, a Python error) must not leave the stream in
-                # capture mode or half-recorded command buffers behind: drop the recording and fall back to a clean eager state
-                self.device.lib.wdgs_encoder_abort(self.device.handle)
-                self._invalidate_command_buffers()
-                raise
-            if record:
-                self._cmd_cache[key] = cmds
+        try:
+            if n_views == 1:
+                self._step_single_view(mine[0])
             else:
-                self._eager_steps += 1
-        else:
-            self.device.queue.submit([cmds[0]])
-            if len(cmds) > 1:
-                self._allreduce()
-                self.device.queue.submit([cmds[1]])
-            self.optimizer.advanceIteration(1)
-        self.device.queue.onSubmittedWorkDone()
+                self._step_batched(mine)
+        except BaseException:
+            # a failed encode (capacity, first-use allocation inside a recording, a Python error) must not leave the stream in
+            # capture mode or half-recorded command buffers behind: drop the recording and fall back to a clean eager state
+            if self.device.handle:
+                self.device.lib.wdgs_encoder_abort(self.device.handle)
+            self._invalidate_command_buffers()
+            raise
+        self._finish_step(n_views)
 
         self.iteration += 1
         self.stepMs = (time.perf_counter() - stepStart) * 1000.0
@@ -340,33 +348,111 @@ class Trainer:
         if self.iteration >= self.maxIterations:
             self.stop()
 
-    def _encode_and_submit_step(self, mine: list, n_views: int, record: bool) -> list:
-        """Encodes (eagerly, or into command buffers when ``record``) and submits one global step; returns the command buffers."""
+    def _run(self, key: tuple, encode) -> bool:
+        """Submits the command buffer recorded under ``key``; the first time, ``encode(encoder)`` is encoded -- eagerly while the
+        pipelines still allocate on first use, into a recorded command buffer (HIP graph) afterwards.  True if it was replayed."""
+        cmd = self._cmd_cache.get(key)
+        if cmd is not None:
+            self.device.queue.submit([cmd])
+            return True
+        record = self.use_command_buffers and self._eager_steps >= 1
+        with self.device.createCommandEncoder("trainer-" + str(key[0]), record=record) as encoder:
+            encode(encoder)
+            cmd = encoder.finish()
+        if record:
+            self._cmd_cache[key] = cmd
+        self.device.queue.submit([cmd])
+        return False
+
+    def _step_single_view(self, view: int) -> None:
+        """The reference's step (trainer.ts:603-645): one view, Adam straight from the packed fp16 gradients."""
         tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
-        if n_views == 1:
-            with self.device.createCommandEncoder("trainer-step", record=record) as encoder:
-                self._encode_view(encoder, mine[0])
-                self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
-                cmds = [encoder.finish()]
-            self.device.queue.submit(cmds)
-            return cmds
-        n = self.pointCloud.num_points
-        if self._dp_grad is None:  # (allocated before any recording is opened)
-            self._dp_grad = self.device.createBuffer(4 * parallel.GRAD_FLOATS * n, "dp-grad-f32")
-            self._dp_visible = self.device.createBuffer(4 * n, "dp-visible")
-        with self.device.createCommandEncoder("trainer-step", record=record) as encoder:
-            for k, v in enumerate(mine):  # the first view overwrites the fp32 block (no clearing pass), the others add to it
+
+        def encode(encoder):
+            self._encode_view(encoder, view)
+            self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
+        if self._run(("step", view), encode):
+            self.optimizer.advanceIteration(1)
+        elif not self.use_command_buffers or self._eager_steps < 1:
+            self._eager_steps += 1
+
+    def _step_batched(self, mine: list) -> None:
+        """[views -> fp32 block] -> exchange -> [Adam on the owned slice] -> all-gather -> [apply the other ranks' rows].  One
+        recorded command buffer per (view, first-of-batch?) plus one each for Adam and apply, whatever the batch's composition."""
+        n, w = self.pointCloud.num_points, self.world_size
+        sl = parallel.slice_points(n, w)
+        if self._dp_grad is None:  # (allocated before any recording is opened; sized world*slice so the collectives run in place)
+            self._dp_grad = self.device.createBuffer(4 * parallel.GRAD_FLOATS * w * sl, "dp-grad-f32")
+            self._dp_visible = self.device.createBuffer(4 * w * sl, "dp-visible")
+            self._dp_flag = self.device.createBuffer(16, "dp-guard")
+            self._dp_rows = self.device.createBuffer(32 * w * sl, "dp-repacked-rows") if self._sliced else None
+            self.optimizer.setGuard(self._dp_flag, 0)
+        first, count = parallel.owned_range(n, w, self.rank)
+        tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
+        stats = self.forwardPass.getStatsBuffer()
+        eager_before = self._eager_steps
+        for k, v in enumerate(mine):  # the first view overwrites the fp32 block (no clearing pass), the others add to it
+            def encode_view(encoder, v=v, k=k):
                 self._encode_view(encoder, v)
                 (ops.storeGradients if k == 0 else ops.accumulateGradients)(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts,
                                                                             self._dp_grad, self._dp_visible)
-            first = encoder.finish()
-        self.device.queue.submit([first])
-        self._allreduce()
-        with self.device.createCommandEncoder("trainer-step-adam", record=record) as encoder2:
-            self.optimizer.stepF32(encoder2, self.pointCloud, self._dp_grad, self._dp_visible)
-            second = encoder2.finish()
-        self.device.queue.submit([second])
-        return [first, second]
+                ops.guardAccumulate(self.device, self._dp_flag, stats, 8, overwrite=(k == 0))
+            self._run(("view", v, k == 0), encode_view)
+        self._timed(lambda: self.exchange.exchange_gradients(self._dp_grad.ptr, self._dp_visible.ptr, self._dp_flag.ptr, sl))
+        if self._run(("adam",), lambda encoder: self.optimizer.stepF32Range(encoder, self.pointCloud, self._dp_grad, self._dp_visible, first, count, self._dp_rows)):
+            self.optimizer.advanceIteration(1)
+        if self._sliced:
+            self._timed(lambda: self.exchange.allgather_rows(self._dp_rows.ptr, sl))
+            self._run(("apply",), lambda encoder: ops.applyRepackedRows(self.device, n, self._dp_rows, first, count, self._dp_flag, self.pointCloud))
+            self._state_sliced = w > 1
+        if not self.use_command_buffers or eager_before < 1:
+            self._eager_steps += 1
+
+    def _timed(self, collective) -> None:
+        if not self.exchange_timing:
+            collective()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(self.device.torch_stream)
+        collective()
+        e1.record(self.device.torch_stream)
+        self._exchange_events.append((e0, e1))
+
+    def exchangeMilliseconds(self) -> float:
+        """Device time spent between the events bracketing the collectives since ``exchange_timing`` was switched on (synchronises)."""
+        self.device.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._exchange_events)
+        self._exchange_events = []
+        return float(ms)
+
+    def _finish_step(self, n_views: int) -> None:
+        """``await onSubmittedWorkDone()`` (trainer.ts:639-645) + the deferred capacity check.  In a batched step the guard word was
+        summed over all ranks by the exchange, so every rank sees the same value and all of them raise together."""
+        err = None
+        try:
+            self.device.queue.onSubmittedWorkDone()
+        except ops.CapacityError as e:
+            err = e
+        if n_views > 1 and self._dp_flag is not None and int(self._dp_flag.read(np.uint32, count=1)[0]) != 0:
+            raise err or ops.CapacityError(-3, "tile entries overflowed on another rank: the step was skipped on every rank")
+        if err is not None:
+            raise err
+
+    def syncOptimizerState(self) -> None:
+        """Brings every rank's optimizer state up to date: after sliced steps a rank holds current (param, m, v) only for the
+        Gaussians it owns; each owner broadcasts its slice of the six state arrays.  A no-op on one rank.  Called before a
+        densify rebuild; call it before reading ``optimizer.getStateBuffers()`` in a multi-rank run."""
+        if not self._state_sliced or self.world_size <= 1:
+            return
+        n, w = self.pointCloud.num_points, self.world_size
+        bufs = self.optimizer.getStateBuffers()  # flushes the compact SH-DC copy into paramSH / stateSH first
+        rows = dict(optPosBuffer=48, optRotBuffer=48, optScaleBuffer=48, optOpacityBuffer=12, paramSH=192, stateSH=384)
+        for root in range(w):
+            first, count = parallel.owned_range(n, w, root)
+            for k, rb in rows.items():
+                self.exchange.broadcast(bufs[k].ptr + first * rb, count * rb, root)
+        self.optimizer.stateChanged()
+        self._state_sliced = False
 
     def destroy(self) -> None:
         """Deterministic teardown: command buffers, then every op, then the buffers this trainer allocated.  The device itself
@@ -380,24 +466,10 @@ class Trainer:
             if op is not None:
                 op.destroy()
             setattr(self, name, None)
-        self._dp_grad = self._dp_visible = self.metricsTarget = None
+        self._dp_grad = self._dp_visible = self._dp_rows = self._dp_flag = self.metricsTarget = None
         self._camera_buffers = []
         self.pointCloud = None
         self.isTraining = False
-
-    def _allreduce(self) -> None:
-        if self.world_size <= 1:
-            return
-        n = self.pointCloud.num_points
-        g = self._dp_grad.tensor().view(torch.float32)[: parallel.GRAD_FLOATS * n]
-        vis = self._dp_visible.tensor()[:n]
-        # Host-side fences on both sides of the exchange instead of cross-stream event waits: the collective runs on the
-        # process group's own stream, and a 2-rank rehearsal on one GPU (gloo, ranks in lock-step) showed the Adam launch
-        # that follows overtaking the copy-back of the reduced block when ordered by stream-wait-event alone.  Two fences
-        # cost ~20 us of a >1.3 ms step and make the order independent of the backend's stream handling.
-        self.device.torch_stream.synchronize()
-        parallel.allreduce_gradients(g, vis)
-        torch.cuda.synchronize(self.device.torch_device)
 
     # ------------------------------------------------------------------ densify / prune
     def runDensifyPruneMultiView(self) -> None:
@@ -432,15 +504,8 @@ class Trainer:
                                                                nContribTexture=self.metricsRasterizer.getNContribTextureView()), dict(clear=False))
         if usedViews == 0:
             return
-        if self.world_size > 1:
-            n = self.pointCloud.num_points
-            mc = self.metricsPass.getMetricCountsBuffer()
-            t = torch.empty(n, dtype=torch.int32, device=self.device.torch_device)
-            t.copy_(torch.from_numpy(mc.read(np.int32, count=n)))  # library-owned buffer -> torch tensor for the collective
-            self.device.torch_stream.synchronize()  # fences as in _allreduce
-            parallel.allreduce_counts(t)
-            torch.cuda.synchronize(self.device.torch_device)
-            mc.write(t.cpu().numpy())
+        if self.world_size > 1:  # u32 sum on the device, in place in the pass's own buffer (SURVEY 8(e) "Determinism")
+            self.exchange.allreduce_counts(self.metricsPass.getMetricCountsBuffer().ptr, self.pointCloud.num_points)
         self.metricsPass.normalizeMetricCounts(encoder, dict(divisor=usedViews))
         self.densifyPrune.ensureSize(self.pointCloud.num_points)
         prepared = self.densifyPrune.encodePrepare(encoder, dict(pointCloud=self.pointCloud, metricCountsBuffer=self.metricsPass.getMetricCountsBuffer()))
@@ -449,6 +514,7 @@ class Trainer:
         outN = min(outTotal, prepared["maxOutPoints"])
         if outN == 0 or outN == inN:
             return
+        self.syncOptimizerState()  # every rank rebuilds the whole cloud, so every rank needs the whole state
         outPointCloud = ops.allocatePointCloudLike(self.device, self.pointCloud, dict(numPoints=outN))
         outState = ops.allocateOptimizerStateBuffers(self.device, outN)
         self.densifyPrune.encodeScatter(encoder, dict(pointCloud=self.pointCloud, optimizerState=self.optimizer.getStateBuffers(),
