@@ -184,8 +184,18 @@ def test_tile_entry_overflow_is_a_hard_error(hip_device):
         pipe.fwd.encode(None)
         with pytest.raises(_lib.CapacityError):
             pipe.fwd.check()
+        hip_device.synchronize()  # the overflow word is consumed by the check that reported it
+        pipe.fwd.encode(None)
+        with pytest.raises(_lib.CapacityError):
+            hip_device.synchronize()  # the deferred check of queue.onSubmittedWorkDone reports it too
+        hip_device.synchronize()
+        # sticky across encodes: a later encode that fits must not hide an earlier one that overflowed (multi-view steps)
+        pipe.fwd.encode(None)
+        small = harness.HipPipeline(hip_device, harness.small_config("c1", num_points=50), g[:50], sh[:50], cam, max_tile_entries=4096)
+        small.fwd.encode(None)
         with pytest.raises(_lib.CapacityError):
             hip_device.synchronize()
+        small.destroy()
     finally:
         pipe.destroy()
     hip_device.synchronize()

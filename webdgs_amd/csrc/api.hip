@@ -34,6 +34,7 @@ int launch_metric_count(wdgs_device*, const RenderSettings&, u32, u32, const voi
 int launch_metric_normalize(wdgs_device*, u32, u32, void*);
 int launch_downsample(wdgs_device*, const void*, u32, u32, void*, u32, u32);
 
+int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges);
 extern "C" int wdgs_sorter_final_out_index(wdgs_sorter* s);
 extern "C" uint32_t wdgs_sorter_capacity(wdgs_sorter* s);
 
@@ -95,6 +96,12 @@ struct wdgs_tiled_forward {
     u32* depths;
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
     wdgs_sorter* sorter;
+    // Per-tile range table u32[tiles + 1].  The sort of tile-structured keys needs it half way (sort.hip, sort_segmented), so the
+    // forward pass builds it and the rasterizer -- which owns K12-K13 in the reference (tiled-rasterizer.ts:213-230) -- takes it over
+    // instead of searching the keys a second time.  Not valid after encode(skip_sort) or under compat_caps (plain 4-pass sort).
+    u32* ranges;
+    u32 ranges_capacity;
+    bool ranges_valid;
     bool encoded;
 };
 
@@ -104,7 +111,8 @@ struct wdgs_tiled_rasterizer {
     u32 compat_caps;
     u32 width, height;       // allocated image size
     u32 ranges_capacity;     // tiles + 1
-    u32* ranges;
+    u32* ranges;             // own table (used when the forward pass did not build one)
+    u32* ranges_used;        // the table the last encode composited with: own or the forward pass's
     u32* rgba8;
     float* alpha;
     u32* n_contrib;
@@ -459,6 +467,9 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;
+    op->ranges = nullptr;
+    op->ranges_capacity = 0;
+    op->ranges_valid = false;
     op->encoded = false;
     const u32 n = cfg->num_points;
     uint64_t cap;
@@ -501,6 +512,7 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     if (op->host_stats) (void)hipHostFree(op->host_stats);
     free_dev(op->splats);
     free_dev(op->depths);
+    free_dev(op->ranges);
     wdgs_prefix_scanner_destroy(op->scanner);
     wdgs_sorter_destroy(op->sorter);
     delete op;
@@ -528,9 +540,25 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     }
     WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->settings, op->tile_info, wdgs_sorter_keys(op->sorter, 0),
                          wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
+    op->ranges_valid = false;
     if (!skip_sort) {
         // key = (tile_id + 1) << 16 | depth16: only 16 + bits(total_tiles) bits are ever set
-        WDGS_TRY(wdgs_sorter_sort(op->sorter, op->cfg.compat_caps ? 32u : 16u + bits_for(op->tile_info.total_tiles)));
+        if (op->cfg.compat_caps) {
+            WDGS_TRY(wdgs_sorter_sort(op->sorter, 32u));  // the reference's four 8-bit passes over the whole key
+        } else {
+            const u32 tiles = op->tile_info.total_tiles;
+            if (tiles + 1 > op->ranges_capacity) {
+                WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledForwardPass.encode allocates its range table on first use: run one eager encode before recording");
+                (void)hipStreamSynchronize(d->stream);
+                free_dev(op->ranges);
+                op->ranges = nullptr;
+                WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(tiles + 1), true, d->stream));
+                op->ranges_capacity = tiles + 1;
+            }
+            // tile passes, range table, per-tile depth sort (sort.hip): the order of a stable sort of the full key
+            WDGS_TRY(sorter_sort_segmented(op->sorter, bits_for(tiles), tiles, op->ranges));
+            op->ranges_valid = true;
+        }
     }
     op->encoded = true;
     return WDGS_OK;
@@ -630,19 +658,24 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
         op->width = width;
         op->height = height;
     }
-    if (ti.total_tiles + 1 > op->ranges_capacity) {
-        WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledRasterizer.encode allocates its range table on first use: run one eager encode before recording");
-        (void)hipStreamSynchronize(d->stream);
-        free_dev(op->ranges);
-        op->ranges = nullptr;
-        WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(ti.total_tiles + 1), true, d->stream));
-        op->ranges_capacity = ti.total_tiles + 1;
-    }
     const int fo = wdgs_sorter_final_out_index(f->sorter);
     const void* keys = wdgs_sorter_keys(f->sorter, fo);
     const void* vals = wdgs_sorter_values(f->sorter, fo);
-    WDGS_TRY(launch_tile_ranges(d, keys, f->stats, ti.total_tiles, op->ranges));
-    WDGS_TRY(launch_rasterize(d, f->settings, ti, f->splats, f->cfg.num_points, op->ranges, keys, vals, f->stats, op->compat_caps ? 32u : 0u, op->rgba8,
+    if (f->ranges_valid) {
+        op->ranges_used = f->ranges;  // built by the forward pass's sort
+    } else {
+        if (ti.total_tiles + 1 > op->ranges_capacity) {
+            WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledRasterizer.encode allocates its range table on first use: run one eager encode before recording");
+            (void)hipStreamSynchronize(d->stream);
+            free_dev(op->ranges);
+            op->ranges = nullptr;
+            WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(ti.total_tiles + 1), true, d->stream));
+            op->ranges_capacity = ti.total_tiles + 1;
+        }
+        WDGS_TRY(launch_tile_ranges(d, keys, f->stats, ti.total_tiles, op->ranges));
+        op->ranges_used = op->ranges;
+    }
+    WDGS_TRY(launch_rasterize(d, f->settings, ti, f->splats, f->cfg.num_points, op->ranges_used, keys, vals, f->stats, op->compat_caps ? 32u : 0u, op->rgba8,
                               op->alpha, op->n_contrib));
     op->encoded = true;
     return WDGS_OK;
@@ -657,7 +690,7 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
 RASTER_GETTER(wdgs_tiled_rasterizer_get_output, rgba8, "output texture")
 RASTER_GETTER(wdgs_tiled_rasterizer_get_alpha, alpha, "alpha texture")
 RASTER_GETTER(wdgs_tiled_rasterizer_get_n_contrib, n_contrib, "n_contrib texture")
-RASTER_GETTER(wdgs_tiled_rasterizer_get_tile_offsets, ranges, "tile offsets")
+RASTER_GETTER(wdgs_tiled_rasterizer_get_tile_offsets, ranges_used, "tile offsets")
 #undef RASTER_GETTER
 
 int wdgs_tiled_rasterizer_blit(wdgs_tiled_rasterizer* op, void* target, uint32_t tw, uint32_t th) {

@@ -58,6 +58,33 @@ WD_DEV int cvt_fixed(float scaled) {
     return r;
 }
 
+// Can any pixel centre of the block [x0, x1] x [y0, y1] (offsets from the splat centre) reach alpha >= 1/255?  alpha = min(0.99, o G)
+// with G = exp(-q/2), q = A dx^2 + 2 B dx dy + C dy^2: the reference skips a pixel-splat pair below that alpha before it touches any
+// state (tiled-backward-rasterize.wgsl:116-118), so a splat whose LARGEST alpha over the block is below it changes nothing for
+// this wave.  For a positive definite conic the minimum of q over the rectangle is 0 if the rectangle holds the centre, else the
+// smallest of the four edge minima (a convex function takes its minimum over a convex set that excludes the unconstrained minimiser on
+// the boundary).  The test is CONSERVATIVE, never exact: it uses approximate reciprocals / logarithm and is padded by a margin that
+// covers their error and the rounding of q (terms of size M, a few ulp each) a hundred times over; anything it is unsure about --
+// an indefinite conic after fp16 rounding, a NaN -- is kept, and the per-pixel test below still decides.  Outputs do not depend
+// on it; only the number of (wave, splat) iterations does (about a third of the box-overlapping ones were empty at BASELINE c3).
+WD_DEV bool block_reaches_min_alpha(float A, float B, float C, float opacity, float x0, float x1, float y0, float y1) {
+    if ((x0 <= 0.0f) & (x1 >= 0.0f) & (y0 <= 0.0f) & (y1 >= 0.0f)) return true;  // the centre is inside: q = 0 there
+    const float det = A * C - B * B;
+    if (!((A > 0.0f) & (C > 0.0f) & (det > 0.0f))) return true;  // not provably convex (also NaN): keep
+    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+    auto q_at = [&](float dx, float dy) { return (A * dx) * dx + ((B + B) * dx) * dy + (C * dy) * dy; };
+    auto clampf = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+    const float q1 = q_at(x0, clampf(-(B * x0) * rC, y0, y1));
+    const float q2 = q_at(x1, clampf(-(B * x1) * rC, y0, y1));
+    const float q3 = q_at(clampf(-(B * y0) * rA, x0, x1), y0);
+    const float q4 = q_at(clampf(-(B * y1) * rA, x0, x1), y1);
+    const float qmin = fminf(fminf(q1, q2), fminf(q3, q4));
+    const float mx = fmaxf(fabsf(x0), fabsf(x1)), my = fmaxf(fabsf(y0), fabsf(y1));
+    const float M = (A * mx) * mx + (2.0f * fabsf(B) * mx) * my + (C * my) * my;
+    const float thr = 2.0f * __logf(255.0f * opacity);  // alpha >= 1/255  <=>  q <= 2 ln(255 o)
+    return !(qmin > thr + (1e-3f + 1e-5f * M));         // NaN anywhere -> true
+}
+
 __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
@@ -126,7 +153,9 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
         const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
         const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
         const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
-        const bool ok = have && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+        const bool in_box = have && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+        const bool ok = in_box && block_reaches_min_alpha(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y), blk_x0 - cx,
+                                                          blk_x1 - cx, blk_y0 - cy, blk_y1 - cy);
         const unsigned long long m = __ballot(ok);
         const u32 n_list = (u32)__popcll(m);
         if (ok) {
@@ -147,13 +176,15 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
         __builtin_amdgcn_wave_barrier();
 
         for (u32 i = n_list; i-- > 0u;) {  // back to front
+            // all four records at once: one LDS round trip per iteration (after the block-level alpha test nearly every iteration
+            // has a contributing pixel, so the early exits the staged reads used to serve are rare)
             const float4 geo = s_geo[i];
             const float4 aux = s_aux[i];  // entry position (bits), 2*conic.x, 2*conic.y, 2*conic.z
-            const f2 d = pxy - f2{geo.x, geo.y};
-            // (bitwise, not short-circuit: one LDS round trip and no branches for the three tests)
-            const bool cand = ((int)(__float_as_uint(aux.x) < pix_n) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
-            if (!__any(cand)) continue;
             const float4 con = s_con[i];
+            const float4 col = s_col[i];
+            const f2 d = pxy - f2{geo.x, geo.y};
+            // (bitwise, not short-circuit: no branches for the three tests)
+            const bool cand = ((int)(__float_as_uint(aux.x) < pix_n) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
             const float t1 = __builtin_fmaf(con.x, d.x, aux.z * d.y);
             const float power = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
             const float G = wd_exp(-0.5f * power);
@@ -161,7 +192,6 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
             const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
             const bool act = cand && !(alpha < (1.0f / 255.0f));
             if (!__any(act)) continue;
-            const float4 col = s_col[i];
             int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
             if (act) {
                 // Pairs (f2) are plain component-wise scalar arithmetic; every product and sum below is the reference's own, in its

@@ -11,6 +11,17 @@
 //   (the exclusive scan of the 256 row totals is done by every scatter block itself)
 //   sort_scatter   ranks by wave64 ballot match (stable: order = wave, round, lane = input order) and scatters
 // HBM traffic per pass: 4E (hist) + 16E (scatter); ranges: 4E + 4(T+1).  Only digits that can be non-zero are sorted.
+//
+// Tile-structured keys (the forward pass: key = (tile + 1) << 16 | depth16) take a shorter route, sort_segmented below:
+//   1. the stable LSD passes above on the TILE bits only (2 passes for up to 65535 tiles instead of 4 over the whole key) -- entries of
+//      a tile are now contiguous, in emission order (ascending Gaussian index);
+//   2. tile_ranges on those keys (the high 16 bits are already in final order);
+//   3. segment_sort: one workgroup per tile sorts its segment by the 16 depth bits, stably, entirely in LDS (two 8-bit counting
+//      passes over <= SEG_CAP entries; larger segments run the same two passes through the ping-pong buffers, chunk by chunk).
+// The result is the order a stable sort of the full 32-bit key gives -- (tile, depth16, emission order) -- for 4E + 16E per tile
+// pass + 16E for the segment sort = 56E bytes instead of 84E, and 9 launches instead of 12.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -35,10 +46,18 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
 #pragma unroll
         for (u32 j = 0; j < SORT_ITEMS / 4; j++) {
             const uint4 q = *reinterpret_cast<const uint4*>(keys + base + (j * SORT_THREADS + threadIdx.x) * 4u);
-            atomicAdd(&lh[wave][(q.x >> shift) & 0xFFu], 1u);
-            atomicAdd(&lh[wave][(q.y >> shift) & 0xFFu], 1u);
-            atomicAdd(&lh[wave][(q.z >> shift) & 0xFFu], 1u);
-            atomicAdd(&lh[wave][(q.w >> shift) & 0xFFu], 1u);
+            // the four keys of a lane are neighbours in memory and, in tile-ordered data, usually share their digit: merge equal
+            // digits inside the lane first (same-address LDS atomics of one wave-instruction serialise; they were 86 % of this
+            // kernel's LDS cycles: profiles/r01e_pmc.json)
+            const u32 d0 = (q.x >> shift) & 0xFFu, d1 = (q.y >> shift) & 0xFFu, d2 = (q.z >> shift) & 0xFFu, d3 = (q.w >> shift) & 0xFFu;
+            if (d0 == d3 && d0 == d1 && d0 == d2) {
+                atomicAdd(&lh[wave][d0], 4u);
+            } else {
+                atomicAdd(&lh[wave][d0], 1u);
+                atomicAdd(&lh[wave][d1], 1u);
+                atomicAdd(&lh[wave][d2], 1u);
+                atomicAdd(&lh[wave][d3], 1u);
+            }
         }
     } else {
         for (u32 j = 0; j < SORT_ITEMS; j++) {
@@ -204,21 +223,213 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
 }
 
 // ranges[t] = first index whose key>>16 == t+1, 0xFFFFFFFF for empty tiles, ranges[T] = E  (tile-ranges.wgsl:34-76 writes the same
-// table with an init pass + one atomicMin per entry).  The keys are sorted, so each tile finds its start by a lower-bound search
-// (23 probes at 6 M entries): one launch over T+1 threads instead of an init launch plus a pass over all E keys.
+// table with an init pass + one atomicMin per entry).  The keys are sorted by their high 16 bits, so each tile finds its start by a
+// lower-bound search: one WAVE per tile probes 64 positions per round (a 64-ary search: 4 dependent memory round trips at 6 M entries
+// instead of 23) -- one launch over T+1 waves instead of an init launch plus a pass over all E keys.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 total_tiles,
                                                            u32* __restrict__ ranges) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = blockIdx.x * 4u + (threadIdx.x >> 6);  // wave index = tile
+    const u32 lane = threadIdx.x & 63u;
     if (t > total_tiles) return;
     const u32 count = *count_ptr;
-    if (t == total_tiles) { ranges[t] = count; return; }
+    if (t == total_tiles) { if (lane == 0u) ranges[t] = count; return; }
     const u32 want = t + 1u;  // tile field of the key is 1-based
-    u32 lo = 0u, hi = count;  // first index with (key >> 16) >= want
-    while (lo < hi) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        if ((keys[mid] >> 16u) < want) lo = mid + 1u; else hi = mid;
+    u32 lo = 0u, hi = count;  // invariant: every index < lo has tile < want; every index >= hi has tile >= want (or hi == count)
+    while (hi - lo > 64u) {
+        const u32 span = hi - lo;
+        // probe positions lo + ceil(span * (l + 1) / 65) - 1 ... strictly inside [lo, hi): 64 distinct, increasing with the lane
+        const u32 pos = lo + (u32)(((unsigned long long)span * (lane + 1u)) / 65ull);
+        const bool less = (keys[pos] >> 16u) < want;
+        const unsigned long long m = __ballot(less);  // monotone: a prefix of ones
+        const u32 k = (u32)__popcll(m);               // lanes [0, k) are "less"
+        const u32 pos_prev = (k == 0u) ? lo : lo + (u32)(((unsigned long long)span * k) / 65ull) + 1u;       // one past the last "less" probe
+        const u32 pos_next = (k == 64u) ? hi : lo + (u32)(((unsigned long long)span * (k + 1u)) / 65ull);   // the first "not less" probe
+        lo = pos_prev;
+        hi = pos_next;
     }
-    ranges[t] = (lo < count && (keys[lo] >> 16u) == want) ? lo : 0xFFFFFFFFu;
+    // final window of <= 64 candidates [lo, hi): first index with tile >= want
+    const u32 idx = lo + lane;
+    const bool ge = idx < hi && (keys[idx] >> 16u) >= want;
+    const unsigned long long m = __ballot(ge);
+    const u32 first = (m == 0ull) ? hi : lo + (u32)__builtin_ctzll(m);
+    if (lane == 0u) ranges[t] = (first < count && (keys[first] >> 16u) == want) ? first : 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- segment sort
+constexpr u32 SEG_CAP = 2048;                    // entries sorted entirely in LDS
+constexpr u32 SEG_THREADS = 256;
+
+// One stable 8-bit counting pass over n <= SEG_CAP (key, value) pairs held in LDS: src -> dst.  Wave w owns the contiguous index
+// range [w*per_wave, (w+1)*per_wave) and walks it in rounds of 64 lanes, so (wave, round, lane) is the index order -- which makes the
+// ranking stable -- exactly as sort_scatter does for a global partition.
+__device__ __forceinline__ void seg_pass_lds(const u32* __restrict__ src_k, const u32* __restrict__ src_v, u32* __restrict__ dst_k, u32* __restrict__ dst_v,
+                                             u32 n, u32 shift, u32 (*whist)[RADIX], u32* s_wsum) {
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 per_wave = ((n + 3u) / 4u + 63u) & ~63u;  // multiple of 64
+    const u32 rounds = per_wave / 64u;                   // <= SEG_CAP / 256
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (u32 w = 0; w < SEG_THREADS / 64; w++) whist[w][threadIdx.x] = 0;
+    __syncthreads();
+    u32 rk[SEG_CAP / SEG_THREADS], kk[SEG_CAP / SEG_THREADS], vv[SEG_CAP / SEG_THREADS];
+#pragma unroll
+    for (u32 j = 0; j < SEG_CAP / SEG_THREADS; j++) {
+        if (j < rounds) {  // uniform per workgroup
+            const u32 i = wave * per_wave + j * 64u + lane;
+            const bool valid = i < n;
+            kk[j] = valid ? src_k[i] : 0xFFFFFFFFu;
+            vv[j] = valid ? src_v[i] : 0u;
+            const u32 digit = (kk[j] >> shift) & (RADIX - 1u);
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (u32 b = 0; b < 8; b++) {
+                const bool bit = (digit >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const u32 pre = whist[wave][digit];
+            const u32 below = (u32)__popcll(m & lt_mask);
+            rk[j] = pre + below;
+            if (valid && below == 0u) whist[wave][digit] = pre + (u32)__popcll(m);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan over the 256 digits of the per-digit totals; per-wave starts within each digit
+        const u32 d = threadIdx.x;
+        u32 cnt_d = 0;
+#pragma unroll
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) cnt_d += whist[w][d];
+        u32 inc = cnt_d;
+#pragma unroll
+        for (u32 sft = 1; sft < 64; sft <<= 1) {
+            const u32 t = __shfl_up(inc, sft, 64);
+            if (lane >= sft) inc += t;
+        }
+        if (lane == 63u) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 woff = 0;
+#pragma unroll
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) if (w < wave) woff += s_wsum[w];
+        u32 run = woff + inc - cnt_d;
+#pragma unroll
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) {
+            const u32 c = whist[w][d];
+            whist[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < SEG_CAP / SEG_THREADS; j++) {
+        if (j < rounds) {
+            const u32 i = wave * per_wave + j * 64u + lane;
+            if (i < n) {
+                const u32 pos = whist[wave][(kk[j] >> shift) & (RADIX - 1u)] + rk[j];
+                dst_k[pos] = kk[j];
+                dst_v[pos] = vv[j];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Segments longer than SEG_CAP: the same two stable passes, through global memory.  pass: histogram of the whole segment, exclusive
+// scan, then the chunks of 256 in index order, each ranked stably (wave ballots + earlier waves' counts) on top of running digit bases.
+__device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __restrict__ src_v, u32* __restrict__ dst_k, u32* __restrict__ dst_v, u32 n,
+                                u32 shift, u32 (*whist)[RADIX], u32* s_base /*[RADIX]*/, u32* s_wsum) {
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    s_base[threadIdx.x] = 0u;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) atomicAdd(&s_base[(src_k[i] >> shift) & (RADIX - 1u)], 1u);
+    __syncthreads();
+    {
+        const u32 cnt_d = s_base[threadIdx.x];
+        u32 inc = cnt_d;
+#pragma unroll
+        for (u32 sft = 1; sft < 64; sft <<= 1) {
+            const u32 t = __shfl_up(inc, sft, 64);
+            if (lane >= sft) inc += t;
+        }
+        if (lane == 63u) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 woff = 0;
+#pragma unroll
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) if (w < wave) woff += s_wsum[w];
+        s_base[threadIdx.x] = woff + inc - cnt_d;  // start of digit d in the sorted segment
+    }
+    __syncthreads();
+    for (u32 c0 = 0; c0 < n; c0 += SEG_THREADS) {
+        const u32 i = c0 + threadIdx.x;  // index order = (wave, lane)
+        const bool valid = i < n;
+        const u32 k = valid ? src_k[i] : 0xFFFFFFFFu;
+        const u32 v = valid ? src_v[i] : 0u;
+        const u32 digit = (k >> shift) & (RADIX - 1u);
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (u32 b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const u32 below = (u32)__popcll(m & lt_mask);
+#pragma unroll
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) whist[w][threadIdx.x] = 0u;
+        __syncthreads();
+        if (valid && below == 0u) whist[wave][digit] = (u32)__popcll(m);  // this wave's count of the digit in this chunk
+        __syncthreads();
+        u32 earlier = 0;
+#pragma unroll
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) if (w < wave) earlier += whist[w][digit];
+        if (valid) {
+            const u32 pos = s_base[digit] + earlier + below;
+            dst_k[pos] = k;
+            dst_v[pos] = v;
+        }
+        __syncthreads();
+        {   // advance the running bases by this chunk's totals
+            const u32 d = threadIdx.x;
+            s_base[d] += whist[0][d] + whist[1][d] + whist[2][d] + whist[3][d];
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+}
+
+// One workgroup per segment (= tile): stable sort of [start, end) by the low 16 key bits.  keys/vals `cur` hold the data (and receive
+// the result); `alt` is the other ping-pong pair, used as scratch by oversized segments only.
+__global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
+                                                                    u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles) {
+    __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP], b_k[SEG_CAP], b_v[SEG_CAP];
+    __shared__ u32 whist[SEG_THREADS / 64][RADIX];
+    __shared__ u32 s_base[RADIX];
+    __shared__ u32 s_wsum[SEG_THREADS / 64];
+    __shared__ u32 s_end;
+    const u32 t = blockIdx.x;
+    const u32 start = ranges[t];
+    if (start == 0xFFFFFFFFu) return;  // empty tile (uniform per workgroup)
+    // end of the segment = start of the next non-empty tile (ranges[T] = E ends the walk)
+    if (threadIdx.x == 0u) {
+        u32 nx = t + 1u;
+        u32 e = ranges[nx];
+        while (e == 0xFFFFFFFFu && nx < total_tiles) { nx++; e = ranges[nx]; }
+        s_end = e;
+    }
+    __syncthreads();
+    const u32 end = s_end;
+    if (end <= start + 1u || end == 0xFFFFFFFFu) return;
+    const u32 n = end - start;
+    if (n <= SEG_CAP) {
+        for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) { a_k[i] = cur_k[start + i]; a_v[i] = cur_v[start + i]; }
+        __syncthreads();
+        seg_pass_lds(a_k, a_v, b_k, b_v, n, 0u, whist, s_wsum);
+        seg_pass_lds(b_k, b_v, a_k, a_v, n, 8u, whist, s_wsum);
+        for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) { cur_k[start + i] = a_k[i]; cur_v[start + i] = a_v[i]; }
+    } else {
+        seg_pass_global(cur_k + start, cur_v + start, alt_k + start, alt_v + start, n, 0u, whist, s_base, s_wsum);
+        __syncthreads();
+        seg_pass_global(alt_k + start, alt_v + start, cur_k + start, cur_v + start, n, 8u, whist, s_base, s_wsum);
+    }
 }
 
 }  // namespace
@@ -278,6 +489,33 @@ void* wdgs_sorter_values(wdgs_sorter* s, int i) { return s ? s->vals[i & 1] : nu
 int wdgs_sorter_final_out_index(wdgs_sorter* s) { return s ? s->final_out_index : 0; }
 uint32_t wdgs_sorter_capacity(wdgs_sorter* s) { return s ? s->capacity : 0; }
 
+}  // extern "C"
+
+// Stable sort of keys laid out as (segment id << 16 | 16-bit minor key): LSD passes over the segment bits, the range table of
+// the segments, then one workgroup per segment for the minor key.  `ranges` = u32[num_segments + 1], written here.
+int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges) {
+    wdgs_device* dev = s->dev;
+    const u32 passes = (std::min(segment_bits, 16u) + 7u) / 8u;
+    int src = 0;
+    for (u32 p = 0; p < passes; p++) {
+        const u32 shift = 16u + p * 8u;
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->counts);
+        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                    s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->counts, s->totals);
+        src ^= 1;
+    }
+    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(num_segments + 1, 4)), dim3(256), 0, s->keys[src], s->count_ptr, num_segments, ranges);
+    if (num_segments > 0)
+        WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(num_segments), dim3(SEG_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                    s->vals[src ^ 1], ranges, num_segments);
+    WDGS_CHECK_HIP(hipGetLastError());
+    s->final_out_index = src;
+    return WDGS_OK;
+}
+
+extern "C" {
+
 int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
     WDGS_REQUIRE(s, WDGS_E_INVALID, "wdgs_sorter_sort: null sorter");
     if (key_bits == 0 || key_bits > 32) key_bits = 32;
@@ -300,7 +538,7 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
 }  // extern "C"
 
 int launch_tile_ranges(wdgs_device* dev, const void* sorted_keys, const void* count_ptr, u32 total_tiles, void* ranges) {
-    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(total_tiles + 1, 256)), dim3(256), 0, (const u32*)sorted_keys, (const u32*)count_ptr,
+    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(total_tiles + 1, 4)), dim3(256), 0, (const u32*)sorted_keys, (const u32*)count_ptr,
                 total_tiles, (u32*)ranges);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
