@@ -8,9 +8,9 @@
 #include "common.h"
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
-int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*);
+int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*);
 int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*, void*, void*);
-int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
+int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
 int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
                      void*, void*);
@@ -94,6 +94,7 @@ struct wdgs_tiled_forward {
     u32* host_stats;  // pinned, device-visible copy of stats[0..3] written by update_stats: the per-step overflow check reads host memory
     u32* splats;
     u32* depths;
+    u32* block_counts;  // u32[ceil(N/256)]: tile entries per project_count workgroup, scanned in place into workgroup offsets
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
     wdgs_sorter* sorter;
     // Per-tile range table u32[tiles + 1].  The sort of tile-structured keys needs it half way (sort.hip, sort_segmented), so the
@@ -463,7 +464,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     wdgs_tiled_forward* op = new wdgs_tiled_forward();
     op->dev = d;
     op->cfg = *cfg;
-    op->stats = op->splats = op->depths = nullptr;
+    op->stats = op->splats = op->depths = op->block_counts = nullptr;
     op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;
@@ -493,6 +494,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     if (r == WDGS_OK) std::memset(op->host_stats, 0, 16);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->splats, (size_t)24 * std::max(n, 1u), true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * std::max(n, 1u), true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->block_counts, (size_t)4 * (ceil_div(std::max(n, 1u), 256) + 1), true, d->stream);
     if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, std::max(n, 1u), &op->scanner);
     if (r == WDGS_OK) r = wdgs_sorter_create(d, (u32)cap, op->stats, &op->sorter);
     if (r != WDGS_OK) { wdgs_tiled_forward_destroy(op); return r; }
@@ -512,6 +514,7 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     if (op->host_stats) (void)hipHostFree(op->host_stats);
     free_dev(op->splats);
     free_dev(op->depths);
+    free_dev(op->block_counts);
     free_dev(op->ranges);
     wdgs_prefix_scanner_destroy(op->scanner);
     wdgs_sorter_destroy(op->sorter);
@@ -531,15 +534,18 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     const u32 n = op->cfg.num_points;
     // clearBuffer(pipelineStatsBuffer) (tiled-forward-pass.ts:345) needs no launch here: update_stats overwrites words 0..2, word 3
     // stays 0, and the visible count is accumulated in shard words that update_stats clears after folding them.
-    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4));
-    if (n > 0) {  // the scan's single-block middle kernel publishes the stats block (update_stats, K5) as its epilogue
-        WDGS_TRY(scan_exclusive_u32_stats(d, &op->scanner->scratch, op->scanner->input, op->scanner->output, n, nullptr,
-                                          ScanStatsEpilogue{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries}));
+    // The offsets scan (K2-K4) is spread over its neighbours: project_count leaves the entry count of each of its workgroups, one
+    // single-workgroup kernel scans those N/256 sums (and publishes the stats block: update_stats, K5, as its epilogue), and emit adds
+    // its own in-workgroup prefix -- writing the per-Gaussian offsets table on the way.  Three launches instead of five.
+    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
+                                  op->block_counts));
+    if (n > 0) {
+        WDGS_TRY(scan_block_sums_inplace(d, op->block_counts, ceil_div(n, 256), ScanStatsEpilogue{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries}));
     } else {
         WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4, op->host_stats));
     }
-    WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->settings, op->tile_info, wdgs_sorter_keys(op->sorter, 0),
-                         wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
+    WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->block_counts, op->settings, op->tile_info,
+                         wdgs_sorter_keys(op->sorter, 0), wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
     op->ranges_valid = false;
     if (!skip_sort) {
         // key = (tile_id + 1) << 16 | depth16: only 16 + bits(total_tiles) bits are ever set

@@ -99,5 +99,7 @@ int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out
 struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u32 capacity; };
 int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep);
 
+int scan_block_sums_inplace(wdgs_device* dev, u32* block_sums, u32 num_blocks, const ScanStatsEpilogue& ep);
+
 struct RenderSettings { float gaussian_scaling, sh_deg, viewport_x, viewport_y, point_size_px, gaussian_mode, max_splat_radius_px; };
 struct TileInfo { u32 num_tiles_x, num_tiles_y, total_tiles, max_tile_entries; };

@@ -89,11 +89,12 @@ WD_DEV TileBox tile_box(vec2 ndc_f16, vec2 extents_f16, vec2 viewport, u32 ntx, 
 __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer,
                                                              const float* __restrict__ camera_f, RenderSettings settings, TileInfo ti,
                                                              u32* __restrict__ splats, u32* __restrict__ depths,
-                                                             u32* __restrict__ tile_counts, u32* __restrict__ visible_shards) {
+                                                             u32* __restrict__ tile_counts, u32* __restrict__ visible_shards,
+                                                             u32* __restrict__ block_counts) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool visible = false;
+    u32 num_tiles_out = 0u;
     if (idx < n) {
-        u32 num_tiles_out = 0u;
         do {
             const u32* g = gaussians + (size_t)idx * 6;
             const uint2 w01 = *reinterpret_cast<const uint2*>(g);
@@ -165,13 +166,19 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
     // visible_gaussians: the reference does one atomicAdd per visible splat on ONE word (tiled-forward.wgsl:292).  Even one
     // atomic per wave on a single address serialises the kernel (~12 ns each, measured: 15.6 K waves = the whole 0.2 ms),
     // so the count goes to 64 shard words (one add per workgroup); update_stats folds the shards into stats[1].
-    __shared__ u32 s_vis[4];
+    // block_counts[b] = tile entries of this workgroup's 256 Gaussians: the first level of the offsets scan, produced where the counts
+    // are (the scan of these ~N/256 sums and the emit kernel's own in-workgroup prefix replace a reduce and a down-sweep launch).
+    __shared__ u32 s_vis[4], s_cnt[4];
     const unsigned long long mask = __ballot(visible);
-    if ((threadIdx.x & 63u) == 0u) s_vis[threadIdx.x >> 6] = (u32)__popcll(mask);
+    u32 wsum = num_tiles_out;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) wsum += (u32)__shfl_xor((int)wsum, (int)d, 64);
+    if ((threadIdx.x & 63u) == 0u) { s_vis[threadIdx.x >> 6] = (u32)__popcll(mask); s_cnt[threadIdx.x >> 6] = wsum; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const u32 c = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
         if (c) atomicAdd(&visible_shards[blockIdx.x & 63u], c);
+        if (block_counts) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
 }
 
@@ -206,10 +213,11 @@ __global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, cons
 // count prefix (wave-private LDS) and derives its tile from the entry's rank inside that splat's box.  Stores are coalesced and
 // every lane does the same work regardless of the box sizes.
 __global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict__ splats, const u32* __restrict__ depths,
-                                                    const u32* __restrict__ tile_counts, const u32* __restrict__ tile_offsets,
-                                                    RenderSettings settings, TileInfo ti, u32* __restrict__ keys, u32* __restrict__ values,
-                                                    u32 capacity) {
+                                                    const u32* __restrict__ tile_counts, u32* __restrict__ tile_offsets,
+                                                    const u32* __restrict__ block_offsets, RenderSettings settings, TileInfo ti,
+                                                    u32* __restrict__ keys, u32* __restrict__ values, u32 capacity) {
     __shared__ u32 s_pre[4][64], s_org[4][64], s_w[4][64], s_inv[4][64], s_dep[4][64];
+    __shared__ u32 s_wtot[4];
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u32 cnt = 0u, org = 0u, width = 1u, depth16 = 0u;
@@ -239,9 +247,23 @@ __global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict_
         if (lane >= d) inc += t;
     }
     const u32 total = (u32)__shfl((int)inc, 63, 64);
-    if (total == 0u) return;
-    const u32 wave_first = idx - lane;  // Gaussian of lane 0 (< n, or total would be 0)
-    const u32 start0 = tile_offsets[wave_first];
+    const u32 wave_first = idx - lane;  // Gaussian of lane 0
+    u32 start0;
+    if (block_offsets) {
+        // offsets are not scanned per Gaussian beforehand: this workgroup's start comes from the scan of the per-workgroup sums
+        // (project_count wrote them), the wave's start from the totals of the waves before it, the Gaussian's from the wave prefix
+        // above -- and the per-Gaussian table the reference exposes (getTileOffsetsBuffer) is written here as a by-product.
+        if (lane == 0u) s_wtot[wave] = total;
+        __syncthreads();
+        start0 = block_offsets[blockIdx.x];
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) start0 += (w < wave) ? s_wtot[w] : 0u;
+        if (idx < n) tile_offsets[idx] = start0 + inc - cnt;
+        if (total == 0u) return;
+    } else {
+        if (total == 0u) return;
+        start0 = tile_offsets[wave_first];  // (< n, or total would be 0)
+    }
     s_pre[wave][lane] = inc - cnt;
     s_org[wave][lane] = org;
     s_w[wave][lane] = width;
@@ -269,10 +291,10 @@ __global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict_
 }  // namespace
 
 int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const void* sh, const void* camera, const RenderSettings& st,
-                         const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards) {
+                         const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards, void* block_counts) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "project_count", project_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh,
-                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards);
+                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
@@ -284,11 +306,11 @@ int launch_update_stats(wdgs_device* dev, u32 n, const void* offsets, const void
     return WDGS_OK;
 }
 
-int launch_emit(wdgs_device* dev, u32 n, const void* splats, const void* depths, const void* counts, const void* offsets,
+int launch_emit(wdgs_device* dev, u32 n, const void* splats, const void* depths, const void* counts, void* offsets, const void* block_offsets,
                 const RenderSettings& st, const TileInfo& ti, void* keys, void* values, u32 capacity) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "emit", emit_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)splats, (const u32*)depths, (const u32*)counts,
-                (const u32*)offsets, st, ti, (u32*)keys, (u32*)values, capacity);
+                (u32*)offsets, (const u32*)block_offsets, st, ti, (u32*)keys, (u32*)values, capacity);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -73,12 +73,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __re
                                                                        ScanStatsEpilogue ep) {
     __shared__ u32 lds[4];
     u32 carry = 0;
-    for (u32 base = 0; base < num_blocks; base += SCAN_THREADS) {
-        const u32 i = base + threadIdx.x;
-        const u32 v = (i < num_blocks) ? block_sums[i] : 0u;
+    // SCAN_TILE sums per round, 16 consecutive ones per thread (the forward pass hands over N/256 of them: one round up to 1 M Gaussians)
+    for (u32 base = 0; base < num_blocks; base += SCAN_TILE) {
+        u32 x[SCAN_ITEMS];
+        load_items(block_sums, base, num_blocks, x);
+        u32 s = 0;
+#pragma unroll
+        for (u32 j = 0; j < SCAN_ITEMS; j++) s += x[j];
         u32 total;
-        const u32 ex = block_exclusive_scan(v, &total, lds);
-        if (i < num_blocks) block_sums[i] = carry + ex;
+        u32 run = carry + block_exclusive_scan(s, &total, lds);
+        const u32 first = base + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+        for (u32 j = 0; j < SCAN_ITEMS; j++) {
+            if (first + j < num_blocks) block_sums[first + j] = run;
+            run += x[j];
+        }
         carry += total;
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;
@@ -137,6 +146,14 @@ void scan_scratch_destroy(ScanScratch* s) {
     if (s->block_sums) (void)hipFree(s->block_sums);
     s->block_sums = nullptr;
     s->capacity_blocks = 0;
+}
+
+// In-place exclusive scan of `num_blocks` per-workgroup sums by one workgroup, with the forward pass's stats epilogue: the middle
+// level of a scan whose first level (the sums) and last level (the in-workgroup prefix) live in the producer and consumer kernels.
+int scan_block_sums_inplace(wdgs_device* dev, u32* block_sums, u32 num_blocks, const ScanStatsEpilogue& ep) {
+    WDGS_LAUNCH(dev, "scan_block_sums", scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, block_sums, num_blocks, (u32*)nullptr, ep);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
 }
 
 int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out) {

@@ -31,7 +31,7 @@ constexpr u32 SORT_ITEMS = 16;
 constexpr u32 SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per partition
 constexpr u32 RADIX = 256;
 
-__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 shift,
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 shift, u32 dmask,
                                                                  u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/) {
     __shared__ u32 lh[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
             // the four keys of a lane are neighbours in memory and, in tile-ordered data, usually share their digit: merge equal
             // digits inside the lane first (same-address LDS atomics of one wave-instruction serialise; they were 86 % of this
             // kernel's LDS cycles: profiles/r01e_pmc.json)
-            const u32 d0 = (q.x >> shift) & 0xFFu, d1 = (q.y >> shift) & 0xFFu, d2 = (q.z >> shift) & 0xFFu, d3 = (q.w >> shift) & 0xFFu;
+            const u32 d0 = (q.x >> shift) & dmask, d1 = (q.y >> shift) & dmask, d2 = (q.z >> shift) & dmask, d3 = (q.w >> shift) & dmask;
             if (d0 == d3 && d0 == d1 && d0 == d2) {
                 atomicAdd(&lh[wave][d0], 4u);
             } else {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
     } else {
         for (u32 j = 0; j < SORT_ITEMS; j++) {
             const u32 i = base + j * SORT_THREADS + threadIdx.x;
-            if (i < count) atomicAdd(&lh[wave][(keys[i] >> shift) & 0xFFu], 1u);
+            if (i < count) atomicAdd(&lh[wave][(keys[i] >> shift) & dmask], 1u);
         }
     }
     __syncthreads();
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ c
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                     u32* __restrict__ keys_out, u32* __restrict__ vals_out,
-                                                                    const u32* __restrict__ count_ptr, u32 shift, u32 num_parts,
+                                                                    const u32* __restrict__ count_ptr, u32 shift, u32 dmask, u32 num_parts,
                                                                     const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals) {
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     for (u32 j = 0; j < SORT_ITEMS; j++) {
         const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
         const bool valid = i < count;
-        const u32 digit = (k[j] >> shift) & (RADIX - 1u);
+        const u32 digit = (k[j] >> shift) & dmask;
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (u32 b = 0; b < 8; b++) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     for (u32 j = 0; j < SORT_ITEMS; j++) {
         const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
         if (i < count) {
-            const u32 digit = (k[j] >> shift) & (RADIX - 1u);
+            const u32 digit = (k[j] >> shift) & dmask;
             const u32 lpos = whist[wave][digit] + rk[j];
             s_keys[lpos] = k[j];
             s_vals[lpos] = v[j];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
 #pragma unroll 4
     for (u32 e = threadIdx.x; e < n_here; e += SORT_THREADS) {
         const u32 key = s_keys[e];
-        const u32 pos = s_gdelta[(key >> shift) & (RADIX - 1u)] + e;
+        const u32 pos = s_gdelta[(key >> shift) & dmask] + e;
         keys_out[pos] = key;
         vals_out[pos] = s_vals[e];
     }
@@ -259,26 +259,25 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict_
 constexpr u32 SEG_CAP = 2048;                    // entries sorted entirely in LDS
 constexpr u32 SEG_THREADS = 256;
 
-// One stable 8-bit counting pass over n <= SEG_CAP (key, value) pairs held in LDS: src -> dst.  Wave w owns the contiguous index
-// range [w*per_wave, (w+1)*per_wave) and walks it in rounds of 64 lanes, so (wave, round, lane) is the index order -- which makes the
-// ranking stable -- exactly as sort_scatter does for a global partition.
-__device__ __forceinline__ void seg_pass_lds(const u32* __restrict__ src_k, const u32* __restrict__ src_v, u32* __restrict__ dst_k, u32* __restrict__ dst_v,
-                                             u32 n, u32 shift, u32 (*whist)[RADIX], u32* s_wsum) {
+// One stable 8-bit counting pass over n <= SEG_CAP (key, value) pairs: the pairs arrive in REGISTERS (kk, vv: element index
+// i = wave*per_wave + j*64 + lane) and leave in LDS dst at their ranked position.  Wave w owns the contiguous index range
+// [w*per_wave, (w+1)*per_wave) and walks it in rounds of 64 lanes, so (wave, round, lane) is the index order -- which makes the ranking
+// stable -- exactly as sort_scatter does for a global partition.  The caller guarantees that nobody still reads dst.
+constexpr u32 SEG_ROUNDS = SEG_CAP / SEG_THREADS;
+__device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const u32 (&vv)[SEG_ROUNDS], u32* __restrict__ dst_k, u32* __restrict__ dst_v, u32 n,
+                                              u32 per_wave, u32 shift, u32 (*whist)[RADIX], u32* s_wsum) {
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 per_wave = ((n + 3u) / 4u + 63u) & ~63u;  // multiple of 64
-    const u32 rounds = per_wave / 64u;                   // <= SEG_CAP / 256
+    const u32 rounds = per_wave / 64u;  // <= SEG_ROUNDS, uniform per workgroup
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (u32 w = 0; w < SEG_THREADS / 64; w++) whist[w][threadIdx.x] = 0;
     __syncthreads();
-    u32 rk[SEG_CAP / SEG_THREADS], kk[SEG_CAP / SEG_THREADS], vv[SEG_CAP / SEG_THREADS];
+    u32 rk[SEG_ROUNDS];
 #pragma unroll
-    for (u32 j = 0; j < SEG_CAP / SEG_THREADS; j++) {
-        if (j < rounds) {  // uniform per workgroup
+    for (u32 j = 0; j < SEG_ROUNDS; j++) {
+        if (j < rounds) {
             const u32 i = wave * per_wave + j * 64u + lane;
             const bool valid = i < n;
-            kk[j] = valid ? src_k[i] : 0xFFFFFFFFu;
-            vv[j] = valid ? src_v[i] : 0u;
             const u32 digit = (kk[j] >> shift) & (RADIX - 1u);
             unsigned long long m = __ballot(valid);
 #pragma unroll
@@ -320,7 +319,7 @@ __device__ __forceinline__ void seg_pass_lds(const u32* __restrict__ src_k, cons
     }
     __syncthreads();
 #pragma unroll
-    for (u32 j = 0; j < SEG_CAP / SEG_THREADS; j++) {
+    for (u32 j = 0; j < SEG_ROUNDS; j++) {
         if (j < rounds) {
             const u32 i = wave * per_wave + j * 64u + lane;
             if (i < n) {
@@ -400,7 +399,7 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 // the result); `alt` is the other ping-pong pair, used as scratch by oversized segments only.
 __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
                                                                     u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles) {
-    __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP], b_k[SEG_CAP], b_v[SEG_CAP];
+    __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP];  // one pair: every pass reads its input into registers before anyone scatters
     __shared__ u32 whist[SEG_THREADS / 64][RADIX];
     __shared__ u32 s_base[RADIX];
     __shared__ u32 s_wsum[SEG_THREADS / 64];
@@ -420,10 +419,27 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
     if (end <= start + 1u || end == 0xFFFFFFFFu) return;
     const u32 n = end - start;
     if (n <= SEG_CAP) {
-        for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) { a_k[i] = cur_k[start + i]; a_v[i] = cur_v[start + i]; }
-        __syncthreads();
-        seg_pass_lds(a_k, a_v, b_k, b_v, n, 0u, whist, s_wsum);
-        seg_pass_lds(b_k, b_v, a_k, a_v, n, 8u, whist, s_wsum);
+        const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const u32 per_wave = ((n + 3u) / 4u + 63u) & ~63u;  // multiple of 64; 4*per_wave >= n
+        const u32 rounds = per_wave / 64u;
+        u32 kk[SEG_ROUNDS], vv[SEG_ROUNDS];
+#pragma unroll
+        for (u32 j = 0; j < SEG_ROUNDS; j++) {  // global -> registers, coalesced per wave-round
+            const u32 i = wave * per_wave + j * 64u + lane;
+            const bool valid = j < rounds && i < n;
+            kk[j] = valid ? cur_k[start + i] : 0xFFFFFFFFu;
+            vv[j] = valid ? cur_v[start + i] : 0u;
+        }
+        seg_pass_regs(kk, vv, a_k, a_v, n, per_wave, 0u, whist, s_wsum);   // low depth byte
+#pragma unroll
+        for (u32 j = 0; j < SEG_ROUNDS; j++) {  // LDS -> registers in index order again
+            const u32 i = wave * per_wave + j * 64u + lane;
+            const bool valid = j < rounds && i < n;
+            kk[j] = valid ? a_k[i] : 0xFFFFFFFFu;
+            vv[j] = valid ? a_v[i] : 0u;
+        }
+        __syncthreads();  // everyone holds its pairs: a_k / a_v may be overwritten
+        seg_pass_regs(kk, vv, a_k, a_v, n, per_wave, 8u, whist, s_wsum);   // high depth byte
         for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) { cur_k[start + i] = a_k[i]; cur_v[start + i] = a_v[i]; }
     } else {
         seg_pass_global(cur_k + start, cur_v + start, alt_k + start, alt_v + start, n, 0u, whist, s_base, s_wsum);
@@ -495,15 +511,23 @@ uint32_t wdgs_sorter_capacity(wdgs_sorter* s) { return s ? s->capacity : 0; }
 // the segments, then one workgroup per segment for the minor key.  `ranges` = u32[num_segments + 1], written here.
 int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges) {
     wdgs_device* dev = s->dev;
-    const u32 passes = (std::min(segment_bits, 16u) + 7u) / 8u;
+    const u32 bits = std::min(segment_bits, 16u);
+    const u32 passes = (bits + 7u) / 8u;
+    // Balanced digit widths (13 tile bits -> 6 + 7, not 8 + 5): a partition's 4096 keys leave in 2^width runs, and the scatter's
+    // write efficiency follows the run length (measured at c3: 40 us for 256 runs of 16 keys, 26 us for 32 runs of 128).
     int src = 0;
+    u32 shift = 16u, left = bits;
     for (u32 p = 0; p < passes; p++) {
-        const u32 shift = 16u + p * 8u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->counts);
+        const u32 width = left / (passes - p);
+        left -= width;
+        const u32 dmask = (1u << width) - 1u;
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, dmask, s->num_parts,
+                    s->counts);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->counts, s->totals);
+                    s->vals[src ^ 1], s->count_ptr, shift, dmask, s->num_parts, s->counts, s->totals);
         src ^= 1;
+        shift += width;
     }
     WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(num_segments + 1, 4)), dim3(256), 0, s->keys[src], s->count_ptr, num_segments, ranges);
     if (num_segments > 0)
@@ -524,10 +548,11 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
     int src = 0;
     for (u32 p = 0; p < passes; p++) {
         const u32 shift = p * 8u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, s->num_parts, s->counts);
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, RADIX - 1u, s->num_parts,
+                    s->counts);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, s->num_parts, s->counts, s->totals);
+                    s->vals[src ^ 1], s->count_ptr, shift, RADIX - 1u, s->num_parts, s->counts, s->totals);
         src ^= 1;
     }
     WDGS_CHECK_HIP(hipGetLastError());

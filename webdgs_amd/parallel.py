@@ -146,7 +146,9 @@ class TorchExchange(Exchange):
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
-        self.fenced = self.backend != "nccl" or os.environ.get("WDGS_DP_FENCE", "") == "1"
+        # WDGS_DP_FENCE=1 / 0 overrides (diagnostics): fences on nccl, or none on gloo
+        fence_env = os.environ.get("WDGS_DP_FENCE", "")
+        self.fenced = (self.backend != "nccl") if fence_env == "" else (fence_env == "1")
         self.name = f"torch.distributed/{self.backend}" + ("+host-fences" if self.fenced else "")
 
     def _t(self, ptr: int, count: int, dtype: torch.dtype) -> torch.Tensor:
