@@ -527,6 +527,124 @@ static napi_value commAllreduceCounts(napi_env env, napi_callback_info info) {
 }
 static napi_value commDestroy(napi_env env, napi_callback_info info) { ARGS(1); wdgs_comm_destroy((wdgs_comm*)get_ptr(env, argv[0])); return js_undefined(env); }
 
+// ---- additions of round 2: recording abort, pinned read-back, scanner / sorter, optimizer guard, sliced data-parallel exchange ------
+static napi_value encoderAbort(napi_env env, napi_callback_info info) { ARGS(1); WDGS_OK_OR_THROW(wdgs_encoder_abort((wdgs_device*)get_ptr(env, argv[0]))); return js_undefined(env); }
+static void free_pinned(napi_env, void* data, void*) { wdgs_host_free(data); }
+static napi_value hostAlloc(napi_env env, napi_callback_info info) {  // (byteLength) -> ArrayBuffer over PINNED host memory (wdgs_host_alloc)
+    ARGS(1);
+    const size_t len = (size_t)get_f64(env, argv[0]);
+    void* p = nullptr;
+    WDGS_OK_OR_THROW(wdgs_host_alloc(len, &p));
+    napi_value ab;
+    if (napi_create_external_arraybuffer(env, p, len, free_pinned, nullptr, &ab) != napi_ok) { wdgs_host_free(p); napi_throw_error(env, nullptr, "external ArrayBuffer refused"); return nullptr; }
+    return ab;
+}
+static napi_value bufferReadAsync(napi_env env, napi_callback_info info) {
+    // (device, bufferHandle, offset, pinnedArrayBuffer, byteLength): mapAsync(READ) -- queues the copy; the bytes are valid once a later
+    // queueOnSubmittedWorkDone() Promise resolves (trainer.ts:455-458)
+    ARGS(5);
+    void* data = nullptr; size_t len = 0;
+    NAPI_OK(napi_get_arraybuffer_info(env, argv[3], &data, &len));
+    const size_t want = (size_t)get_f64(env, argv[4]);
+    if (want > len) { napi_throw_range_error(env, nullptr, "bufferReadAsync: destination too small"); return nullptr; }
+    WDGS_OK_OR_THROW(wdgs_buffer_read_async((wdgs_device*)get_ptr(env, argv[0]), (const wdgs_buffer*)get_ptr(env, argv[1]), (size_t)get_f64(env, argv[2]), data, want));
+    return js_undefined(env);
+}
+static napi_value prefixScanner(napi_env env, napi_callback_info info) {
+    // (op: 0 create(device, maxElements) -> {handle, inputBuffer, outputBuffer} | 1 setCount(handle, n) | 2 scan(handle) | 3 destroy(handle))
+    ARGS(3);
+    switch (get_u32(env, argv[0])) {
+        case 0: {
+            wdgs_prefix_scanner* s = nullptr;
+            WDGS_OK_OR_THROW(wdgs_prefix_scanner_create((wdgs_device*)get_ptr(env, argv[1]), get_u32(env, argv[2]), &s));
+            napi_value o; napi_create_object(env, &o);
+            set_prop(env, o, "handle", make_ptr(env, s));
+            set_prop(env, o, "inputBuffer", make_ptr(env, wdgs_prefix_scanner_input(s)));
+            set_prop(env, o, "outputBuffer", make_ptr(env, wdgs_prefix_scanner_output(s)));
+            return o;
+        }
+        case 1: WDGS_OK_OR_THROW(wdgs_prefix_scanner_set_count((wdgs_prefix_scanner*)get_ptr(env, argv[1]), get_u32(env, argv[2]))); break;
+        case 2: WDGS_OK_OR_THROW(wdgs_prefix_scanner_scan((wdgs_prefix_scanner*)get_ptr(env, argv[1]))); break;
+        default: wdgs_prefix_scanner_destroy((wdgs_prefix_scanner*)get_ptr(env, argv[1])); break;
+    }
+    return js_undefined(env);
+}
+static napi_value dynamicSorter(napi_env env, napi_callback_info info) {
+    // (op: 0 create(device, maxCapacity, statsPtr) -> {handle, capacity, keys0, values0, keys1, values1} | 1 sort(handle, keyBits) -> final_out_index |
+    //      2 destroy(handle))
+    ARGS(4);
+    switch (get_u32(env, argv[0])) {
+        case 0: {
+            wdgs_sorter* s = nullptr;
+            WDGS_OK_OR_THROW(wdgs_sorter_create((wdgs_device*)get_ptr(env, argv[1]), get_u32(env, argv[2]), get_ptr(env, argv[3]), &s));
+            napi_value o; napi_create_object(env, &o);
+            set_prop(env, o, "handle", make_ptr(env, s));
+            set_prop(env, o, "capacity", make_u32(env, wdgs_sorter_capacity(s)));
+            set_prop(env, o, "keys0", make_ptr(env, wdgs_sorter_keys(s, 0))); set_prop(env, o, "values0", make_ptr(env, wdgs_sorter_values(s, 0)));
+            set_prop(env, o, "keys1", make_ptr(env, wdgs_sorter_keys(s, 1))); set_prop(env, o, "values1", make_ptr(env, wdgs_sorter_values(s, 1)));
+            return o;
+        }
+        case 1: {
+            wdgs_sorter* s = (wdgs_sorter*)get_ptr(env, argv[1]);
+            WDGS_OK_OR_THROW(wdgs_sorter_sort(s, get_u32(env, argv[2])));
+            return make_u32(env, (uint32_t)wdgs_sorter_final_out_index(s));
+        }
+        default: wdgs_sorter_destroy((wdgs_sorter*)get_ptr(env, argv[1])); break;
+    }
+    return js_undefined(env);
+}
+static napi_value optimizerSetGuard(napi_env env, napi_callback_info info) {  // (optimizer, flagPtr | null)
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_optimizer_set_guard((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1])));
+    return js_undefined(env);
+}
+static napi_value optimizerStepF32Range(napi_env env, napi_callback_info info) {  // (optimizer, gaussiansPtr, shPtr, gradF32Ptr, visiblePtr, first, count, rowsPtr | null)
+    ARGS(8);
+    WDGS_OK_OR_THROW(wdgs_optimizer_step_f32_range((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]),
+                                                   get_ptr(env, argv[4]), get_u32(env, argv[5]), get_u32(env, argv[6]), get_ptr(env, argv[7])));
+    return js_undefined(env);
+}
+static napi_value optimizerStateChanged(napi_env env, napi_callback_info info) { ARGS(1); WDGS_OK_OR_THROW(wdgs_optimizer_state_changed((wdgs_optimizer*)get_ptr(env, argv[0]))); return js_undefined(env); }
+static napi_value storeGradients(napi_env env, napi_callback_info info) {  // (device, numPoints, gradientsPtr, tileCountsPtr, accF32Ptr, visiblePtr)
+    ARGS(6);
+    WDGS_OK_OR_THROW(wdgs_store_gradients((wdgs_device*)get_ptr(env, argv[0]), get_u32(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]), get_ptr(env, argv[4]),
+                                          get_ptr(env, argv[5])));
+    return js_undefined(env);
+}
+static napi_value guardAccumulate(napi_env env, napi_callback_info info) {  // (device, flagPtr, srcPtr, overwrite)
+    ARGS(4);
+    WDGS_OK_OR_THROW(wdgs_guard_accumulate((wdgs_device*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), (int)get_u32(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value applyRepackedRows(napi_env env, napi_callback_info info) {  // (device, numPoints, rowsPtr, skipFirst, skipCount, guardPtr | null, gaussiansPtr, shPtr)
+    ARGS(8);
+    WDGS_OK_OR_THROW(wdgs_apply_repacked_rows((wdgs_device*)get_ptr(env, argv[0]), get_u32(env, argv[1]), get_ptr(env, argv[2]), get_u32(env, argv[3]),
+                                              get_u32(env, argv[4]), get_ptr(env, argv[5]), get_ptr(env, argv[6]), get_ptr(env, argv[7])));
+    return js_undefined(env);
+}
+static napi_value commExchangeGradients(napi_env env, napi_callback_info info) {  // (comm, gradF32Ptr, visiblePtr, flagPtr | null, slicePoints)
+    ARGS(5);
+    WDGS_OK_OR_THROW(wdgs_comm_exchange_gradients((wdgs_comm*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]), get_u32(env, argv[4])));
+    return js_undefined(env);
+}
+static napi_value commAllgatherRows(napi_env env, napi_callback_info info) {  // (comm, rowsPtr, slicePoints)
+    ARGS(3);
+    WDGS_OK_OR_THROW(wdgs_comm_allgather_rows((wdgs_comm*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_u32(env, argv[2])));
+    return js_undefined(env);
+}
+static napi_value commBroadcast(napi_env env, napi_callback_info info) {  // (comm, ptr, bytes, root)
+    ARGS(4);
+    WDGS_OK_OR_THROW(wdgs_comm_broadcast((wdgs_comm*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), (size_t)get_f64(env, argv[2]), (int)get_u32(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value commInfo(napi_env env, napi_callback_info info) {  // (comm) -> {worldSize, rank}
+    ARGS(1);
+    napi_value o; napi_create_object(env, &o);
+    set_prop(env, o, "worldSize", make_u32(env, (uint32_t)wdgs_comm_world_size((wdgs_comm*)get_ptr(env, argv[0]))));
+    set_prop(env, o, "rank", make_u32(env, (uint32_t)wdgs_comm_rank((wdgs_comm*)get_ptr(env, argv[0]))));
+    return o;
+}
+
 #define EXPORT_FN(name)                                                              \
     do {                                                                             \
         napi_value fn;                                                               \
@@ -550,6 +668,9 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(densifyStage);
     EXPORT_FN(densifyDestroy);
     EXPORT_FN(commUniqueId); EXPORT_FN(commCreate); EXPORT_FN(commAllreduceGradients); EXPORT_FN(commAllreduceCounts); EXPORT_FN(commDestroy);
+    EXPORT_FN(encoderAbort); EXPORT_FN(hostAlloc); EXPORT_FN(bufferReadAsync); EXPORT_FN(prefixScanner); EXPORT_FN(dynamicSorter);
+    EXPORT_FN(optimizerSetGuard); EXPORT_FN(optimizerStepF32Range); EXPORT_FN(optimizerStateChanged); EXPORT_FN(storeGradients); EXPORT_FN(guardAccumulate);
+    EXPORT_FN(applyRepackedRows); EXPORT_FN(commExchangeGradients); EXPORT_FN(commAllgatherRows); EXPORT_FN(commBroadcast); EXPORT_FN(commInfo);
     return exports;
 }
 NAPI_MODULE(webdgs_napi, Init)

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python scripts/profile_step.py c3 10 > gpurun_out/r02f_profile_noorder.txt 2>&1; head -8 gpurun_out/r02f_profile_noorder.txt
-WDGS_TILE_ORDER=1 python scripts/profile_step.py c3 10 > gpurun_out/r02f_profile_order.txt 2>&1; head -8 gpurun_out/r02f_profile_order.txt; grep "tile_order\|scan_block\|kernel sum" gpurun_out/r02f_profile_order.txt
-WDGS_TILE_ORDER=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -q -x 2>&1 | tail -3
+timeout -k 10 600 python -m pytest tests/test_gpu_napi.py -q -x > gpurun_out/r02g_napi.log 2>&1; echo "napi pytest rc=$?"; tail -30 gpurun_out/r02g_napi.log
+timeout -k 10 120 node bindings/napi/smoke.js gpu; echo "smoke rc=$?"

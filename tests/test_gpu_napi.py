@@ -1,0 +1,80 @@
+"""GPU: the TypeScript-side host -- bindings/ts/trainer.js (the reference's ``Trainer`` rewritten over the N-API addon) driven by
+node -- against the Python host on the same dataset and the same view draws: steps, a densify/prune rebuild in the middle, more
+steps.  The trained cloud and all six optimizer-state arrays must be byte-identical (both hosts call the same C ABI; this pins the
+binding layer, the recorded command buffers and the sequencing of the JS trainer)."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from webdgs_amd import ops, synth
+from webdgs_amd.trainer import Trainer
+
+import harness
+from harness import assert_bits_equal
+from test_gpu_trainer_oracle import _FixedViews
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_node_trainer_equals_python_trainer(hip_device, orc, tmp_path):
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "bindings", "napi", "webdgs_napi.node")
+    if not node or not os.path.exists(addon):
+        pytest.skip("node or the N-API addon is not available")
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=5000, width=128, height=96, s0=0.01)
+    g, sh, _ = harness.scene(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    cams = synth.circle_cameras(cfg, 4)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    imgs = [orc.forward(tg, tsh, cams[i], st, ti)["rgba8"] for i in range(4)]
+    dens = dict(schedule=dict(enabled=True, warmupIterations=6, interval=50, stopIterations=40), metricViews=3, metricDownscale=2, metricThreshold=0.5,
+                cloneThresholdCount=5, splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300, maxBufferBytes=128 * 1024 * 1024)
+    steps = 11
+    train_views = [2, 0, 3, 1, 1, 2, 0, 3, 2, 2, 1]
+    metric_views = {6: [1, 3, 0]}
+    draws = []
+    for i in range(steps):
+        draws.append(train_views[i])
+        draws += metric_views.get(i + 1, [])
+    g.tofile(tmp_path / "gaussians.bin")
+    sh.tofile(tmp_path / "sh.bin")
+    np.ascontiguousarray(cams, np.float32).tofile(tmp_path / "cameras.bin")
+    np.stack(imgs).tofile(tmp_path / "images.bin")
+    (tmp_path / "meta.json").write_text(json.dumps(dict(num_points=cfg.num_points, sh_deg=cfg.sh_deg, width=cfg.width, height=cfg.height, views=4, steps=steps,
+                                                        draws=draws, densify=dens)))
+    r = subprocess.run([node, os.path.join(ROOT, "bindings", "napi", "trainer_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TRAINER_RUN_OK" in r.stdout, f"exit code {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    out = json.loads((tmp_path / "out_meta.json").read_text())
+    assert out["scan_ok"] and out["sort_ok"], "get_prefix_scanner / get_dynamic_sorter through the addon"
+    assert out["recorded_views"] >= 2, "the JS trainer replays recorded command buffers"
+
+    t = Trainer(dev, seed=0)
+    t.setDensifyPruneConfig(dens)
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset([dict(camera=cams[i], width=cfg.width, height=cfg.height) for i in range(4)],
+                 [dict(texture=dev.bufferFrom(imgs[i]), width=cfg.width, height=cfg.height) for i in range(4)])
+    t.start()
+    t._rng = _FixedViews(draws)
+    sizes = [t.getPointCount()]
+    try:
+        for _ in range(steps):
+            t.step()
+            sizes.append(t.getPointCount())
+        dev.synchronize()
+        n = t.getPointCount()
+        assert out["sizes"] == sizes and out["num_points"] == n and sizes[6] != sizes[5], (out["sizes"], sizes)
+        assert out["iteration"] == t.getIteration() == steps and out["optimizer_iteration"] == t.optimizer.getIteration()
+        assert out["last_densify"] == t.getLastDensifyPruneIteration() == 6 and out["next_densify"] == t.getNextDensifyPruneIteration()
+        assert_bits_equal(np.fromfile(tmp_path / "out_gaussians.bin", np.uint32), t.pointCloud.gaussian_3d_buffer.read(np.uint32)[: n * 6], "node vs python: gaussians")
+        assert_bits_equal(np.fromfile(tmp_path / "out_sh.bin", np.uint32), t.pointCloud.sh_buffer.read(np.uint32)[: n * 24], "node vs python: sh")
+        words = dict(optPosBuffer=12, optRotBuffer=12, optScaleBuffer=12, optOpacityBuffer=3, paramSH=48, stateSH=96)
+        for k, b in t.optimizer.getStateBuffers().items():
+            assert_bits_equal(np.fromfile(tmp_path / f"out_state_{k}.bin", np.uint32), b.read(np.uint32)[: n * words[k]], f"node vs python: state {k}")
+    finally:
+        t.destroy()

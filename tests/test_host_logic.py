@@ -1,5 +1,8 @@
 """CPU: host-side logic that needs no GPU -- synthetic scene generator contract, camera block, densify schedule."""
 import math
+import os
+
+import pytest
 
 import numpy as np
 
@@ -73,3 +76,34 @@ def test_densify_schedule_matches_reference_formula():
     t.densifyPruneConfig["schedule"]["enabled"] = False
     t.iteration = 10
     assert t.getNextDensifyPruneIteration() is None
+
+
+def test_js_host_modules_load_and_mirror_the_reference_surface():
+    """bindings/ts/*.js (the TypeScript-side host: operator classes + Trainer over the N-API addon) load on a CPU-only box and export
+    the reference's names; the JS metrics camera equals the Python one bit for bit (pure host math, no GPU)."""
+    import json
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    node = shutil.which("node")
+    if not node or not os.path.exists(os.path.join(root, "bindings", "napi", "webdgs_napi.node")):
+        pytest.skip("node or the N-API addon is not available")
+    js = ("const hip=require('./bindings/ts/webdgs_hip.js'); const tr=require('./bindings/ts/trainer.js');"
+          "const own=(c)=>Object.getOwnPropertyNames(c.prototype);"
+          "console.log(JSON.stringify({hip:Object.keys(hip), trainer:own(tr.Trainer), fwd:own(hip.TiledForwardPass), dens:own(hip.DensifyPrunePass),"
+          " cam:Array.from(new Uint32Array(tr.cameraBlockFor(new Float32Array(JSON.parse(process.argv[1])),320,240).buffer))}))")
+    from webdgs_amd import synth
+    from webdgs_amd.trainer import Trainer
+    cam = synth.circle_cameras(synth.CONFIGS["c2"], 4)[1]
+    out = json.loads(subprocess.check_output([node, "-e", js, json.dumps([float(x) for x in cam])], text=True, cwd=root))
+    for name in ("TiledForwardPass", "TiledRasterizer", "TiledBackwardPass", "Optimizer", "DensifyPrunePass", "get_prefix_scanner", "get_dynamic_sorter",
+                 "allocatePointCloudLike", "allocateOptimizerStateBuffers"):
+        assert name in out["hip"], name
+    for m in ("setPointCloud", "requestPointCloudSwap", "consumePointCloudSwapRequest", "requestResizeTo", "applyPointCloudSwap", "setDataset", "getTrainingConfig",
+              "setTrainingConfig", "getOptimizerHyperparameters", "setOptimizerHyperparameters", "setDensifyPruneConfig", "start", "stop", "getIsTraining",
+              "setMaxIterations", "getMaxIterations", "getIteration", "getPointCount", "getLastStepMs", "getItersPerSec", "getLastDensifyPruneIteration",
+              "getNextDensifyPruneIteration", "step"):   # trainer.ts:177-566
+        assert m in out["trainer"], m
+    for m in ("encodeDecision", "encodePrefixSum", "encodeCapToMax", "encodeTotalOut", "encodePrepare", "encodeScatter", "ensureSize", "setConfig", "getConfig"):
+        assert m in out["dens"], m
+    assert np.array_equal(np.array(out["cam"], np.uint32), Trainer.metrics_camera(cam, 320, 240).view(np.uint32))
