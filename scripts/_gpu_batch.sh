@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 600 python -m pytest tests/test_gpu_napi.py -q -x > gpurun_out/r02g_napi.log 2>&1; echo "napi pytest rc=$?"; tail -30 gpurun_out/r02g_napi.log
-timeout -k 10 120 node bindings/napi/smoke.js gpu; echo "smoke rc=$?"
+timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py -q -x -k c5_from > gpurun_out/r02_c5ply.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/r02_c5ply.log

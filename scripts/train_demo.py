@@ -2,7 +2,10 @@
 """End-to-end run of the Trainer on a synthetic scene: training steps with the reference's densify schedule, PSNR against the
 ground-truth views and the point count over time.
 
-    python scripts/train_demo.py [config] [iterations] [views]        (default: c3 1200 8; needs an MI355X)
+    python scripts/train_demo.py [config] [iterations] [views] [lr_scale] [report_every] [frozen_rates]   (default: c3 1200 8 1.0 100 ''; needs an MI355X)
+
+lr_scale multiplies the five Adam learning rates: 0.316 (= sqrt(1 - beta2) / (1 - beta1)) makes the first steps as long as
+bias-corrected Adam would, which is how the start-up PSNR dip of the reference's uncorrected Adam is told from a defect.
 """
 import os
 import sys
@@ -20,6 +23,9 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c3"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
     views = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    lr_scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+    every = int(sys.argv[5]) if len(sys.argv) > 5 else 100
+    frozen = [k for k in (sys.argv[6].split(",") if len(sys.argv) > 6 else []) if k]   # e.g. lr_pos,lr_rot,lr_scale: those rates become 0
     cfg = synth.CONFIGS[name]
     dev = ops.HipDevice(0)
     g, sh = synth.make_gaussians(cfg)
@@ -46,6 +52,9 @@ def main():
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
     t.setMaxIterations(10 ** 9)
+    if lr_scale != 1.0 or frozen:
+        hp = t.getOptimizerHyperparameters()
+        t.setOptimizerHyperparameters({k: (0.0 if k in frozen else v * lr_scale) for k, v in hp.items() if k.startswith("lr_")})
     t.start()
 
     def psnr():
@@ -58,13 +67,13 @@ def main():
         return float(np.mean(vals))
 
     t.step()  # builds the pipelines
-    print(f"{name}: {cfg.num_points} Gaussians, {cfg.width}x{cfg.height}, {views} views", flush=True)
+    print(f"{name}: {cfg.num_points} Gaussians, {cfg.width}x{cfg.height}, {views} views, lr x {lr_scale}, frozen {frozen}", flush=True)
     print(f"iter {t.getIteration():5d}  points {t.getPointCount():8d}  PSNR {psnr():6.2f} dB", flush=True)
     t0, last = time.perf_counter(), 1
     while t.getIteration() < iters:
         t.step()
         it = t.getIteration()
-        if it % 100 == 0 or it == iters:
+        if it % every == 0 or it == iters:
             dev.synchronize()
             dt = time.perf_counter() - t0
             st = t.forwardPass.check()

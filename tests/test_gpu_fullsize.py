@@ -250,3 +250,57 @@ def test_c5_full_size_forward_and_train_step_equal_the_oracle(hip_device, orc):
         harness.assert_bits_equal(pipe.pc.sh_buffer.read(np.uint32).reshape(-1, 24), ref_sh, "c5 re-packed SH")
     finally:
         pipe.destroy()
+
+
+def test_c5_from_a_loaded_ply_with_the_50k_densify_equals_the_oracle_trainer(hip_device, orc, tmp_path):
+    """BASELINE config c5 as written (the 8-GPU part aside): 5 M Gaussians LOADED FROM A .ply (written by exportPly, parsed by loadPly:
+    the round trip must reproduce the fp16 cloud bit for bit), a 4K training step, then the densify/prune rebuild with
+    maxNewPointsPerStep = 50 000 over two half-resolution metric views -- the Trainer against the oracle's restatement of trainer.ts,
+    every buffer bit for bit."""
+    from oracle import oracle_trainer
+    from webdgs_amd import loaders
+    from webdgs_amd.trainer import Trainer
+    from test_gpu_trainer_oracle import _FixedViews, _compare
+    cfg = synth.CONFIGS["c5"]
+    g0, sh0 = synth.make_gaussians(cfg)
+    path = tmp_path / "c5.ply"
+    path.write_bytes(loaders.exportPly(g0, sh0, cfg.sh_deg))
+    assert path.stat().st_size > 1_000_000_000
+    pcd = loaders.loadPly(path.read_bytes())
+    path.unlink()
+    g, sh = pcd.gaussians, pcd.sh
+    assert pcd.num_points == cfg.num_points and pcd.sh_deg == cfg.sh_deg
+    harness.assert_bits_equal(g, g0, "c5 Gaussians after the .ply round trip")
+    harness.assert_bits_equal(sh, sh0, "c5 SH after the .ply round trip")
+    del g0, sh0
+    dev = hip_device
+    cams = synth.circle_cameras(cfg, 2)
+    tg, tsh = synth.make_target_scene(g, sh)
+    imgs = []
+    for c in cams:  # ground truth by the HIP forward (equal to the oracle's: test_c5_train_step...), 33 MB each
+        tp = harness.HipPipeline(dev, cfg, tg, tsh, c)
+        tp.forward()
+        imgs.append(tp.rast.getOutputTextureView().read(np.uint8).reshape(cfg.height, cfg.width, 4).copy())
+        tp.destroy()
+    del tg, tsh
+    dens = dict(schedule=dict(enabled=True, warmupIterations=1, interval=1000, stopIterations=10), metricViews=2, metricThreshold=0.5, cloneThresholdCount=1,
+                splitScaleThreshold=0.01, pruneOpacity=0.03, maxNewPointsPerStep=50_000, maxBufferBytes=2 ** 40)
+    # (thresholds chosen from an oracle dry run of this scene so that additions exceed prunes by more than 50 k: the cap binds)
+    o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, list(cams), imgs, densify=dens)
+    t = Trainer(dev, seed=0)
+    t.setDensifyPruneConfig(dens)
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset([dict(camera=cams[i], width=cfg.width, height=cfg.height) for i in range(2)],
+                 [dict(texture=dev.bufferFrom(imgs[i]), width=cfg.width, height=cfg.height) for i in range(2)])
+    t.start()
+    try:
+        t._rng = _FixedViews([1, 0, 1])
+        o.step(1, metric_view_ids=[0, 1])
+        t.step()
+        d = o.last_densify
+        a = d["prepared"]["actions"]
+        assert d["used_views"] == 2 and d["rebuilt"] and min((a == i).sum() for i in range(4)) > 1000, [(a == i).sum() for i in range(4)]
+        assert d["prepared"]["total"] >= d["max_out"] == cfg.num_points + 50_000 == o.num_points, "the 50k cap binds"
+        _compare(t, o, "c5: step + 50k-capped densify")
+    finally:
+        t.destroy()

@@ -1,0 +1,52 @@
+"""CPU: which parameter group limits quality when training with the reference's semantics -- shown on the oracle, whose trajectory
+the HIP trainer equals bit for bit (tests/test_gpu_trainer_oracle.py), so the behaviour is the reference's, not a kernel artefact.
+
+Round 1's only end-to-end quality evidence looked wrong: on c3 PSNR fell from 24.9 dB to 22.2 within 100 iterations and stayed near
+23.  The GPU experiments of round 2 (profiles/r02_psnr_experiments.md) show that with the three GEOMETRY learning rates (position,
+rotation, log-scale) set to zero the same run climbs monotonically to 51 dB, for any learning-rate scale: colour and opacity gradients
+(K16) are right, the geometry chain (K17) is what drives the scene away.  K17 is restated line by line from tiled-backward.wgsl and
+carries the inconsistencies SURVEY lists as Q10 (backward rebuilds the 2D covariance with W = view3x3, forward with its transpose)
+and Q11 (dL/dndc.y takes +0.5 viewport although px.y = (-0.5 ndc.y + 0.5) H: the y gradient of the position has the wrong sign).
+This test reproduces the effect in small: the same schedule reaches a higher PSNR with the geometry rates frozen than with them on."""
+import numpy as np
+
+from webdgs_amd import synth
+
+import harness
+
+
+def _psnr(a, b):
+    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+    mse = float((d * d).mean())
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)
+
+
+def _run(orc, ot, cfg, g, sh, cams, imgs, views, adam):
+    o = ot.OracleTrainer(g, sh, cfg.sh_deg, list(cams), imgs, adam=adam, densify=dict(schedule=dict(enabled=False)))
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    curve = []
+    for i, v in enumerate(views):
+        if i % 20 == 0:
+            curve.append(np.mean([_psnr(orc.forward(o.g, o.sh, cams[k], st, ti)["rgba8"], imgs[k]) for k in range(len(cams))]))
+        o.step(v)
+    curve.append(np.mean([_psnr(orc.forward(o.g, o.sh, cams[k], st, ti)["rgba8"], imgs[k]) for k in range(len(cams))]))
+    return np.array(curve)
+
+
+def test_geometry_rates_limit_the_quality_the_reference_semantics_reach(orc):
+    from oracle import oracle_trainer as ot
+    cfg = harness.small_config("c2", num_points=4000, width=128, height=96, s0=0.012)
+    g, sh, _ = harness.scene(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    cams = synth.circle_cameras(cfg, 4)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    imgs = [orc.forward(tg, tsh, cams[i], st, ti)["rgba8"] for i in range(4)]
+    views = [int(v) for v in np.random.default_rng(3).integers(0, 4, 200)]
+    full = _run(orc, ot, cfg, g, sh, cams, imgs, views, orc.ADAM_DEFAULT.copy())
+    frozen_cfg = orc.ADAM_DEFAULT.copy()
+    frozen_cfg[[0, 3, 4]] = 0.0   # lr_pos, lr_scale, lr_rot (adam-config.ts:12-21 order: pos, color, opacity, scale, rot)
+    frozen = _run(orc, ot, cfg, g, sh, cams, imgs, views, frozen_cfg)
+    print("PSNR every 20 iterations, all rates on        :", np.round(full, 2))
+    print("PSNR every 20 iterations, geometry rates = 0  :", np.round(frozen, 2))
+    assert frozen[-1] > full[-1] + 1.0, "training colour and opacity only ends higher: the geometry gradients hold the full run back"
+    assert frozen[-1] > frozen[0] + 8.0 and (np.diff(frozen) > -0.5).all(), "and that run improves steadily"
