@@ -147,6 +147,12 @@ def main() -> None:
     ap.add_argument("--cpu-baseline-points", type=int, default=0, help="0 = full workload")
     args = ap.parse_args()
 
+    # WDGS_BENCH_WATCHDOG=<seconds>: if the run is still going after that long, every thread's Python stack goes to stderr and the
+    # process exits -- a hung collective then names itself instead of running into the caller's timeout
+    if os.environ.get("WDGS_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["WDGS_BENCH_WATCHDOG"]), exit=True)
+
     import torch
     from webdgs_amd import ops, parallel, synth
     from webdgs_amd.trainer import Trainer

@@ -29,6 +29,9 @@ def main():
         if i == 3:  # ranks in lock-step from here on: the condition under which an unfenced exchange was overtaken by Adam
             torch.cuda.synchronize()
             parallel.barrier()
+        if i == 2 and os.environ.get("WDGS_DP_TEST_WARMUP") == "1":
+            # by now the ranks have recorded DIFFERENT views; the warm-up must still take the same number of (collective) steps on each
+            t.warmupCommandBuffers()
         t.step(ids)
     dev.synchronize()
     own_first, own_count = parallel.owned_range(t.pointCloud.num_points, world, rank)

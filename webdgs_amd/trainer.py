@@ -288,18 +288,16 @@ class Trainer:
         self.backwardPass.encode(encoder, self.rasterizer.getOutputTextureView(), image["texture"], res)
 
     def warmupCommandBuffers(self) -> int:
-        """Runs training steps on every view in turn until each view's command buffer is recorded (the first pass over a
-        dataset does this anyway; calling it up front keeps recording out of a timed region).  Returns the steps taken."""
+        """Records every view's command buffers up front (the first pass over a dataset does this anyway; calling it before a timed
+        region keeps recording out of it).  The number of steps taken is a function of the dataset size ONLY -- never of which
+        buffers this rank happens to hold already: under data parallelism every step is a collective, so all ranks must take the same
+        number of them (a rank-local "skip what is recorded" here once left one rank in the exchange and its peer at the barrier).
+        Two passes: the first step of a fresh trainer runs eagerly (first-use allocations), any later one records."""
         if not self.use_command_buffers or not self.isTraining or self.pointCloud is None:
             return 0
         n_views, taken = self.world_size * self.views_per_rank, 0
-
-        def recorded(v: int) -> bool:
-            if n_views == 1:
-                return ("step", v) in self._cmd_cache
-            return ("view", v, True) in self._cmd_cache and (self.views_per_rank == 1 or ("view", v, False) in self._cmd_cache)
         for v in range(len(self.trainCameras)):
-            while not recorded(v) and taken < 4 * len(self.trainCameras) + 4:  # (every rank walks the same list: collectives stay matched)
+            for _ in range(2 if v == 0 else 1):
                 self.step([v] * n_views)
                 taken += 1
         return taken
