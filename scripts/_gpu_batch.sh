@@ -1,4 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 300 python -m pytest tests/test_gpu_dp.py -q -x > gpurun_out/r02_dp.log 2>&1; echo "dp rc=$?"; tail -5 gpurun_out/r02_dp.log
-WDGS_BENCH_WATCHDOG=100 WDGS_DIST_BACKEND=gloo WDGS_FORCE_DEVICE=0 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --config c2 --steps 10 --warmup 3 --views-per-rank 4 --views 8 > gpurun_out/r02_bench_dp2_gloo_c2.json 2> gpurun_out/r02_bench_dp2_gloo_c2.err; echo "rc=$?"; tail -c 1500 gpurun_out/r02_bench_dp2_gloo_c2.json; grep -v "^\[W\|amdgpu.ids\|^\*\*\*\|OMP_NUM" gpurun_out/r02_bench_dp2_gloo_c2.err | tail -20
+mkdir -p gpurun_out/r02p
+python bench.py --gpus 1 --steps 30 --warmup 5 > gpurun_out/r02p/bench_c3.json 2> gpurun_out/r02p/bench_c3.err; echo "c3 rc=$?"
+python bench.py --gpus 1 --steps 20 --warmup 5 --views-per-rank 8 --no-cpu-baseline --sustained-steps 0 > gpurun_out/r02p/bench_c3_vpr8.json 2> gpurun_out/r02p/bench_c3_vpr8.err; echo "vpr8 rc=$?"
+python bench.py --gpus 1 --config c2 --steps 100 --warmup 10 > gpurun_out/r02p/bench_c2.json 2> gpurun_out/r02p/bench_c2.err; echo "c2 rc=$?"
+python bench.py --gpus 1 --config c5 --steps 10 --warmup 3 --no-cpu-baseline --sustained-steps 0 > gpurun_out/r02p/bench_c5.json 2> gpurun_out/r02p/bench_c5.err; echo "c5 rc=$?"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02p/prof -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --sustained-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/r02p/bench_c3_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/r02p/bench_rocprof.err); echo "rocprof rc=$?"
+bash scripts/pmc.sh r02b c3 3 > gpurun_out/r02p/pmc.log 2>&1; echo "pmc rc=$?"
+python scripts/profile_step.py c5 5 > gpurun_out/r02p/c5_kernel_times.txt 2>&1
+ls gpurun_out/r02p gpurun_out/pmc_r02b | head -40

@@ -4,7 +4,7 @@
 // uncached texture loads per pixel.  Here a workgroup stages the 36x36 halo of a 32x32 tile of both images in LDS as float4
 // texels (clamp-to-edge), converting rgba8unorm -> f32 ONCE per texel through a 256-entry table of i/255 (each entry one
 // correctly rounded division, so values equal the per-tap f32(u8)/255 of the restatement).  HBM traffic is the
-// compulsory 8 B read + 16 B write per pixel; window taps are conflict-free ds_read_b128, shared by four pixels per thread.
+// compulsory 8 B read + 16 B write per pixel; window taps are a conflict-free ds_read_b128 + ds_read_b64, shared by four pixels per thread.
 // The window sums keep the reference's order (dy outer, dx inner, one rounding per add).
 #include "common.h"
 #include "dmath.h"
@@ -24,8 +24,11 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
     __shared__ float s_lut[256];
     // A thread row is 32 lanes on 32 consecutive texels, so each 16-lane group of a ds_read_b128 covers 256 contiguous
     // bytes = every bank once, whatever the row stride.
+    // Texel pair = 24 bytes: {pred.r, pred.g, pred.b, targ.r} + {targ.g, targ.b} (two float4 would carry 8 bytes of padding per texel:
+    // 41.5 KB per workgroup = 3 per CU; at 31 KB five fit, the halo loads of one overlap the window sums of the others and the tail of
+    // the 2040-workgroup grid is shorter).
     __shared__ float4 sp[LH][LH];
-    __shared__ float4 st[LH][LH];
+    __shared__ float2 st[LH][LH];
     s_lut[threadIdx.x] = wd_div((float)threadIdx.x, 255.0f);
     __syncthreads();
     const int bx = blockIdx.x * LT, by = blockIdx.y * LT;
@@ -35,8 +38,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
         gx = gx < 0 ? 0 : (gx > (int)W - 1 ? (int)W - 1 : gx);
         gy = gy < 0 ? 0 : (gy > (int)H - 1 ? (int)H - 1 : gy);
         const u32 a = pred[(size_t)gy * W + gx], b = targ[(size_t)gy * W + gx];
-        sp[hy][hx] = make_float4(s_lut[a & 0xFFu], s_lut[(a >> 8) & 0xFFu], s_lut[(a >> 16) & 0xFFu], 0.0f);
-        st[hy][hx] = make_float4(s_lut[b & 0xFFu], s_lut[(b >> 8) & 0xFFu], s_lut[(b >> 16) & 0xFFu], 0.0f);
+        sp[hy][hx] = make_float4(s_lut[a & 0xFFu], s_lut[(a >> 8) & 0xFFu], s_lut[(a >> 16) & 0xFFu], s_lut[b & 0xFFu]);
+        st[hy][hx] = make_float2(s_lut[(b >> 8) & 0xFFu], s_lut[(b >> 16) & 0xFFu]);
     }
     __syncthreads();
     // Each thread owns PPT vertically adjacent pixels: their 5x5 windows share 8 x 5 texels, so a texel is read from LDS once
@@ -58,12 +61,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
         for (u32 r = 0; r < PPT + 4u; r++) {
 #pragma unroll
             for (u32 c = 0; c < 5u; c++) {
-                const float4 a = sp[ly0 + r][lx + c], b = st[ly0 + r][lx + c];
+                const float4 a = sp[ly0 + r][lx + c];
+                const float2 b = st[ly0 + r][lx + c];
 #pragma unroll
                 for (u32 k = 0; k < PPT; k++)
                     if (r >= k && r <= k + 4u) {
-                        mxa[k] += f2{a.x, a.y}; mxb[k] += f2{a.z, a.w};
-                        mya[k] += f2{b.x, b.y}; myb[k] += f2{b.z, b.w};
+                        mxa[k] += f2{a.x, a.y}; mxb[k].x += a.z;
+                        mya[k] += f2{a.w, b.x}; myb[k].x += b.y;
                     }
             }
             // pin the running sums here: otherwise the adds are sunk to their use and every loaded texel stays live (500 VGPRs)
@@ -84,15 +88,18 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
         for (u32 r = 0; r < PPT + 4u; r++) {
 #pragma unroll
             for (u32 c = 0; c < 5u; c++) {
-                const float4 a = sp[ly0 + r][lx + c], b = st[ly0 + r][lx + c];
+                const float4 a = sp[ly0 + r][lx + c];
+                const float2 b = st[ly0 + r][lx + c];
 #pragma unroll
                 for (u32 k = 0; k < PPT; k++)
                     if (r >= k && r <= k + 4u) {
-                        const f2 daa = f2{a.x, a.y} - ma[k], dab = f2{a.z, a.w} - mb[k];
-                        const f2 dba = f2{b.x, b.y} - na[k], dbb = f2{b.z, b.w} - nb[k];
-                        sx2a[k] += daa * daa; sx2b[k] += dab * dab;
-                        sy2a[k] += dba * dba; sy2b[k] += dbb * dbb;
-                        sxya[k] += daa * dba; sxyb[k] += dab * dbb;
+                        const f2 daa = f2{a.x, a.y} - ma[k];
+                        const float dab = a.z - mb[k].x;
+                        const f2 dba = f2{a.w, b.x} - na[k];
+                        const float dbb = b.y - nb[k].x;
+                        sx2a[k] += daa * daa; sx2b[k].x += dab * dab;
+                        sy2a[k] += dba * dba; sy2b[k].x += dbb * dbb;
+                        sxya[k] += daa * dba; sxyb[k].x += dab * dbb;
                     }
             }
 #pragma unroll
@@ -111,8 +118,9 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
     for (u32 k = 0; k < PPT; k++) {
         const u32 y = y0 + k;
         if (y >= H) break;
-        const float4 p = sp[ly0 + k + 2u][lx + 2u], t = st[ly0 + k + 2u][lx + 2u];
-        const float d[3] = {p.x - t.x, p.y - t.y, p.z - t.z};
+        const float4 p = sp[ly0 + k + 2u][lx + 2u];
+        const float2 t = st[ly0 + k + 2u][lx + 2u];
+        const float d[3] = {p.x - p.w, p.y - t.x, p.z - t.y};
         float g[3] = {0.0f, 0.0f, 0.0f};
         if (dssim) {
 #pragma unroll

@@ -14,15 +14,29 @@ __constant__ float SH_C2c[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315
 __constant__ float SH_C3c[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                 -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
-WD_DEV vec3 sh_coef(const uint16_t* __restrict__ sh_half, u32 c_idx) {
-    // SH is 48 fp16 per Gaussian in [k][rgb] order; element e lives in half-word e.
-    const float r = __half2float(__ushort_as_half(sh_half[c_idx * 3u + 0u]));
-    const float g = __half2float(__ushort_as_half(sh_half[c_idx * 3u + 1u]));
-    const float b = __half2float(__ushort_as_half(sh_half[c_idx * 3u + 2u]));
-    return V3(r, g, b);
+// The SH row of one Gaussian in registers: 48 fp16 in [k][rgb] order = 24 words, fetched as 16-byte loads at the TOP of the kernel
+// together with the Gaussian itself (only the words the degree needs).  Fetching it where the colour is evaluated -- after the
+// culling tests -- put a second, dependent HBM round trip on every wave's critical path; the kernel is latency-bound (18 us per wave
+// for ~1000 instructions: profiles/r02a_pmc.json), so the 7 % of rows fetched for Gaussians that are then culled are well spent.
+struct ShRow { u32 w[24]; };
+WD_DEV ShRow load_sh_row(const u32* __restrict__ sh_buffer, u32 idx, u32 sh_deg) {
+    ShRow r;
+#pragma unroll
+    for (u32 i = 0; i < 24u; i++) r.w[i] = 0u;
+    const uint4* q = reinterpret_cast<const uint4*>(sh_buffer + (size_t)idx * 24);
+    const u32 nq = (sh_deg == 0u) ? 1u : (sh_deg == 1u) ? 2u : (sh_deg == 2u) ? 4u : 6u;  // ceil(6 (deg+1)^2 / 16) 16-byte words
+#pragma unroll
+    for (u32 i = 0; i < 6u; i++)
+        if (i < nq) { const uint4 v = q[i]; r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w; }
+    return r;
 }
+WD_DEV float sh_half(const ShRow& sh, u32 h) {  // element h of the 48; h is a compile-time constant at every call site
+    const u32 w = sh.w[h >> 1];
+    return (h & 1u) ? wd_unpack_hi(w) : wd_unpack_lo(w);
+}
+WD_DEV vec3 sh_coef(const ShRow& sh, u32 c_idx) { return V3(sh_half(sh, c_idx * 3u), sh_half(sh, c_idx * 3u + 1u), sh_half(sh, c_idx * 3u + 2u)); }
 
-WD_DEV vec3 color_from_sh(const uint16_t* __restrict__ sh, vec3 dir, u32 sh_deg) {
+WD_DEV vec3 color_from_sh(const ShRow& sh, vec3 dir, u32 sh_deg) {
     const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
     vec3 result = SH_C0 * sh_coef(sh, 0u);
     if (sh_deg > 0u) {
@@ -104,6 +118,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
             const vec3 gaussian_scale = vexp(V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y)));
             const vec3 pos = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
             const float opacity_raw = wd_unpack_hi(w01.y);
+            const ShRow sh_row = load_sh_row(sh_buffer, idx, wd_to_u32(settings.sh_deg));
             const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
 
             const CameraUniforms& cam = *reinterpret_cast<const CameraUniforms*>(camera_f);
@@ -140,8 +155,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
 
             const vec3 cam_pos = xyz(cam.view_inv.c[3]);
             const vec3 dir = normalize(pos - cam_pos);
-            const uint16_t* shp = reinterpret_cast<const uint16_t*>(sh_buffer + (size_t)idx * 24);
-            const vec3 color = color_from_sh(shp, dir, wd_to_u32(settings.sh_deg));
+            const vec3 color = color_from_sh(sh_row, dir, wd_to_u32(settings.sh_deg));
 
             const u32 num_tiles = (tb.max_x - tb.min_x + 1u) * (tb.max_y - tb.min_y + 1u);
             if (num_tiles > 2048u) break;
