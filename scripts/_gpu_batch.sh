@@ -1,11 +1,10 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02p
-python bench.py --gpus 1 --steps 30 --warmup 5 > gpurun_out/r02p/bench_c3.json 2> gpurun_out/r02p/bench_c3.err; echo "c3 rc=$?"
-python bench.py --gpus 1 --steps 20 --warmup 5 --views-per-rank 8 --no-cpu-baseline --sustained-steps 0 > gpurun_out/r02p/bench_c3_vpr8.json 2> gpurun_out/r02p/bench_c3_vpr8.err; echo "vpr8 rc=$?"
-python bench.py --gpus 1 --config c2 --steps 100 --warmup 10 > gpurun_out/r02p/bench_c2.json 2> gpurun_out/r02p/bench_c2.err; echo "c2 rc=$?"
-python bench.py --gpus 1 --config c5 --steps 10 --warmup 3 --no-cpu-baseline --sustained-steps 0 > gpurun_out/r02p/bench_c5.json 2> gpurun_out/r02p/bench_c5.err; echo "c5 rc=$?"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02p/prof -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --sustained-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/r02p/bench_c3_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/r02p/bench_rocprof.err); echo "rocprof rc=$?"
-bash scripts/pmc.sh r02b c3 3 > gpurun_out/r02p/pmc.log 2>&1; echo "pmc rc=$?"
-python scripts/profile_step.py c5 5 > gpurun_out/r02p/c5_kernel_times.txt 2>&1
-ls gpurun_out/r02p gpurun_out/pmc_r02b | head -40
+python -m pytest tests -m gpu -q -x > gpurun_out/r02i_gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02i_gputest.log; tail -4 gpurun_out/r02i_gputest.log
+python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --sustained-steps 0 > gpurun_out/r02i_bench_c3.json 2> gpurun_out/r02i_bench_c3.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r02i_bench_c3.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["kernel_ms_per_view"])
+PY
+python scripts/profile_step.py c3 10 2>&1 | grep "sort_\|tile_ranges\|kernel sum"

@@ -137,3 +137,49 @@ def test_empty_point_cloud(hip_device):
     finally:
         rast.destroy()
         fwd.destroy()
+
+
+@pytest.mark.parametrize("w,h,fy,kind", [(96, 64, 70.0, "oversized"), (320, 208, 230.0, "lds-two-pass")])
+def test_sort_paths_wide_depth_span_and_oversized_tiles(hip_device, orc, w, h, fy, kind):
+    """The tile-structured sort has three per-tile paths (sort.hip, segment_sort): one 10-bit pass when the tile's depth span is below
+    1024 depth16 steps, two 8-bit passes when it is wider, and the same two passes through global memory for tiles with more than 2048
+    entries.  The synthetic scenes (z in [2, 10]) only ever take the first: here every Gaussian is moved along its view ray by a
+    factor in [0.03, 9] (same pixel footprint, depth16 spanning dozens of exponent steps); a small viewport packs thousands of
+    entries into each tile ("oversized"), a larger one keeps tiles below 2048 entries ("lds-two-pass").  Keys, stable order, ranges,
+    the image and a training step must equal the oracle."""
+    dev = hip_device
+    cfg = harness.small_config("c3", num_points=60_000, width=w, height=h, s0=0.004, fy=fy)
+    g, sh, cam = harness.scene(cfg)
+    rng = np.random.default_rng(11)
+    hv = g.copy().view(np.float16).reshape(-1, 12)
+    f = np.exp(rng.uniform(np.log(0.03), np.log(9.0), cfg.num_points)).astype(np.float32)
+    hv[:, 0:3] = (hv[:, 0:3].astype(np.float32) * f[:, None]).astype(np.float16)          # slide along the ray through the origin
+    hv[:, 8:11] = (hv[:, 8:11].astype(np.float32) + np.log(f)[:, None]).astype(np.float16)  # keep the projected size
+    g = hv.view(np.uint32).reshape(-1, 6)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    ref = orc.forward(g, sh, cam, st, ti)
+    e = ref["total_entries"]
+    keys = ref["sorted_keys"][:e]
+    tiles = keys >> 16
+    counts = np.bincount(tiles, minlength=ti[2] + 2)
+    d16 = (keys & 0xFFFF).astype(np.int64)
+    spans = np.array([d16[tiles == t].max() - d16[tiles == t].min() for t in np.unique(tiles)])
+    if kind == "oversized":
+        assert counts.max() > 2048, "tiles beyond the LDS capacity"
+    else:
+        big = counts[1:ti[2] + 1]
+        assert big.max() <= 2048 and (spans >= 1024).any() and big.max() > 300, "LDS-resident tiles that need the two-pass digit split"
+    tg, tsh = synth.make_target_scene(g, sh)
+    target = orc.forward(tg, tsh, cam, st, ti)["rgba8"]
+    pipe = harness.HipPipeline(dev, cfg, g, sh, cam)
+    try:
+        pipe.forward()
+        got = pipe.collect_forward()
+        assert got["total_entries"] == e
+        assert_bits_equal(got["sorted_keys"], keys, "sorted keys (wide depth span)")
+        assert_bits_equal(got["sorted_values"], ref["sorted_values"][:e], "stable order (wide depth span)")
+        assert_bits_equal(got["tile_ranges"], ref["tile_ranges"], "tile ranges")
+        assert_bits_equal(got["rgba8"], ref["rgba8"], "image")
+    finally:
+        pipe.destroy()
+    _full_step_matches_oracle(orc, dev, cfg, g, sh, cam, target, steps=1)

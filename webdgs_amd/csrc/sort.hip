@@ -259,18 +259,28 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict_
 constexpr u32 SEG_CAP = 2048;                    // entries sorted entirely in LDS
 constexpr u32 SEG_THREADS = 256;
 
-// One stable 8-bit counting pass over n <= SEG_CAP (key, value) pairs: the pairs arrive in REGISTERS (kk, vv: element index
-// i = wave*per_wave + j*64 + lane) and leave in LDS dst at their ranked position.  Wave w owns the contiguous index range
-// [w*per_wave, (w+1)*per_wave) and walks it in rounds of 64 lanes, so (wave, round, lane) is the index order -- which makes the ranking
-// stable -- exactly as sort_scatter does for a global partition.  The caller guarantees that nobody still reads dst.
+// One stable counting pass over n <= SEG_CAP (key, value) pairs on a digit of BITS bits: the pairs arrive in REGISTERS (kk, vv: element
+// index i = wave*per_wave + j*64 + lane) and leave in LDS dst at their ranked position.  digit = (((key & 0xFFFF) - sub) >> shift) &
+// (2^BITS - 1).  Wave w owns the contiguous index range [w*per_wave, (w+1)*per_wave) and walks it in rounds of 64 lanes, so (wave,
+// round, lane) is the index order -- which makes the ranking stable -- exactly as sort_scatter does for a global partition.  The
+// caller guarantees that nobody still reads dst.
 constexpr u32 SEG_ROUNDS = SEG_CAP / SEG_THREADS;
+constexpr u32 SEG_WIDE_BITS = 10;              // one pass sorts a segment whose depth span is below 2^10 (z within a factor ~256)
+constexpr u32 SEG_BINS = 1u << SEG_WIDE_BITS;  // bins held per wave in LDS
+typedef unsigned short seg_hist_t;             // counts and positions are <= SEG_CAP: 16 bits keep the four per-wave tables at 8 KB
+template <u32 BITS>
 __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const u32 (&vv)[SEG_ROUNDS], u32* __restrict__ dst_k, u32* __restrict__ dst_v, u32 n,
-                                              u32 per_wave, u32 shift, u32 (*whist)[RADIX], u32* s_wsum) {
+                                              u32 per_wave, u32 sub, u32 shift, seg_hist_t (*whist)[SEG_BINS], u32* s_wsum) {
+    constexpr u32 BINS = 1u << BITS, PER_THREAD = BINS / SEG_THREADS;  // digits per thread in the scan (1 or 4)
+    static_assert(BINS <= SEG_BINS && BINS % SEG_THREADS == 0, "digit width");
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 rounds = per_wave / 64u;  // <= SEG_ROUNDS, uniform per workgroup
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto digit_of = [&](u32 key) { return (((key & 0xFFFFu) - sub) >> shift) & (BINS - 1u); };
 #pragma unroll
-    for (u32 w = 0; w < SEG_THREADS / 64; w++) whist[w][threadIdx.x] = 0;
+    for (u32 w = 0; w < SEG_THREADS / 64; w++)
+#pragma unroll
+        for (u32 j = 0; j < PER_THREAD; j++) whist[w][threadIdx.x * PER_THREAD + j] = 0;
     __syncthreads();
     u32 rk[SEG_ROUNDS];
 #pragma unroll
@@ -278,10 +288,10 @@ __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const
         if (j < rounds) {
             const u32 i = wave * per_wave + j * 64u + lane;
             const bool valid = i < n;
-            const u32 digit = (kk[j] >> shift) & (RADIX - 1u);
+            const u32 digit = digit_of(kk[j]);
             unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (u32 b = 0; b < 8; b++) {
+            for (u32 b = 0; b < BITS; b++) {
                 const bool bit = (digit >> b) & 1u;
                 const unsigned long long bal = __ballot(bit);
                 m &= bit ? bal : ~bal;
@@ -289,16 +299,21 @@ __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const
             const u32 pre = whist[wave][digit];
             const u32 below = (u32)__popcll(m & lt_mask);
             rk[j] = pre + below;
-            if (valid && below == 0u) whist[wave][digit] = pre + (u32)__popcll(m);
+            if (valid && below == 0u) whist[wave][digit] = (seg_hist_t)(pre + (u32)__popcll(m));
         }
     }
     __syncthreads();
-    {   // exclusive scan over the 256 digits of the per-digit totals; per-wave starts within each digit
-        const u32 d = threadIdx.x;
-        u32 cnt_d = 0;
+    {   // exclusive scan over the digits of the per-digit totals (PER_THREAD consecutive digits per thread); per-wave starts per digit
+        u32 cnt[PER_THREAD], tsum = 0;
 #pragma unroll
-        for (u32 w = 0; w < SEG_THREADS / 64; w++) cnt_d += whist[w][d];
-        u32 inc = cnt_d;
+        for (u32 j = 0; j < PER_THREAD; j++) {
+            const u32 d = threadIdx.x * PER_THREAD + j;
+            cnt[j] = 0;
+#pragma unroll
+            for (u32 w = 0; w < SEG_THREADS / 64; w++) cnt[j] += whist[w][d];
+            tsum += cnt[j];
+        }
+        u32 inc = tsum;
 #pragma unroll
         for (u32 sft = 1; sft < 64; sft <<= 1) {
             const u32 t = __shfl_up(inc, sft, 64);
@@ -306,15 +321,18 @@ __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const
         }
         if (lane == 63u) s_wsum[wave] = inc;
         __syncthreads();
-        u32 woff = 0;
+        u32 run = inc - tsum;
 #pragma unroll
-        for (u32 w = 0; w < SEG_THREADS / 64; w++) if (w < wave) woff += s_wsum[w];
-        u32 run = woff + inc - cnt_d;
+        for (u32 w = 0; w < SEG_THREADS / 64; w++) if (w < wave) run += s_wsum[w];
 #pragma unroll
-        for (u32 w = 0; w < SEG_THREADS / 64; w++) {
-            const u32 c = whist[w][d];
-            whist[w][d] = run;
-            run += c;
+        for (u32 j = 0; j < PER_THREAD; j++) {
+            const u32 d = threadIdx.x * PER_THREAD + j;
+#pragma unroll
+            for (u32 w = 0; w < SEG_THREADS / 64; w++) {
+                const u32 c = whist[w][d];
+                whist[w][d] = (seg_hist_t)run;
+                run += c;
+            }
         }
     }
     __syncthreads();
@@ -323,7 +341,7 @@ __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const
         if (j < rounds) {
             const u32 i = wave * per_wave + j * 64u + lane;
             if (i < n) {
-                const u32 pos = whist[wave][(kk[j] >> shift) & (RADIX - 1u)] + rk[j];
+                const u32 pos = (u32)whist[wave][digit_of(kk[j])] + rk[j];
                 dst_k[pos] = kk[j];
                 dst_v[pos] = vv[j];
             }
@@ -335,7 +353,7 @@ __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const
 // Segments longer than SEG_CAP: the same two stable passes, through global memory.  pass: histogram of the whole segment, exclusive
 // scan, then the chunks of 256 in index order, each ranked stably (wave ballots + earlier waves' counts) on top of running digit bases.
 __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __restrict__ src_v, u32* __restrict__ dst_k, u32* __restrict__ dst_v, u32 n,
-                                u32 shift, u32 (*whist)[RADIX], u32* s_base /*[RADIX]*/, u32* s_wsum) {
+                                u32 shift, seg_hist_t (*whist)[SEG_BINS], u32* s_base /*[RADIX]*/, u32* s_wsum) {
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     s_base[threadIdx.x] = 0u;
@@ -375,7 +393,7 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 #pragma unroll
         for (u32 w = 0; w < SEG_THREADS / 64; w++) whist[w][threadIdx.x] = 0u;
         __syncthreads();
-        if (valid && below == 0u) whist[wave][digit] = (u32)__popcll(m);  // this wave's count of the digit in this chunk
+        if (valid && below == 0u) whist[wave][digit] = (seg_hist_t)__popcll(m);  // this wave's count of the digit in this chunk
         __syncthreads();
         u32 earlier = 0;
 #pragma unroll
@@ -400,10 +418,11 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
                                                                     u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles) {
     __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP];  // one pair: every pass reads its input into registers before anyone scatters
-    __shared__ u32 whist[SEG_THREADS / 64][RADIX];
+    __shared__ seg_hist_t whist[SEG_THREADS / 64][SEG_BINS];
     __shared__ u32 s_base[RADIX];
     __shared__ u32 s_wsum[SEG_THREADS / 64];
     __shared__ u32 s_end;
+    __shared__ u32 s_min[SEG_THREADS / 64], s_max[SEG_THREADS / 64];
     const u32 t = blockIdx.x;
     const u32 start = ranges[t];
     if (start == 0xFFFFFFFFu) return;  // empty tile (uniform per workgroup)
@@ -430,16 +449,37 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
             kk[j] = valid ? cur_k[start + i] : 0xFFFFFFFFu;
             vv[j] = valid ? cur_v[start + i] : 0u;
         }
-        seg_pass_regs(kk, vv, a_k, a_v, n, per_wave, 0u, whist, s_wsum);   // low depth byte
+        // depth span of the segment: when max - min < 2^10 (a tile whose splats lie within a factor ~256 in depth -- nearly always) ONE
+        // pass on the 10-bit digit (depth16 - min) sorts it; otherwise the two 8-bit passes on the raw depth bytes
+        u32 lo16 = 0xFFFFu, hi16 = 0u;
 #pragma unroll
-        for (u32 j = 0; j < SEG_ROUNDS; j++) {  // LDS -> registers in index order again
+        for (u32 j = 0; j < SEG_ROUNDS; j++) {
             const u32 i = wave * per_wave + j * 64u + lane;
-            const bool valid = j < rounds && i < n;
-            kk[j] = valid ? a_k[i] : 0xFFFFFFFFu;
-            vv[j] = valid ? a_v[i] : 0u;
+            if (j < rounds && i < n) { lo16 = min(lo16, kk[j] & 0xFFFFu); hi16 = max(hi16, kk[j] & 0xFFFFu); }
         }
-        __syncthreads();  // everyone holds its pairs: a_k / a_v may be overwritten
-        seg_pass_regs(kk, vv, a_k, a_v, n, per_wave, 8u, whist, s_wsum);   // high depth byte
+#pragma unroll
+        for (u32 d = 32; d >= 1; d >>= 1) {
+            lo16 = min(lo16, (u32)__shfl_xor((int)lo16, (int)d, 64));
+            hi16 = max(hi16, (u32)__shfl_xor((int)hi16, (int)d, 64));
+        }
+        if (lane == 0u) { s_min[wave] = lo16; s_max[wave] = hi16; }
+        __syncthreads();
+        lo16 = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        hi16 = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (hi16 - lo16 < SEG_BINS) {   // uniform per workgroup
+            seg_pass_regs<SEG_WIDE_BITS>(kk, vv, a_k, a_v, n, per_wave, lo16, 0u, whist, s_wsum);
+        } else {
+            seg_pass_regs<8>(kk, vv, a_k, a_v, n, per_wave, 0u, 0u, whist, s_wsum);   // low depth byte
+#pragma unroll
+            for (u32 j = 0; j < SEG_ROUNDS; j++) {  // LDS -> registers in index order again
+                const u32 i = wave * per_wave + j * 64u + lane;
+                const bool valid = j < rounds && i < n;
+                kk[j] = valid ? a_k[i] : 0xFFFFFFFFu;
+                vv[j] = valid ? a_v[i] : 0u;
+            }
+            __syncthreads();  // everyone holds its pairs: a_k / a_v may be overwritten
+            seg_pass_regs<8>(kk, vv, a_k, a_v, n, per_wave, 0u, 8u, whist, s_wsum);   // high depth byte
+        }
         for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) { cur_k[start + i] = a_k[i]; cur_v[start + i] = a_v[i]; }
     } else {
         seg_pass_global(cur_k + start, cur_v + start, alt_k + start, alt_v + start, n, 0u, whist, s_base, s_wsum);
