@@ -68,9 +68,18 @@ static vec3 computeSSIMGrad(const uint8_t* pred_img, const uint8_t* targ_img, u3
             const vec3 x = texel_rgb(pred_img, W, H, cx + dx, cy + dy);
             const vec3 y = texel_rgb(targ_img, W, H, cx + dx, cy + dy);
             const vec3 dx_val = x - mu_x, dy_val = y - mu_y;
-            sigma_x2 = sigma_x2 + dx_val * dx_val;
-            sigma_y2 = sigma_y2 + dy_val * dy_val;
-            sigma_xy = sigma_xy + dx_val * dy_val;
+            if (g_literal_order) {
+                sigma_x2 = sigma_x2 + dx_val * dx_val;
+                sigma_y2 = sigma_y2 + dy_val * dy_val;
+                sigma_xy = sigma_xy + dx_val * dy_val;
+            } else {
+                // pinned contraction (WGSL may fuse a multiply into the add that consumes it): the window accumulations are FMAs
+                for (int c = 0; c < 3; c++) {
+                    sigma_x2[c] = std::fmaf(dx_val[c], dx_val[c], sigma_x2[c]);
+                    sigma_y2[c] = std::fmaf(dy_val[c], dy_val[c], sigma_y2[c]);
+                    sigma_xy[c] = std::fmaf(dx_val[c], dy_val[c], sigma_xy[c]);
+                }
+            }
         }
     sigma_x2 = sigma_x2 / n;
     sigma_y2 = sigma_y2 / n;

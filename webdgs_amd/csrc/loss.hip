@@ -5,7 +5,8 @@
 // texels (clamp-to-edge), converting rgba8unorm -> f32 ONCE per texel through a 256-entry table of i/255 (each entry one
 // correctly rounded division, so values equal the per-tap f32(u8)/255 of the restatement).  HBM traffic is the
 // compulsory 8 B read + 16 B write per pixel; window taps are a conflict-free ds_read_b128 + ds_read_b64, shared by four pixels per thread.
-// The window sums keep the reference's order (dy outer, dx inner, one rounding per add).
+// The window sums keep the reference's order (dy outer, dx inner); the second-moment accumulations are FMAs, the contraction the
+// parity oracle pins (WGSL leaves it open).
 #include "common.h"
 #include "dmath.h"
 
@@ -97,9 +98,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
                         const float dab = a.z - mb[k].x;
                         const f2 dba = f2{a.w, b.x} - na[k];
                         const float dbb = b.y - nb[k].x;
-                        sx2a[k] += daa * daa; sx2b[k].x += dab * dab;
-                        sy2a[k] += dba * dba; sy2b[k].x += dbb * dbb;
-                        sxya[k] += daa * dba; sxyb[k].x += dab * dbb;
+                        // the window accumulations are FMAs (the pinned contraction of the parity oracle: WGSL may fuse the multiply)
+                        sx2a[k].x = __builtin_fmaf(daa.x, daa.x, sx2a[k].x); sx2a[k].y = __builtin_fmaf(daa.y, daa.y, sx2a[k].y);
+                        sx2b[k].x = __builtin_fmaf(dab, dab, sx2b[k].x);
+                        sy2a[k].x = __builtin_fmaf(dba.x, dba.x, sy2a[k].x); sy2a[k].y = __builtin_fmaf(dba.y, dba.y, sy2a[k].y);
+                        sy2b[k].x = __builtin_fmaf(dbb, dbb, sy2b[k].x);
+                        sxya[k].x = __builtin_fmaf(daa.x, dba.x, sxya[k].x); sxya[k].y = __builtin_fmaf(daa.y, dba.y, sxya[k].y);
+                        sxyb[k].x = __builtin_fmaf(dab, dbb, sxyb[k].x);
                     }
             }
 #pragma unroll
