@@ -121,7 +121,8 @@ void orc_loss_grad(u32 W, u32 H, const uint8_t* pred, const uint8_t* targ, const
 // K16 tiled-backward-rasterize.wgsl:34-172.  Accumulators are the reference's four i32 arrays
 // (means[2N], conics[4N] slots 0,1,3, opacity[N], colors[3N]); they are added to, not cleared here
 // (the reference clears them with clearBuffer before the pass, tiled-backward-pass.ts:624-627).
-// Contraction choice pinned as in K14: power = fma(fma(cx,dx,(2cy)*dy), dx, (cz*dy)*dy).
+// Contraction choices pinned as in K14: power = fma(fma(cx,dx,(2cy)*dy), dx, (cz*dy)*dy); the accum_rec, dL_dalpha and dpow
+// multiply-adds are FMAs (see the loop).
 void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, const u32* tile_instances, const u32* splats,
                             const f32* final_Ts, const u32* n_contrib_tex, const f32* loss_gradient,
                             i32* grad_means_2d, i32* grad_conics, i32* grad_opacity, i32* grad_colors) {
@@ -194,21 +195,31 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
                 if (alpha < 1.0f / 255.0f) continue;
                 T = T / (1.0f - alpha);
                 f32 dL_dalpha = 0.0f;
-                accum_rec = last_alpha * last_color + (1.0f - last_alpha) * accum_rec;
+                // Pinned contraction (WGSL may fuse a multiply into the add that consumes it; `literal` keeps one rounding per operator):
+                //   accum_rec = fma(last_alpha, last_color, (1 - last_alpha) * accum_rec);  dL_dalpha = fma(color - accum_rec, grad, dL_dalpha);
+                //   dpow_dx = fma(2 cx, dx, (2 cy) dy);  dpow_dy = fma(2 cz, dy, (2 cy) dx)
+                if (g_literal_order) {
+                    accum_rec = last_alpha * last_color + (1.0f - last_alpha) * accum_rec;
+                } else {
+                    for (u32 ch = 0; ch < 3u; ch++) accum_rec[ch] = std::fmaf(last_alpha, last_color[ch], (1.0f - last_alpha) * accum_rec[ch]);
+                }
                 for (u32 ch = 0; ch < 3u; ch++) {
                     const f32 grad_pix = dL_dpixel[ch];
                     const f32 dchannel_dcolor = alpha * T;
                     const f32 dL_dc = dchannel_dcolor * grad_pix;
                     L[6u + ch] += (u32)to_fixed(dL_dc);
-                    dL_dalpha += (color[ch] - accum_rec[ch]) * grad_pix;
+                    if (g_literal_order) dL_dalpha += (color[ch] - accum_rec[ch]) * grad_pix;
+                    else dL_dalpha = std::fmaf(color[ch] - accum_rec[ch], grad_pix, dL_dalpha);
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
                 last_color = color;
                 const f32 dL_dG = opacity * dL_dalpha;
                 const f32 dL_dopacity = G * dL_dalpha;
-                const f32 dpow_dx = 2.0f * conic.x * delta.x + 2.0f * conic.y * delta.y;
-                const f32 dpow_dy = 2.0f * conic.z * delta.y + 2.0f * conic.y * delta.x;
+                const f32 dpow_dx = g_literal_order ? 2.0f * conic.x * delta.x + 2.0f * conic.y * delta.y
+                                                    : std::fmaf(2.0f * conic.x, delta.x, (2.0f * conic.y) * delta.y);
+                const f32 dpow_dy = g_literal_order ? 2.0f * conic.z * delta.y + 2.0f * conic.y * delta.x
+                                                    : std::fmaf(2.0f * conic.z, delta.y, (2.0f * conic.y) * delta.x);
                 const f32 dG_ddelta_x = -0.5f * G * dpow_dx;
                 const f32 dG_ddelta_y = -0.5f * G * dpow_dy;
                 const f32 dL_dmean_x = dL_dG * (-dG_ddelta_x);

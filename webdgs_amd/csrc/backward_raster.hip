@@ -198,22 +198,23 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
                 // order (tiled-backward-rasterize.wgsl:108-160).
                 T = wd_div(T, 1.0f - alpha);
                 const float oml = 1.0f - la;
-                ar_rg = la * lc_rg + oml * ar_rg;
-                ar_b = la * lc_b + oml * ar_b;
+                // (multiply-adds below are FMAs where the parity oracle pins them: accum_rec, dL_dalpha, dpow)
+                ar_rg = f2{__builtin_fmaf(la, lc_rg.x, oml * ar_rg.x), __builtin_fmaf(la, lc_rg.y, oml * ar_rg.y)};
+                ar_b = __builtin_fmaf(la, lc_b, oml * ar_b);
                 const float aT = alpha * T;
                 const f2 frg = (aT * g_rg) * FIXED_SCALE;
                 f_r = cvt_fixed(frg.x);
                 f_g = cvt_fixed(frg.y);
                 f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
                 const f2 col_rg = f2{col.x, col.y};
-                const f2 p_rg = (col_rg - ar_rg) * g_rg;
+                const f2 dc_rg = col_rg - ar_rg;
                 // (the reference starts this sum from 0.0; that only decides the sign of an all-zero sum, which the fixed-point
                 // conversion of every product it feeds maps to 0 either way)
-                const float dL_dalpha = ((p_rg.x + p_rg.y) + (col.z - ar_b) * g_b) * T;
+                const float dL_dalpha = __builtin_fmaf(col.z - ar_b, g_b, __builtin_fmaf(dc_rg.y, g_rg.y, dc_rg.x * g_rg.x)) * T;
                 la = alpha; lc_rg = col_rg; lc_b = col.z;
                 const float dL_dG = con.w * dL_dalpha;
                 f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
-                const f2 dpow = f2{aux.y, aux.w} * d + f2{aux.z, aux.z} * f2{d.y, d.x};  // (dpow/ddx, dpow/ddy)
+                const f2 dpow = f2{__builtin_fmaf(aux.y, d.x, aux.z * d.y), __builtin_fmaf(aux.w, d.y, aux.z * d.x)};  // (dpow/ddx, dpow/ddy)
                 const float mhG = -0.5f * G;
                 const f2 dG = mhG * dpow;
                 const f2 fm = (dL_dG * (-dG)) * FIXED_SCALE;
