@@ -183,3 +183,29 @@ def test_sort_paths_wide_depth_span_and_oversized_tiles(hip_device, orc, w, h, f
     finally:
         pipe.destroy()
     _full_step_matches_oracle(orc, dev, cfg, g, sh, cam, target, steps=1)
+
+
+def test_needle_splats_and_marginal_opacities(hip_device, orc):
+    """Adversarial input for the block-level alpha test of backward_rasterize (a CONSERVATIVE cull: it may only drop a splat from an
+    8x8 block when no pixel of the block can reach alpha >= 1/255): needles with axis ratios up to 300:1 at random orientations --
+    their bounding boxes are mostly empty corners, exactly what the test culls -- large screen footprints, and opacities spread down
+    to the 1/128 visibility threshold, where the 1/255 contour hugs the box.  Every accumulator must still equal the oracle."""
+    cfg = harness.small_config("c3", num_points=12_000, width=208, height=144, s0=0.01, fy=160.0)
+    g, sh, cam = harness.scene(cfg)
+    rng = np.random.default_rng(5)
+    hv = g.copy().view(np.float16).reshape(-1, 12)
+    n = cfg.num_points
+    axis = rng.integers(0, 3, n)
+    stretch = np.where(rng.random(n) < 0.5, rng.uniform(np.log(10.0), np.log(30.0), n), 0.0).astype(np.float32)
+    ls = hv[:, 8:11].astype(np.float32)
+    ls[np.arange(n), axis] += stretch                       # one axis up to 30x longer (on top of the generator's 10:1 spread)
+    hv[:, 8:11] = ls.astype(np.float16)
+    hv[:, 3] = rng.uniform(-4.8, 3.0, n).astype(np.float16)  # sigmoid(-4.8) = 0.0082: just above the 1/128 = 0.0078 cull
+    g = hv.view(np.uint32).reshape(-1, 6)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    tg, tsh = synth.make_target_scene(g, sh)
+    target = orc.forward(tg, tsh, cam, st, ti)["rgba8"]
+    ref = orc.forward(g, sh, cam, st, ti)
+    assert (ref["tile_counts"] > 0).sum() > 5000 and ref["total_entries"] > 100_000
+    _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target, steps=2)
+    _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target, steps=1, max_radius=-1.0)  # radius cap lifted: footprints of hundreds of pixels
