@@ -1,5 +1,5 @@
 // N-API addon over the C ABI of libwebdgs_hip.so (include/webdgs.h) -- the binding a WebDGS maintainer would add so that
-// the TypeScript host (bindings/ts/webdgs_hip.ts, shaped like the reference's src/renderers/*.ts) drives the HIP kernels.
+// the TypeScript-side host (bindings/ts/webdgs_hip.js + .d.ts and trainer.js, shaped like the reference's src/renderers/*.ts) drives the HIP kernels.
 // Handles and device pointers cross the boundary as BigInt (64-bit); configs cross as plain objects.
 // Build: make -C bindings/napi   (g++, /usr/include/node/node_api.h; no node-gyp needed).
 #include <node_api.h>
