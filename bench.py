@@ -140,6 +140,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", help="c3 (headline), c3-small, c2, c1, c5 -- only c3 is the BASELINE metric")
     ap.add_argument("--views", type=int, default=0, help="training views in the dataset (default: 8 at N = 1, 64 at N > 1)")
+    ap.add_argument("--lanes", type=int, default=0, help="device lanes a batched step deals its views to (0 = the Trainer's default; 1 = no overlap)")
     ap.add_argument("--views-per-rank", type=int, default=0, help="views per rank per global step (default: 1 at N = 1, 8 at N > 1)")
     ap.add_argument("--sustained-steps", type=int, default=620, help="N = 1: length of the densify-inclusive leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,7 +175,8 @@ def main() -> None:
     cams = synth.circle_cameras(cfg, n_dataset)
     cameras, images = make_dataset(dev, cfg, tg, tsh, cams)
 
-    trainer = Trainer(dev, seed=1234, world_size=world, rank=rank, views_per_rank=vpr)
+    trainer = Trainer(dev, seed=1234, world_size=world, rank=rank, views_per_rank=vpr, overlap_views=args.lanes or None)
+    lanes = trainer._op_sets
     trainer.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     trainer.setDataset(cameras, images)
     trainer.setMaxIterations(10 ** 9)
@@ -310,7 +312,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "head": head_commit(),
             "config": {"workload": f"{cfg.name}: {n} Gaussians, {cfg.width}x{cfg.height}, SH deg {cfg.sh_deg}, fwd+bwd per view, {n_dataset} circle views"
                                    + (" (BASELINE c3: the reference's one-view step)" if views_per_step == 1 else f" (BASELINE c4 shape: {vpr} views per rank per global step)"),
-                       "views_per_rank": vpr, "global_batch_views": views_per_step,
+                       "views_per_rank": vpr, "global_batch_views": views_per_step, "lanes": lanes,
                        "parallelism": (f"dp{world}: views sharded; per global step one reduce-scatter (60 B/Gaussian) -> Adam on the owned 1/{world} slice -> "
                                        f"all-gather (32 B/Gaussian) over RCCL") if world > 1 else "single GPU",
                        "tile_entries_E": e_entries, "visible_V": v_visible, "contributing_pairs_C_upper": pairs,

@@ -27,6 +27,9 @@ export class HipDevice {
   createPinnedArrayBuffer(byteLength: number): ArrayBuffer;
   readBufferAsync(buffer: HipBuffer, offset: number, pinned: ArrayBuffer, byteLength: number): Promise<ArrayBuffer>;
   synchronize(): void;
+  /** Lanes (include/webdgs.h): lane 0 is the device's stream, 1..3 internal ones; work on different lanes may overlap. */
+  selectLane(lane: number): void;
+  laneOrder(waiterLane: number, signalLane: number): void;
   destroy(): void;
 }
 

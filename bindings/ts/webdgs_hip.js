@@ -74,6 +74,8 @@ class HipDevice {                        // GPUDevice + GPUQueue
   }
   /** Blocking variant of onSubmittedWorkDone; also raises deferred capacity errors (code WDGS_E_CAPACITY). */
   synchronize() { addon.deviceSynchronize(this.handle); }
+  selectLane(lane) { addon.deviceSelectLane(this.handle, lane); }            // include/webdgs.h "Lanes"
+  laneOrder(waiter, signal) { addon.deviceLaneOrder(this.handle, waiter, signal); }
   destroy() { if (this.handle !== null) { addon.encoderAbort(this.handle); addon.deviceDestroy(this.handle); this.handle = null; } }
 }
 

@@ -81,6 +81,18 @@ typedef struct wdgs_kernel_time {
 } wdgs_kernel_time;
 int wdgs_device_get_kernel_times(wdgs_device* dev, wdgs_kernel_time* out, uint32_t cap, uint32_t* count);
 int wdgs_device_reset_kernel_times(wdgs_device* dev);
+/* Lanes.  A device has WDGS_MAX_LANES in-order queues: lane 0 is its stream (the one given to wdgs_device_create), the others are
+ * internal and created on first use.  wdgs_device_select_lane makes `lane` the target of every later encode / submit / copy; work
+ * on different lanes may run concurrently and is ordered only where wdgs_device_lane_order says so: everything submitted to lane
+ * `waiter` after the call runs after everything submitted to lane `signal` before it (an event, no host wait).
+ * wdgs_device_synchronize waits for all of them.  The reference has one GPUQueue and no counterpart; a batched step
+ * (views_per_rank > 1, BASELINE config c4) uses the lanes to run the bandwidth-bound stages of one view beside the rasterization
+ * kernels of another.  Each lane needs its own forward / rasterizer / backward ops (their intermediate buffers are per op); the
+ * point cloud is shared read-only until the lanes are joined in front of the optimizer step.  Neither call is allowed while
+ * recording. */
+#define WDGS_MAX_LANES 4
+int wdgs_device_select_lane(wdgs_device* dev, int lane);
+int wdgs_device_lane_order(wdgs_device* dev, int waiter_lane, int signal_lane);
 
 /* ---------------------------------------------------------------- recorded command buffers (hipGraph)
  * Replaces device.createCommandEncoder() ... encoder.finish() -> GPUCommandBuffer -> queue.submit([cmd]) (trainer.ts:603-645).

@@ -97,6 +97,8 @@ SIGNATURES = {
     "wdgs_device_set_profiling": (_I, [_P, _I]),
     "wdgs_device_get_kernel_times": (_I, [_P, C.POINTER(KernelTime), _U, C.POINTER(_U)]),
     "wdgs_device_reset_kernel_times": (_I, [_P]),
+    "wdgs_device_select_lane": (_I, [_P, _I]),
+    "wdgs_device_lane_order": (_I, [_P, _I, _I]),
     "wdgs_encoder_begin": (_I, [_P]),
     "wdgs_encoder_finish": (_I, [_P, C.POINTER(_P)]),
     "wdgs_encoder_abort": (_I, [_P]),

@@ -51,7 +51,7 @@ bool wdgs_device_alive(const wdgs_device* d) {
 }
 // stream of a live device that is not in the middle of a recording, else nullptr ("nothing to wait for")
 static void sync_if_alive(wdgs_device* d) {
-    if (wdgs_device_alive(d) && !d->capturing) (void)hipStreamSynchronize(d->stream);
+    if (wdgs_device_alive(d) && !d->capturing) (void)wdgs_sync_lanes(d);
 }
 
 void wdgs_set_error(const char* fmt, ...) {
@@ -178,8 +178,36 @@ int wdgs_device_create(int ordinal, void* external_stream, wdgs_device** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess) d->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d->lanes[0] = d->stream;
     { std::lock_guard<std::mutex> lock(g_live_mutex); g_live_devices.insert(d); }
     *out = d;
+    return WDGS_OK;
+}
+
+// ---- lanes: in-order streams of one device, ordered against each other only where the host says so ----
+int wdgs_device_select_lane(wdgs_device* d, int lane) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_select_lane: null device");
+    WDGS_REQUIRE(lane >= 0 && lane < WDGS_MAX_LANES, WDGS_E_INVALID, "wdgs_device_select_lane: lane %d (0..%d)", lane, WDGS_MAX_LANES - 1);
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_select_lane while recording a command buffer");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    if (!d->lanes[lane]) WDGS_CHECK_HIP(hipStreamCreateWithFlags(&d->lanes[lane], hipStreamNonBlocking));
+    d->stream = d->lanes[lane];
+    d->lane = lane;
+    return WDGS_OK;
+}
+
+int wdgs_device_lane_order(wdgs_device* d, int waiter, int signal) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_lane_order: null device");
+    WDGS_REQUIRE(waiter >= 0 && waiter < WDGS_MAX_LANES && signal >= 0 && signal < WDGS_MAX_LANES, WDGS_E_INVALID, "wdgs_device_lane_order: lanes %d, %d (0..%d)", waiter,
+                 signal, WDGS_MAX_LANES - 1);
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_lane_order while recording a command buffer");
+    if (waiter == signal || !d->lanes[signal]) return WDGS_OK;  // a lane is in order with itself; a lane never used has nothing pending
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    if (!d->lanes[waiter]) WDGS_CHECK_HIP(hipStreamCreateWithFlags(&d->lanes[waiter], hipStreamNonBlocking));
+    // one event per signalling lane: a wait refers to the record that precedes it, so re-recording the event later is safe
+    if (!d->lane_events[signal]) WDGS_CHECK_HIP(hipEventCreateWithFlags(&d->lane_events[signal], hipEventDisableTiming));
+    WDGS_CHECK_HIP(hipEventRecord(d->lane_events[signal], d->lanes[signal]));
+    WDGS_CHECK_HIP(hipStreamWaitEvent(d->lanes[waiter], d->lane_events[signal], 0));
     return WDGS_OK;
 }
 
@@ -202,7 +230,7 @@ int wdgs_device_synchronize(wdgs_device* d) {
     WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_synchronize: null device");
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_synchronize while recording a command buffer");
     WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
-    WDGS_CHECK_HIP(hipStreamSynchronize(d->stream));
+    WDGS_CHECK_HIP(wdgs_sync_lanes(d));
     collect_profile(d);
     for (wdgs_tiled_forward* f : d->forwards) {
         if (!f->encoded) continue;
@@ -228,10 +256,13 @@ int wdgs_device_destroy(wdgs_device* d) {
         if (g) (void)hipGraphDestroy(g);
         d->capturing = false;
     }
-    (void)hipStreamSynchronize(d->stream);
+    (void)wdgs_sync_lanes(d);
     collect_profile(d);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
-    if (d->own_stream) (void)hipStreamDestroy(d->stream);
+    for (hipEvent_t e : d->lane_events) if (e) (void)hipEventDestroy(e);
+    for (int l = 1; l < WDGS_MAX_LANES; l++)
+        if (d->lanes[l]) (void)hipStreamDestroy(d->lanes[l]);
+    if (d->own_stream) (void)hipStreamDestroy(d->lanes[0]);
     delete d;
     return WDGS_OK;
 }
@@ -335,7 +366,7 @@ int wdgs_copy_to_host(wdgs_device* d, void* dst, const void* src, size_t bytes) 
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_copy_to_host while recording a command buffer");
     if (bytes == 0) return WDGS_OK;
     WDGS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
-    WDGS_CHECK_HIP(hipStreamSynchronize(d->stream));
+    WDGS_CHECK_HIP(wdgs_sync_lanes(d));
     return WDGS_OK;
 }
 
@@ -555,7 +586,7 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
             const u32 tiles = op->tile_info.total_tiles;
             if (tiles + 1 > op->ranges_capacity) {
                 WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledForwardPass.encode allocates its range table on first use: run one eager encode before recording");
-                (void)hipStreamSynchronize(d->stream);
+                (void)wdgs_sync_lanes(d);
                 free_dev(op->ranges);
                 op->ranges = nullptr;
                 WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(tiles + 1), true, d->stream));
@@ -614,7 +645,7 @@ int wdgs_tiled_forward_get_resources(wdgs_tiled_forward* op, wdgs_tiled_forward_
 int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
     WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_tiled_forward_check while recording a command buffer");
-    WDGS_CHECK_HIP(hipStreamSynchronize(op->dev->stream));
+    WDGS_CHECK_HIP(wdgs_sync_lanes(op->dev));
     u32 st[4];
     for (int i = 0; i < 4; i++) st[i] = ((const volatile u32*)op->host_stats)[i];
     ((volatile u32*)op->host_stats)[2] = 0u;  // the overflow word is sticky (set by any encode since the last check): consumed here
@@ -654,7 +685,7 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
     const TileInfo& ti = f->tile_info;
     if (width != op->width || height != op->height) {  // ensureTextures (tiled-rasterizer.ts:244-306)
         WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledRasterizer.encode allocates its textures on first use: run one eager encode before recording");
-        (void)hipStreamSynchronize(d->stream);
+        (void)wdgs_sync_lanes(d);
         free_dev(op->rgba8); free_dev(op->alpha); free_dev(op->n_contrib);
         op->rgba8 = nullptr; op->alpha = nullptr; op->n_contrib = nullptr;
         const size_t px = (size_t)width * height;
@@ -672,7 +703,7 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
     } else {
         if (ti.total_tiles + 1 > op->ranges_capacity) {
             WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledRasterizer.encode allocates its range table on first use: run one eager encode before recording");
-            (void)hipStreamSynchronize(d->stream);
+            (void)wdgs_sync_lanes(d);
             free_dev(op->ranges);
             op->ranges = nullptr;
             WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(ti.total_tiles + 1), true, d->stream));
@@ -710,7 +741,7 @@ int wdgs_tiled_rasterizer_blit(wdgs_tiled_rasterizer* op, void* target, uint32_t
 static int backward_alloc_images(wdgs_tiled_backward* op, u32 w, u32 h) {
     const u32 px = w * h;
     if (px <= op->img_capacity) return WDGS_OK;
-    (void)hipStreamSynchronize(op->dev->stream);
+    (void)wdgs_sync_lanes(op->dev);
     free_dev(op->loss_image); free_dev(op->metric_err); free_dev(op->metric_flags);
     op->loss_image = nullptr; op->metric_err = nullptr; op->metric_flags = nullptr;
     WDGS_TRY(wdgs_alloc((void**)&op->loss_image, (size_t)px * 16, true, op->dev->stream));

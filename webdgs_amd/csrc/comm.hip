@@ -107,7 +107,7 @@ int wdgs_comm_create(wdgs_device* dev, const uint8_t id[WDGS_COMM_ID_BYTES], int
 
 int wdgs_comm_destroy(wdgs_comm* c) {
     if (!c) return WDGS_OK;
-    if (wdgs_device_alive(c->dev) && !c->dev->capturing) (void)hipStreamSynchronize(c->dev->stream);
+    if (wdgs_device_alive(c->dev) && !c->dev->capturing) (void)wdgs_sync_lanes(c->dev);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
     return WDGS_OK;

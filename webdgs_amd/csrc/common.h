@@ -40,8 +40,14 @@ void wdgs_set_error(const char* fmt, ...);
 
 struct wdgs_device {
     int ordinal = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // the CURRENT lane's stream: everything is launched, recorded and copied on it
     bool own_stream = false;
+    // Lanes: lane 0 is the device's own stream (the host framework's), the others internal ones created on first use.  A batched step
+    // deals consecutive views to the lanes in turn so that the bandwidth-bound kernels of one view execute beside the VALU-bound
+    // rasterization kernels of another (api.hip: wdgs_device_select_lane / wdgs_device_lane_order).
+    hipStream_t lanes[WDGS_MAX_LANES] = {};
+    hipEvent_t lane_events[WDGS_MAX_LANES] = {};
+    int lane = 0;
     bool profiling = false;
     bool capturing = false;
     struct Pending { const char* name; hipEvent_t a, b; };
@@ -52,6 +58,16 @@ struct wdgs_device {
     std::vector<wdgs_tiled_forward*> forwards;  // live forward passes, for deferred overflow checks
     int num_cus = 256;
 };
+
+// Host wait for everything submitted to the device, on either lane.
+inline hipError_t wdgs_sync_lanes(wdgs_device* d) {
+    for (int l = 1; l < WDGS_MAX_LANES; l++) {
+        if (!d->lanes[l]) continue;
+        const hipError_t e = hipStreamSynchronize(d->lanes[l]);
+        if (e != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(d->lanes[0] ? d->lanes[0] : d->stream);
+}
 
 // Brackets one kernel launch with events when profiling is on (hipEvents on the launch stream).
 struct KernelScope {

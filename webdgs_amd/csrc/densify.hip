@@ -378,7 +378,7 @@ int wdgs_densify_prune_create(wdgs_device* dev, const wdgs_densify_config* cfg, 
 
 int wdgs_densify_prune_destroy(wdgs_densify_prune* op) {
     if (!op) return WDGS_OK;
-    if (wdgs_device_alive(op->dev) && !op->dev->capturing) (void)hipStreamSynchronize(op->dev->stream);
+    if (wdgs_device_alive(op->dev) && !op->dev->capturing) (void)wdgs_sync_lanes(op->dev);
     densify_free(op);
     if (op->total) (void)hipFree(op->total);
     delete op;
@@ -394,7 +394,7 @@ int wdgs_densify_prune_set_config(wdgs_densify_prune* op, const wdgs_densify_con
 int wdgs_densify_prune_ensure_size(wdgs_densify_prune* op, uint32_t n) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
     if (n <= op->capacity && op->actions) return WDGS_OK;
-    (void)hipStreamSynchronize(op->dev->stream);
+    (void)wdgs_sync_lanes(op->dev);
     densify_free(op);
     const size_t N = std::max(n, 1u);
     WDGS_TRY(wdgs_alloc((void**)&op->actions, N * 4, true, op->dev->stream));

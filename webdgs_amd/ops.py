@@ -21,6 +21,9 @@ from ._lib import CapacityError, StateError, WdgsError, check  # noqa: F401  (re
 
 
 # ----------------------------------------------------------------------------- device / buffers
+MAX_LANES = 4  # WDGS_MAX_LANES (include/webdgs.h)
+
+
 class HipBuffer:
     """A span of device memory (``GPUBuffer``): either a view into library-owned memory or a torch-backed allocation."""
 
@@ -183,6 +186,14 @@ class HipDevice:
     def synchronize(self) -> None:
         check(self.lib.wdgs_device_synchronize(self.handle))
         self._keepalive.clear()
+
+    def selectLane(self, lane: int) -> None:
+        """Directs every later encode / submit to lane 0 (this device's stream) or an internal one, 1..MAX_LANES-1 (``include/webdgs.h``: lanes)."""
+        check(self.lib.wdgs_device_select_lane(self.handle, int(lane)))
+
+    def laneOrder(self, waiter: int, signal: int) -> None:
+        """What lane ``waiter`` gets from now on runs after what lane ``signal`` has been given so far (device-side, no host wait)."""
+        check(self.lib.wdgs_device_lane_order(self.handle, int(waiter), int(signal)))
 
     def setProfiling(self, enabled: bool) -> None:
         check(self.lib.wdgs_device_set_profiling(self.handle, 1 if enabled else 0))

@@ -11,6 +11,7 @@ produced it instead of on the next animation frame.  New: ``world_size > 1`` run
 from __future__ import annotations
 
 import math
+import os
 import random
 import time
 from typing import Optional
@@ -23,7 +24,8 @@ from . import loaders, ops, parallel
 
 class Trainer:
     def __init__(self, device: ops.HipDevice, trainingConfig: Optional[dict] = None, seed: int = 0, world_size: int = 1, rank: int = 0,
-                 views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True, exchange: Optional[parallel.Exchange] = None):
+                 views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True, exchange: Optional[parallel.Exchange] = None,
+                 overlap_views: Optional[bool] = None):
         self.device = device
         self.trainingConfig = dict(trainingConfig or dict(lambda_l1=0.8, lambda_l2=0.0, lambda_dssim=0.2))  # trainer.ts:100-104
         self.optimizerHyperparameters = dict(ops.DEFAULT_ADAM_HYPERPARAMETERS)
@@ -40,11 +42,21 @@ class Trainer:
         self.use_command_buffers = bool(use_command_buffers)
         self._cmd_cache: dict = {}
         self._eager_steps = 0
+        # A batched step deals its views to several op sets in turn; once their command buffers are recorded, set s replays on the
+        # device's lane s, so the bandwidth-bound stages of one view (project, sort, loss, geometry backward) run beside the
+        # VALU-bound rasterization kernels of another.  Results do not depend on it: the fp32 block is still filled in view order.
+        # overlap_views: None = default (WDGS_LANES, else DEFAULT_LANES), False / 1 = one lane, True or n = that many lanes.
+        if overlap_views is None:
+            overlap_views = int(os.environ.get("WDGS_LANES", self.DEFAULT_LANES))
+        elif isinstance(overlap_views, bool):
+            overlap_views = self.DEFAULT_LANES if overlap_views else 1
+        self._op_sets = max(1, min(int(overlap_views), self.views_per_rank, ops.MAX_LANES))
         self._camera_buffers: list = []
         # every rank draws the same view sequence (same seed), then takes its shard
         self._rng = random.Random(seed)
 
         self.forwardPass = self.rasterizer = self.backwardPass = self.optimizer = None
+        self._more_op_sets: list = []  # [forwardPass, rasterizer, backwardPass] of lanes 1.. (set 0 is the three above)
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
         self.metricsViewportWidth = self.metricsViewportHeight = 0
         self.metricsTarget: Optional[ops.HipBuffer] = None
@@ -77,6 +89,15 @@ class Trainer:
         self.exchange_timing = False  # bracket the collectives with events on the device stream (bench.py)
         self._exchange_events: list = []
 
+    DEFAULT_LANES = 3
+    _OP_NAMES = ("forwardPass", "rasterizer", "backwardPass", "metricsForwardPass", "metricsRasterizer", "metricsPass", "optimizer")
+
+    def _destroy_more_op_sets(self) -> None:
+        for ops_of_lane in self._more_op_sets:
+            for op in ops_of_lane:
+                op.destroy()
+        self._more_op_sets = []
+
     # ------------------------------------------------------------------ configuration
     def _densify_op_config(self) -> dict:
         c = self.densifyPruneConfig
@@ -102,11 +123,12 @@ class Trainer:
         """``trainer.ts:201-237``: tear down the op graph, adopt the new cloud (+ optimizer state), rebuild."""
         self.device.synchronize()
         oldParams = self.optimizer.getHyperparameters() if self.optimizer else None
-        for name in ("forwardPass", "rasterizer", "backwardPass", "metricsForwardPass", "metricsRasterizer", "metricsPass", "optimizer"):
+        for name in self._OP_NAMES:
             op = getattr(self, name)
             if op is not None:
                 op.destroy()
             setattr(self, name, None)
+        self._destroy_more_op_sets()
         old = self.pointCloud
         self.pointCloud = request["pointCloud"]
         self.optimizer = ops.Optimizer(self.device, self.pointCloud, oldParams or self.optimizerHyperparameters, request.get("optimizerInitialState"))
@@ -147,7 +169,7 @@ class Trainer:
     def setTrainingConfig(self, next_cfg: dict) -> None:
         self.trainingConfig.update({k: v for k, v in next_cfg.items() if v is not None})
         self._invalidate_command_buffers()
-        for p in (self.backwardPass, self.metricsPass):
+        for p in [self.backwardPass, self.metricsPass] + [more[2] for more in self._more_op_sets]:
             if p is not None:
                 p.setTrainingConfig(next_cfg)
 
@@ -231,6 +253,14 @@ class Trainer:
             self.backwardPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
         else:
             self.backwardPass.setViewport(w, h)
+        for more in self._more_op_sets:
+            more[0].setViewport(w, h)
+            more[2].setViewport(w, h)
+        while len(self._more_op_sets) < self._op_sets - 1:
+            fw = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
+                                      dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+            self._more_op_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
+                                       ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))])
         if self.optimizer is not None and self.world_size * self.views_per_rank == 1:
             # a step whose tile-entry list overflowed is skipped on the device (and reported by the next synchronize)
             self.optimizer.setGuard(self.forwardPass.getStatsBuffer(), 8)
@@ -276,16 +306,20 @@ class Trainer:
         return out
 
     # ------------------------------------------------------------------ one training step
-    def _encode_view(self, encoder, index: int) -> None:
+    def _ops_of(self, op_set: int) -> tuple:
+        return tuple(self._more_op_sets[op_set - 1]) if op_set > 0 else (self.forwardPass, self.rasterizer, self.backwardPass)
+
+    def _encode_view(self, encoder, index: int, op_set: int = 0) -> None:
+        forwardPass, rasterizer, backwardPass = self._ops_of(op_set)
         image = self.images[index]
         cam = self._camera_buffers[index]  # camera.set_preset + update_buffer (trainer.ts:583-586): the view's resident block
-        self.forwardPass.setCameraBuffer(cam)
-        self.forwardPass.encode(encoder)
-        self.rasterizer.encode(encoder, image["width"], image["height"])
-        res = dict(splatBuffer=self.forwardPass.getResources()["splatBuffer"], tileOffsetsBuffer=self.rasterizer.getTileOffsetsBuffer(),
-                   tileIndicesBuffer=self.forwardPass.getSortedIndicesBuffer(), cameraBuffer=cam,
-                   alphaTexture=self.rasterizer.getAlphaTextureView(), nContribTexture=self.rasterizer.getNContribTextureView())
-        self.backwardPass.encode(encoder, self.rasterizer.getOutputTextureView(), image["texture"], res)
+        forwardPass.setCameraBuffer(cam)
+        forwardPass.encode(encoder)
+        rasterizer.encode(encoder, image["width"], image["height"])
+        res = dict(splatBuffer=forwardPass.getResources()["splatBuffer"], tileOffsetsBuffer=rasterizer.getTileOffsetsBuffer(),
+                   tileIndicesBuffer=forwardPass.getSortedIndicesBuffer(), cameraBuffer=cam,
+                   alphaTexture=rasterizer.getAlphaTextureView(), nContribTexture=rasterizer.getNContribTextureView())
+        backwardPass.encode(encoder, rasterizer.getOutputTextureView(), image["texture"], res)
 
     def warmupCommandBuffers(self) -> int:
         """Records every view's command buffers up front (the first pass over a dataset does this anyway; calling it before a timed
@@ -376,7 +410,8 @@ class Trainer:
 
     def _step_batched(self, mine: list) -> None:
         """[views -> fp32 block] -> exchange -> [Adam on the owned slice] -> all-gather -> [apply the other ranks' rows].  One
-        recorded command buffer per (view, first-of-batch?) plus one each for Adam and apply, whatever the batch's composition."""
+        recorded command buffer per (view, op set) plus one each for Adam and apply, whatever the batch's composition; the sums into
+        the fp32 block are two small eager launches per view, ordered across the lanes."""
         n, w = self.pointCloud.num_points, self.world_size
         sl = parallel.slice_points(n, w)
         if self._dp_grad is None:  # (allocated before any recording is opened; sized world*slice so the collectives run in place)
@@ -386,16 +421,32 @@ class Trainer:
             self._dp_rows = self.device.createBuffer(32 * w * sl, "dp-repacked-rows") if self._sliced else None
             self.optimizer.setGuard(self._dp_flag, 0)
         first, count = parallel.owned_range(n, w, self.rank)
-        tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
-        stats = self.forwardPass.getStatsBuffer()
         eager_before = self._eager_steps
-        for k, v in enumerate(mine):  # the first view overwrites the fp32 block (no clearing pass), the others add to it
-            def encode_view(encoder, v=v, k=k):
-                self._encode_view(encoder, v)
-                (ops.storeGradients if k == 0 else ops.accumulateGradients)(self.device, n, self.backwardPass.getGradientsBuffer(), tileCounts,
+        dev = self.device
+        # lanes carry replays only: a step that still encodes eagerly (first-use allocations) or records keeps to lane 0
+        L = self._op_sets
+        lanes = L > 1 and self.use_command_buffers and all(("view", v, k % L) in self._cmd_cache for k, v in enumerate(mine))
+        try:
+            for s in range(1, L if lanes else 0):
+                dev.laneOrder(s, 0)  # every lane starts behind whatever lane 0 holds (the previous step's Adam, a densify rebuild)
+            for k, v in enumerate(mine):
+                s = k % L
+                forwardPass, _, backwardPass = self._ops_of(s)
+                if lanes:
+                    dev.selectLane(s)
+                self._run(("view", v, s), lambda encoder, v=v, s=s: self._encode_view(encoder, v, s))
+                if lanes and k > 0:
+                    dev.laneOrder(s, (k - 1) % L)  # the fp32 block is filled in view order: this view's sums follow the previous view's
+                # the first view overwrites the fp32 block (no clearing pass), the others add to it
+                (ops.storeGradients if k == 0 else ops.accumulateGradients)(dev, n, backwardPass.getGradientsBuffer(), forwardPass.getResources()["tileCountsBuffer"],
                                                                             self._dp_grad, self._dp_visible)
-                ops.guardAccumulate(self.device, self._dp_flag, stats, 8, overwrite=(k == 0))
-            self._run(("view", v, k == 0), encode_view)
+                ops.guardAccumulate(dev, self._dp_flag, forwardPass.getStatsBuffer(), 8, overwrite=(k == 0))
+        finally:
+            if lanes:
+                dev.lib.wdgs_encoder_abort(dev.handle)  # (a no-op unless an encode above failed mid-recording)
+                dev.selectLane(0)
+                for s in range(1, L):
+                    dev.laneOrder(0, s)  # join: the exchange and the optimizer step follow every lane
         self._timed(lambda: self.exchange.exchange_gradients(self._dp_grad.ptr, self._dp_visible.ptr, self._dp_flag.ptr, sl))
         if self._run(("adam",), lambda encoder: self.optimizer.stepF32Range(encoder, self.pointCloud, self._dp_grad, self._dp_visible, first, count, self._dp_rows)):
             self.optimizer.advanceIteration(1)
@@ -459,11 +510,12 @@ class Trainer:
             self.device.lib.wdgs_encoder_abort(self.device.handle)
             self.device.synchronize()
         self._invalidate_command_buffers()
-        for name in ("forwardPass", "rasterizer", "backwardPass", "metricsForwardPass", "metricsRasterizer", "metricsPass", "optimizer", "densifyPrune"):
+        for name in self._OP_NAMES + ("densifyPrune",):
             op = getattr(self, name, None)
             if op is not None:
                 op.destroy()
             setattr(self, name, None)
+        self._destroy_more_op_sets()
         self._dp_grad = self._dp_visible = self._dp_rows = self._dp_flag = self.metricsTarget = None
         self._camera_buffers = []
         self.pointCloud = None
