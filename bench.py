@@ -90,13 +90,13 @@ def make_dataset(dev, cfg, tg, tsh, cams):
     return cameras, images
 
 
-def run_sustained(dev, cfg, g, sh, cameras, images, steps: int) -> dict:
+def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: int = 1) -> dict:
     """BASELINE config c3 as written -- "full train loop with densify/prune schedule": a fresh Trainer at the reference's densify
     defaults (warm-up 500, every 100, 10 metric views at half resolution, <= 5000 new points per event), `steps` iterations
     crossing the first densify events.  Wall clock around every step(), densify events timed separately."""
     from webdgs_amd import ops
     from webdgs_amd.trainer import Trainer
-    t = Trainer(dev, seed=99)
+    t = Trainer(dev, seed=99, pipeline_depth=pipeline_depth)
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
     t.setMaxIterations(10 ** 9)
@@ -118,6 +118,7 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int) -> dict:
             sizes.append(t.getPointCount())
         else:
             plain.append(dt)
+    t.drain()
     dev.synchronize()
     total = time.perf_counter() - t_all
     n_steps = t.getIteration() - start_it
@@ -128,7 +129,7 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int) -> dict:
                iters_per_s_steady=round(1.0 / med, 2) if med > 0 else None, ms_per_step_median=round(med * 1e3, 4), densify_events=len(events),
                ms_per_densify_event=round((sum(events) + rerecord) / max(1, len(events)) * 1e3, 2) if events else None,
                ms_per_densify_event_excluding_rerecording=round(float(np.mean(events)) * 1e3, 2) if events else None,
-               points=sizes, schedule="reference defaults: warm-up 500, interval 100, 10 metric views at 1/2 resolution, maxNewPointsPerStep 5000")
+               points=sizes, pipeline_depth=pipeline_depth, schedule="reference defaults: warm-up 500, interval 100, 10 metric views at 1/2 resolution, maxNewPointsPerStep 5000")
     t.destroy()
     return out
 
@@ -140,6 +141,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", help="c3 (headline), c3-small, c2, c1, c5 -- only c3 is the BASELINE metric")
     ap.add_argument("--views", type=int, default=0, help="training views in the dataset (default: 8 at N = 1, 64 at N > 1)")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="1: every step awaits its own completion (trainer.ts:639-645); 2: a step awaits the previous "
+                    "one, so the host submits step k+1 while step k runs (the same K steps, all finished inside the timed region)")
     ap.add_argument("--lanes", type=int, default=0, help="device lanes a batched step deals its views to (0 = the Trainer's default; 1 = no overlap)")
     ap.add_argument("--views-per-rank", type=int, default=0, help="views per rank per global step (default: 1 at N = 1, 8 at N > 1)")
     ap.add_argument("--sustained-steps", type=int, default=620, help="N = 1: length of the densify-inclusive leg (0 = skip)")
@@ -175,7 +178,7 @@ def main() -> None:
     cams = synth.circle_cameras(cfg, n_dataset)
     cameras, images = make_dataset(dev, cfg, tg, tsh, cams)
 
-    trainer = Trainer(dev, seed=1234, world_size=world, rank=rank, views_per_rank=vpr, overlap_views=args.lanes or None)
+    trainer = Trainer(dev, seed=1234, world_size=world, rank=rank, views_per_rank=vpr, overlap_views=args.lanes or None, pipeline_depth=args.pipeline_depth)
     lanes = trainer._op_sets
     trainer.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     trainer.setDataset(cameras, images)
@@ -199,11 +202,25 @@ def main() -> None:
     ev0.record(dev.torch_stream)
     for _ in range(args.steps):
         trainer.step()
+    trainer.drain()  # (pipeline depth 2: the last step's own await, with its deferred error check)
     ev1.record(dev.torch_stream)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
     device_ms = ev0.elapsed_time(ev1)
+    # the same K steps with the reference's own await inside every step (depth 1), for comparison; not the headline
+    awaited_ms = None
+    if trainer.pipeline_depth > 1:
+        trainer.pipeline_depth = 1
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t_a = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        awaited_ms = (time.perf_counter() - t_a) / args.steps * 1e3
+        trainer.pipeline_depth = args.pipeline_depth
     exchange_ms = trainer.exchangeMilliseconds() if world > 1 else 0.0
     trainer.exchange_timing = False
     if world > 1:
@@ -293,7 +310,7 @@ def main() -> None:
     if rank == 0 and world == 1:
         trainer.destroy()
         if args.sustained_steps > 0 and args.config in ("c3", "c3-small", "c2"):
-            sustained = run_sustained(dev, cfg, g, sh, cameras, images, args.sustained_steps)
+            sustained = run_sustained(dev, cfg, g, sh, cameras, images, args.sustained_steps, args.pipeline_depth)
         if not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(cfg, g, sh, cams[0], args.cpu_baseline_points)
 
@@ -308,6 +325,7 @@ def main() -> None:
             "metric": "training iters/sec (fwd+bwd+Adam), 1M Gaussians @1080p SH3" if args.config == "c3" else f"training iters/sec (fwd+bwd+Adam), {cfg.name}",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "device_ms_per_step": round(device_ms / args.steps, 4),
+            "ms_per_step_awaiting_every_step": round(awaited_ms, 4) if awaited_ms is not None else None,
             "eager_profiled_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4) if ktimes else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "head": head_commit(),
             "config": {"workload": f"{cfg.name}: {n} Gaussians, {cfg.width}x{cfg.height}, SH deg {cfg.sh_deg}, fwd+bwd per view, {n_dataset} circle views"
@@ -316,7 +334,11 @@ def main() -> None:
                        "parallelism": (f"dp{world}: views sharded; per global step one reduce-scatter (60 B/Gaussian) -> Adam on the owned 1/{world} slice -> "
                                        f"all-gather (32 B/Gaussian) over RCCL") if world > 1 else "single GPU",
                        "tile_entries_E": e_entries, "visible_V": v_visible, "contributing_pairs_C_upper": pairs,
-                       "submission": "recorded command buffers (HIP graphs), one per view, re-submitted; per-step host sync as in the reference",
+                       "pipeline_depth": args.pipeline_depth,
+                       "submission": "recorded command buffers (HIP graphs), one per view, re-submitted; " +
+                                     ("every step awaits its own completion, as the reference does" if args.pipeline_depth <= 1 else
+                                      "a step awaits the PREVIOUS step's completion ticket (the host submits step k+1 while step k runs); all K steps "
+                                      "finish inside the timed region; `ms_per_step_awaiting_every_step` is the reference's own await-per-step"),
                        "densify_schedule": "reference defaults (warm-up 500): not reached in the timed region; see `sustained`" if views_per_step == 1 else "disabled in this leg",
                        "iter_definition": "value counts training VIEWS (fwd+bwd) per second; a step = views_per_rank x n_gpus views + 1 exchange + 1 Adam"},
             "kernel_ms_per_view": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},

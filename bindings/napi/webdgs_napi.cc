@@ -529,6 +529,16 @@ static napi_value commDestroy(napi_env env, napi_callback_info info) { ARGS(1); 
 
 // ---- additions of round 2: recording abort, pinned read-back, scanner / sorter, optimizer guard, sliced data-parallel exchange ------
 static napi_value encoderAbort(napi_env env, napi_callback_info info) { ARGS(1); WDGS_OK_OR_THROW(wdgs_encoder_abort((wdgs_device*)get_ptr(env, argv[0]))); return js_undefined(env); }
+// tickets (include/webdgs.h: wdgs_queue_mark / wdgs_queue_wait): the ticket travels as a double (exact below 2^53)
+static napi_value queueMark(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    uint64_t t = 0;
+    WDGS_OK_OR_THROW(wdgs_queue_mark((wdgs_device*)get_ptr(env, argv[0]), &t));
+    napi_value v;
+    napi_create_double(env, (double)t, &v);
+    return v;
+}
+static napi_value queueWait(napi_env env, napi_callback_info info) { ARGS(2); WDGS_OK_OR_THROW(wdgs_queue_wait((wdgs_device*)get_ptr(env, argv[0]), (uint64_t)get_f64(env, argv[1]))); return js_undefined(env); }
 // lanes (include/webdgs.h): (device, lane) / (device, waiterLane, signalLane)
 static napi_value deviceSelectLane(napi_env env, napi_callback_info info) { ARGS(2); WDGS_OK_OR_THROW(wdgs_device_select_lane((wdgs_device*)get_ptr(env, argv[0]), (int)get_u32(env, argv[1]))); return js_undefined(env); }
 static napi_value deviceLaneOrder(napi_env env, napi_callback_info info) {
@@ -677,7 +687,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(commUniqueId); EXPORT_FN(commCreate); EXPORT_FN(commAllreduceGradients); EXPORT_FN(commAllreduceCounts); EXPORT_FN(commDestroy);
     EXPORT_FN(encoderAbort); EXPORT_FN(hostAlloc); EXPORT_FN(bufferReadAsync); EXPORT_FN(prefixScanner); EXPORT_FN(dynamicSorter);
     EXPORT_FN(optimizerSetGuard); EXPORT_FN(optimizerStepF32Range); EXPORT_FN(optimizerStateChanged); EXPORT_FN(storeGradients); EXPORT_FN(guardAccumulate);
-    EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder);
+    EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder); EXPORT_FN(queueMark); EXPORT_FN(queueWait);
     EXPORT_FN(applyRepackedRows); EXPORT_FN(commExchangeGradients); EXPORT_FN(commAllgatherRows); EXPORT_FN(commBroadcast); EXPORT_FN(commInfo);
     return exports;
 }

@@ -18,6 +18,9 @@ export class HipDevice {
   readonly queue: {
     submit(cmds: HipCommandBuffer[]): void;
     onSubmittedWorkDone(): Promise<void>;
+    /** include/webdgs.h wdgs_queue_mark / wdgs_queue_wait: keep the completion of step k and await it after submitting step k+1. */
+    mark(): number;
+    wait(ticket: number): void;
     writeBuffer(buffer: HipBuffer, offset: number, data: ArrayBufferView | ArrayBuffer): void;
   };
   createBuffer(desc: { size: number; label?: string }): HipBuffer;

@@ -54,6 +54,8 @@ class HipDevice {                        // GPUDevice + GPUQueue
     this.queue = {
       submit(cmds) { for (const c of cmds) if (c.handle !== null) addon.queueSubmit(self.handle, c.handle); },
       onSubmittedWorkDone() { return addon.queueOnSubmittedWorkDone(self.handle); },   // Promise, resolved from the HIP runtime thread
+      mark() { return addon.queueMark(self.handle); },                                  // a ticket for the work submitted so far ...
+      wait(ticket) { addon.queueWait(self.handle, ticket); },                           // ... awaited later (blocking; raises deferred capacity errors)
       writeBuffer(buffer, offset, data) { addon.copyToDevice(self.handle, buffer.ptr + BigInt(offset), data); },
     };
   }

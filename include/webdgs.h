@@ -115,6 +115,14 @@ int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd);
  * still reported by wdgs_device_synchronize / wdgs_tiled_forward_check. */
 typedef void (*wdgs_done_callback)(void* user);
 int wdgs_queue_on_done(wdgs_device* dev, wdgs_done_callback fn, void* user);
+/* The same promise, kept and awaited later: wdgs_queue_mark returns a ticket for "everything submitted to the current lane so far",
+ * wdgs_queue_wait blocks the host until that work has finished and then reports the deferred device-side errors exactly as
+ * wdgs_device_synchronize does.  A host that waits for step k-1's ticket after submitting step k (`const p = queue.onSubmittedWorkDone();
+ * ...; await previous`) keeps the device busy across the step boundary; trainer.ts:639-645 awaits at once, which is mark + wait.
+ * At most WDGS_TICKET_RING tickets stay distinct: an older one waits for the mark that took its slot (later in the same queue). */
+#define WDGS_TICKET_RING 8
+int wdgs_queue_mark(wdgs_device* dev, uint64_t* ticket);
+int wdgs_queue_wait(wdgs_device* dev, uint64_t ticket);
 
 /* Raw device<->host copies on the device's stream (copy_to_host synchronises): mapAsync/getMappedRange
  * (trainer.ts:455-458) and queue.writeBuffer. */

@@ -1,0 +1,92 @@
+"""GPU: tickets (wdgs_queue_mark / wdgs_queue_wait) and the Trainer's pipelined step.
+
+trainer.ts:639-645 awaits `onSubmittedWorkDone()` inside every step.  With `pipeline_depth = 2` the Trainer keeps that promise and
+awaits the PREVIOUS step's instead, so step k+1 is prepared and submitted while step k runs.  Nothing about the work changes, so the
+check is bit-equality with depth 1 -- single-view and batched, across a densify rebuild -- plus the error path: a step whose tile-entry
+list overflowed must leave the parameters untouched and be reported, at the latest, by the step after it."""
+import numpy as np
+import pytest
+
+from webdgs_amd import ops
+from webdgs_amd.trainer import Trainer
+
+import dp_common
+from harness import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _train(dev, depth, vpr, steps=14, densify_at=8):
+    cfg, g, sh, cameras, images = dp_common.dataset(dev)
+    t = Trainer(dev, seed=9, views_per_rank=vpr, pipeline_depth=depth)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=True, warmupIterations=densify_at, interval=1000, stopIterations=10 ** 6),
+                                 metricViews=3, cloneThresholdCount=5, splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300))
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset(cameras, images)
+    t.start()
+    in_flight = 0
+    for ids in dp_common.view_schedule(steps, 1, vpr):
+        t.step(ids)
+        in_flight = max(in_flight, len(t._tickets))
+    t.drain()
+    assert not t._tickets
+    dev.synchronize()
+    out = dict(g=t.pointCloud.gaussian_3d_buffer.read(np.uint32), sh=t.pointCloud.sh_buffer.read(np.uint32), n=t.getPointCount(),
+               state={k: b.read(np.uint32) for k, b in t.optimizer.getStateBuffers().items()}, iteration=t.getIteration(), in_flight=in_flight)
+    t.destroy()
+    return out
+
+
+@pytest.mark.parametrize("vpr", [1, 3])
+def test_pipelined_steps_leave_the_same_bits(hip_device, vpr):
+    a = _train(hip_device, 2, vpr)
+    b = _train(hip_device, 1, vpr)
+    assert a["in_flight"] == 1 and b["in_flight"] == 0, "depth 2 keeps one step in flight after step() returns, depth 1 none"
+    assert a["n"] == b["n"] != 6000 and a["iteration"] == b["iteration"] == 14, "same rebuild, same count of steps"
+    assert_bits_equal(a["g"], b["g"], f"gaussians, {vpr} view(s) per step: pipelined vs awaited")
+    assert_bits_equal(a["sh"], b["sh"], "sh: pipelined vs awaited")
+    for k in a["state"]:
+        assert_bits_equal(a["state"][k], b["state"][k], f"optimizer state {k}: pipelined vs awaited")
+
+
+@pytest.mark.parametrize("vpr,depth", [(1, 1), (1, 2), (3, 1), (3, 2)])
+def test_overflowing_step_is_reported_and_changes_nothing(hip_device, vpr, depth):
+    dev = hip_device
+    cfg, g, sh, cameras, images = dp_common.dataset(dev)
+    t = Trainer(dev, seed=9, views_per_rank=vpr, pipeline_depth=depth, maxTileEntries=4096)  # the scene needs several times that
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset(cameras, images)
+    t.start()
+    before = t.pointCloud.gaussian_3d_buffer.read(np.uint32)
+    with pytest.raises(ops.CapacityError):
+        for _ in range(depth):  # depth 1: the step itself raises; depth 2: the next one does
+            t.step([0] * vpr)
+    try:
+        dev.synchronize()
+    except ops.CapacityError:
+        pass  # (the step that was still in flight overflowed too)
+    assert_bits_equal(t.pointCloud.gaussian_3d_buffer.read(np.uint32), before, "an overflowed step must not touch the parameters")
+    t.destroy()
+
+
+def test_tickets(hip_device):
+    dev = hip_device
+    buf = dev.createBuffer(64 << 20)
+    with pytest.raises(ops.WdgsError):
+        dev.queue.wait(0)
+    with pytest.raises(ops.WdgsError):
+        dev.queue.wait(10 ** 9)  # never issued
+    tickets = []
+    for i in range(20):  # more marks than the ring holds: old tickets stay waitable (they wait for the mark that took their slot)
+        buf.clear()
+        tickets.append(dev.queue.mark())
+    assert tickets == list(range(tickets[0], tickets[0] + 20))
+    dev.queue.wait(tickets[0])
+    dev.queue.wait(tickets[-1])
+    assert not buf.read(np.uint32, count=16).any()
+    with dev.createCommandEncoder("tickets", record=True) as encoder:
+        encoder.clearBuffer(buf)
+        with pytest.raises(ops.WdgsError):
+            dev.queue.mark()  # not while recording
+        encoder.finish().destroy()

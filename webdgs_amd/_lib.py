@@ -97,6 +97,8 @@ SIGNATURES = {
     "wdgs_device_set_profiling": (_I, [_P, _I]),
     "wdgs_device_get_kernel_times": (_I, [_P, C.POINTER(KernelTime), _U, C.POINTER(_U)]),
     "wdgs_device_reset_kernel_times": (_I, [_P]),
+    "wdgs_queue_mark": (_I, [_P, C.POINTER(C.c_uint64)]),
+    "wdgs_queue_wait": (_I, [_P, C.c_uint64]),
     "wdgs_device_select_lane": (_I, [_P, _I]),
     "wdgs_device_lane_order": (_I, [_P, _I, _I]),
     "wdgs_encoder_begin": (_I, [_P]),

@@ -21,8 +21,8 @@ int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSetting
 int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
                        const void*);
 int launch_adam_repack_f32(wdgs_device*, u32, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*,
-                           void*, const void*, void*);
-int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, void*, void*);
+                           void*, const void*, void*, void*);
+int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, void*, void*, void*);
 int launch_guard_accumulate(wdgs_device*, void*, const void*, u32);
 int launch_dc_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
 int launch_dc_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
@@ -179,6 +179,13 @@ int wdgs_device_create(int ordinal, void* external_stream, wdgs_device** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess) d->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     d->lanes[0] = d->stream;
+    if (hipHostMalloc((void**)&d->host_guard, 16, hipHostMallocDefault) != hipSuccess) {
+        wdgs_set_error("hipHostMalloc(16) failed");
+        if (d->own_stream) (void)hipStreamDestroy(d->stream);
+        delete d;
+        return WDGS_E_HIP;
+    }
+    std::memset(d->host_guard, 0, 16);
     { std::lock_guard<std::mutex> lock(g_live_mutex); g_live_devices.insert(d); }
     *out = d;
     return WDGS_OK;
@@ -226,21 +233,55 @@ static int collect_profile(wdgs_device* d) {
     return WDGS_OK;
 }
 
+// Device-side conditions that are reported at the next host wait: a truncated tile-entry list (per forward pass, sticky since its last
+// check) and a guarded optimizer step that skipped itself (sticky; set when the guard word of a batched / data-parallel step was
+// non-zero -- on this rank or, after the exchange summed it, on any other).  Reading consumes them.
+static int deferred_checks(wdgs_device* d) {
+    volatile u32* hg = d->host_guard;
+    const u32 skipped = hg[0];
+    hg[0] = 0u;
+    u32 needed = 0u, cap = 0u;  // every pass's word is consumed; the first overflow found is the one reported
+    for (wdgs_tiled_forward* f : d->forwards) {
+        if (!f->encoded) continue;
+        volatile u32* st = f->host_stats;  // written by update_stats before the stream drained (no device round trip here)
+        const u32 v = st[2];               // sticky across the encodes since the last check: reading it here consumes it
+        st[2] = 0u;
+        if (v != 0u && needed == 0u) { needed = v; cap = f->tile_info.max_tile_entries; }
+    }
+    WDGS_REQUIRE(needed == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)", needed, cap);
+    WDGS_REQUIRE(skipped == 0u, WDGS_E_CAPACITY, "an optimizer step was skipped on every rank: tile entries overflowed on another rank (its own error names the size)");
+    return WDGS_OK;
+}
+
 int wdgs_device_synchronize(wdgs_device* d) {
     WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_synchronize: null device");
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_synchronize while recording a command buffer");
     WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
     WDGS_CHECK_HIP(wdgs_sync_lanes(d));
     collect_profile(d);
-    for (wdgs_tiled_forward* f : d->forwards) {
-        if (!f->encoded) continue;
-        volatile u32* st = f->host_stats;  // written by update_stats before the stream drained (no device round trip here)
-        const u32 needed = st[2];          // sticky across the encodes since the last check: reading it here consumes it
-        st[2] = 0u;
-        WDGS_REQUIRE(needed == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)",
-                     needed, f->tile_info.max_tile_entries);
-    }
+    return deferred_checks(d);
+}
+
+int wdgs_queue_mark(wdgs_device* d, uint64_t* ticket) {
+    WDGS_REQUIRE(d && ticket, WDGS_E_INVALID, "wdgs_queue_mark: null argument");
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_mark while recording a command buffer");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    const uint64_t t = d->ticket_next;
+    hipEvent_t& e = d->ticket_events[t % WDGS_TICKET_RING];
+    if (!e) WDGS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    WDGS_CHECK_HIP(hipEventRecord(e, d->stream));
+    d->ticket_next = t + 1;
+    *ticket = t;
     return WDGS_OK;
+}
+
+int wdgs_queue_wait(wdgs_device* d, uint64_t ticket) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_queue_wait: null device");
+    WDGS_REQUIRE(ticket != 0 && ticket < d->ticket_next, WDGS_E_INVALID, "wdgs_queue_wait: ticket %llu was never issued", (unsigned long long)ticket);
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_wait while recording a command buffer");
+    // (a ticket older than the ring waits on the mark that took its slot: later in the same queue, so the wait still holds)
+    WDGS_CHECK_HIP(hipEventSynchronize(d->ticket_events[ticket % WDGS_TICKET_RING]));
+    return deferred_checks(d);
 }
 
 int wdgs_device_destroy(wdgs_device* d) {
@@ -260,6 +301,8 @@ int wdgs_device_destroy(wdgs_device* d) {
     collect_profile(d);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lane_events) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->ticket_events) if (e) (void)hipEventDestroy(e);
+    if (d->host_guard) (void)hipHostFree(d->host_guard);
     for (int l = 1; l < WDGS_MAX_LANES; l++)
         if (d->lanes[l]) (void)hipStreamDestroy(d->lanes[l]);
     if (d->own_stream) (void)hipStreamDestroy(d->lanes[0]);
@@ -922,7 +965,7 @@ int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");
     op->iteration++;
     op->dc_dirty = true;
-    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, nullptr);
+    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, nullptr);
 }
 int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible, uint32_t first, uint32_t count,
                                   void* rows_out) {
@@ -931,7 +974,7 @@ int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh,
                  op->num_points);
     op->iteration++;
     op->dc_dirty = true;
-    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, rows_out);
+    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, rows_out);
 }
 int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
@@ -946,7 +989,7 @@ int wdgs_optimizer_state_changed(wdgs_optimizer* op) {
 int wdgs_apply_repacked_rows(wdgs_device* d, uint32_t n, const void* rows, uint32_t skip_first, uint32_t skip_count, const void* guard, void* gaussians,
                              void* sh) {
     WDGS_REQUIRE(d && rows && gaussians && sh, WDGS_E_INVALID, "wdgs_apply_repacked_rows: null argument");
-    return launch_apply_rows(d, n, rows, skip_first, skip_count, guard, gaussians, sh);
+    return launch_apply_rows(d, n, rows, skip_first, skip_count, guard, d->host_guard, gaussians, sh);
 }
 int wdgs_guard_accumulate(wdgs_device* d, void* flag, const void* src, int overwrite) {
     WDGS_REQUIRE(d && flag && src, WDGS_E_INVALID, "wdgs_guard_accumulate: null argument");

@@ -48,6 +48,11 @@ struct wdgs_device {
     hipStream_t lanes[WDGS_MAX_LANES] = {};
     hipEvent_t lane_events[WDGS_MAX_LANES] = {};
     int lane = 0;
+    // Tickets (wdgs_queue_mark / wdgs_queue_wait): a ring of events, so a host can wait for step k-1 while step k runs.
+    hipEvent_t ticket_events[WDGS_TICKET_RING] = {};
+    uint64_t ticket_next = 1;
+    // Sticky, device-written: a guarded optimizer step found its guard word set and skipped itself (pinned host memory).
+    u32* host_guard = nullptr;
     bool profiling = false;
     bool capturing = false;
     struct Pending { const char* name; hipEvent_t a, b; };

@@ -134,10 +134,13 @@ __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyper
 __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 count, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
                                                                const float* __restrict__ grad_f32, float4* opt_pos, float4* opt_rot,
                                                                float4* opt_scale, float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer,
-                                                               const u32* __restrict__ guard, u32* __restrict__ rows_out) {
+                                                               const u32* __restrict__ guard, u32* __restrict__ guard_seen_host, u32* __restrict__ rows_out) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
-    if (guard && *guard != 0u) return;
+    if (guard && *guard != 0u) {
+        if (t == 0u && guard_seen_host) *guard_seen_host = 1u;  // sticky host-visible note: this step skipped itself (deferred_checks, api.hip)
+        return;
+    }
     const u32 idx = first + t;
     const bool update = visible[idx] != 0u;
     Grad14 g = {};
@@ -153,9 +156,10 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 cou
 
 // Rows published by the other ranks (wdgs_comm_allgather_rows) -> this replica's point cloud: every Gaussian outside
 // [skip_first, skip_first + skip_count), which this rank re-packed itself.
-__global__ __launch_bounds__(256) void apply_rows_kernel(u32 n, const u32* __restrict__ rows, u32 skip_first, u32 skip_count, const u32* __restrict__ guard,
+__global__ __launch_bounds__(256) void apply_rows_kernel(u32 n, const u32* __restrict__ rows, u32 skip_first, u32 skip_count, const u32* __restrict__ guard, u32* __restrict__ guard_seen_host,
                                                           u32* __restrict__ gaussians, u32* __restrict__ sh_buffer) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0u && guard && guard_seen_host && *guard != 0u) *guard_seen_host = 1u;  // (a rank whose owned slice is empty runs no Adam kernel)
     if (idx >= n || (idx >= skip_first && idx - skip_first < skip_count)) return;
     if (guard && *guard != 0u) return;
     const uint4* ri = reinterpret_cast<const uint4*>(rows + (size_t)idx * 8);
@@ -268,19 +272,19 @@ int launch_adam_repack(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters&
 }
 
 int launch_adam_repack_f32(wdgs_device* dev, u32 first, u32 count, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
-                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* rows_out) {
+                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out) {
     if (count == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, first, count, h, (const u32*)visible,
                 (const float*)grad_f32, (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians,
-                (u32*)sh, (const u32*)guard, (u32*)rows_out);
+                (u32*)sh, (const u32*)guard, (u32*)guard_seen_host, (u32*)rows_out);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_apply_rows(wdgs_device* dev, u32 n, const void* rows, u32 skip_first, u32 skip_count, const void* guard, void* gaussians, void* sh) {
+int launch_apply_rows(wdgs_device* dev, u32 n, const void* rows, u32 skip_first, u32 skip_count, const void* guard, void* guard_seen_host, void* gaussians, void* sh) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "apply_repacked_rows", apply_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)rows, skip_first, skip_count,
-                (const u32*)guard, (u32*)gaussians, (u32*)sh);
+                (const u32*)guard, (u32*)guard_seen_host, (u32*)gaussians, (u32*)sh);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -137,6 +137,16 @@ class _Queue:
         self.device._keepalive.append(cb)  # the trampoline must outlive its call; released at the next synchronize()
         check(self.device.lib.wdgs_queue_on_done(self.device.handle, cb, None))
 
+    def mark(self) -> int:
+        """A ticket for "everything submitted to the current lane so far" -- the Promise of ``onSubmittedWorkDone()``, kept for later."""
+        t = C.c_uint64(0)
+        check(self.device.lib.wdgs_queue_mark(self.device.handle, C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket: int) -> None:
+        """Awaits a ticket: blocks until that work is done, then raises deferred device-side errors like ``synchronize()``."""
+        check(self.device.lib.wdgs_queue_wait(self.device.handle, C.c_uint64(int(ticket))))
+
     def writeBuffer(self, buf: HipBuffer, offset: int, data: np.ndarray) -> None:
         buf.write(data, offset)
 

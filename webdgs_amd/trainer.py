@@ -25,7 +25,7 @@ from . import loaders, ops, parallel
 class Trainer:
     def __init__(self, device: ops.HipDevice, trainingConfig: Optional[dict] = None, seed: int = 0, world_size: int = 1, rank: int = 0,
                  views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True, exchange: Optional[parallel.Exchange] = None,
-                 overlap_views: Optional[bool] = None):
+                 overlap_views: Optional[bool] = None, pipeline_depth: int = 1):
         self.device = device
         self.trainingConfig = dict(trainingConfig or dict(lambda_l1=0.8, lambda_l2=0.0, lambda_dssim=0.2))  # trainer.ts:100-104
         self.optimizerHyperparameters = dict(ops.DEFAULT_ADAM_HYPERPARAMETERS)
@@ -56,6 +56,12 @@ class Trainer:
         self._rng = random.Random(seed)
 
         self.forwardPass = self.rasterizer = self.backwardPass = self.optimizer = None
+        # pipeline_depth 1: every step awaits its own completion, as trainer.ts:639-645 does.  2: step() returns once the PREVIOUS
+        # step has finished, so the host prepares and submits step k+1 while step k runs (the device never idles across the step
+        # boundary); a capacity error then surfaces one step late -- the device-side guard has already kept that step's Adam from
+        # running on incomplete gradients.  Densify steps, stop() and every read-back drain the pipeline first.
+        self.pipeline_depth = max(1, min(int(pipeline_depth), 4))
+        self._tickets: list = []
         self._more_op_sets: list = []  # [forwardPass, rasterizer, backwardPass] of lanes 1.. (set 0 is the three above)
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
         self.metricsViewportWidth = self.metricsViewportHeight = 0
@@ -143,6 +149,9 @@ class Trainer:
 
     def _invalidate_command_buffers(self) -> None:
         """Recorded kernels bake pointers, viewport, hyper-parameters and loss weights: any change drops the recordings."""
+        if self._tickets and self.device.handle:  # steps in flight replay these recordings: wait before destroying them
+            self._tickets = []
+            self.device.synchronize()
         for c in self._cmd_cache.values():
             c.destroy()
         self._cmd_cache = {}
@@ -199,6 +208,8 @@ class Trainer:
 
     def stop(self) -> None:
         self.isTraining = False
+        if self.device.handle and self._tickets:
+            self.drain()
 
     def getIsTraining(self) -> bool:
         return self.isTraining
@@ -365,20 +376,27 @@ class Trainer:
             if self.device.handle:
                 self.device.lib.wdgs_encoder_abort(self.device.handle)
             self._invalidate_command_buffers()
+            self._tickets = []
             raise
-        self._finish_step(n_views)
+        try:
+            self._finish_step(n_views)
+        except BaseException:
+            self._tickets = []  # (the error has been consumed; whatever is still in flight is awaited by the next synchronize)
+            raise
 
         self.iteration += 1
         self.stepMs = (time.perf_counter() - stepStart) * 1000.0
         inst = 1000.0 / self.stepMs if self.stepMs > 0 else 0.0
         self.stepItersPerSec = inst if self.stepItersPerSec == 0 else self.stepItersPerSec * 0.9 + inst * 0.1
         if shouldDensify:
+            self.drain()
             self.runDensifyPruneMultiView()
             req = self.consumePointCloudSwapRequest()
             if req is not None:
                 self.applyPointCloudSwap(req)
         if self.iteration >= self.maxIterations:
             self.stop()
+            self.drain()
 
     def _run(self, key: tuple, encode) -> bool:
         """Submits the command buffer recorded under ``key``; the first time, ``encode(encoder)`` is encoded -- eagerly while the
@@ -475,17 +493,18 @@ class Trainer:
         return float(ms)
 
     def _finish_step(self, n_views: int) -> None:
-        """``await onSubmittedWorkDone()`` (trainer.ts:639-645) + the deferred capacity check.  In a batched step the guard word was
-        summed over all ranks by the exchange, so every rank sees the same value and all of them raise together."""
-        err = None
-        try:
-            self.device.queue.onSubmittedWorkDone()
-        except ops.CapacityError as e:
-            err = e
-        if n_views > 1 and self._dp_flag is not None and int(self._dp_flag.read(np.uint32, count=1)[0]) != 0:
-            raise err or ops.CapacityError(-3, "tile entries overflowed on another rank: the step was skipped on every rank")
-        if err is not None:
-            raise err
+        """``await onSubmittedWorkDone()`` (trainer.ts:639-645) + the deferred capacity check, for the step ``pipeline_depth - 1``
+        submissions ago.  In a batched step the guard word was summed over all ranks by the exchange and the optimizer kernels leave
+        a host-visible note when they skip themselves, so every rank raises at the same step."""
+        self._tickets.append(self.device.queue.mark())
+        while len(self._tickets) >= self.pipeline_depth:
+            self.device.queue.wait(self._tickets.pop(0))
+
+    def drain(self) -> None:
+        """Awaits every step still in flight (a no-op at ``pipeline_depth`` 1)."""
+        tickets, self._tickets = self._tickets, []
+        for t in tickets:
+            self.device.queue.wait(t)
 
     def syncOptimizerState(self) -> None:
         """Brings every rank's optimizer state up to date: after sliced steps a rank holds current (param, m, v) only for the
@@ -508,7 +527,11 @@ class Trainer:
         belongs to the caller (``HipDevice.destroy()`` comes after this, and before ``torch.distributed.destroy_process_group``)."""
         if self.device.handle:
             self.device.lib.wdgs_encoder_abort(self.device.handle)
-            self.device.synchronize()
+            self._tickets = []
+            try:
+                self.device.synchronize()
+            except ops.CapacityError:
+                pass  # (a deferred report about a step of a trainer that is going away)
         self._invalidate_command_buffers()
         for name in self._OP_NAMES + ("densifyPrune",):
             op = getattr(self, name, None)
