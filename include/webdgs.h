@@ -201,6 +201,11 @@ typedef struct wdgs_tiled_forward_resources { /* TiledForwardResources (tiled-fo
 
 int wdgs_tiled_forward_create(wdgs_device* dev, const wdgs_tiled_forward_config* cfg, wdgs_tiled_forward** out);
 int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op);
+/* The point cloud changed size (densify / prune).  applyPointCloudSwap (trainer.ts:201-237) destroys every pass and builds new ones; this
+ * keeps the pass: its buffers are reused when large enough and re-allocated with 25 % headroom when not, and the pass is left in the
+ * state of a freshly created one for num_points (zeroed per-Gaussian buffers, nothing encoded, max_tile_entries by the creation
+ * formula).  Synchronises; not allowed while recording; command buffers recorded against the pass must be dropped by the caller. */
+int wdgs_tiled_forward_resize(wdgs_tiled_forward* op, uint32_t num_points);
 /* encode(encoder, {skipSort}): K1 project+count, scan, stats, K6 emit, sort. gaussians/sh/camera are device pointers. */
 int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians_dev, const void* sh_dev, const void* camera_dev, int skip_sort);
 int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t width, uint32_t height);
@@ -252,6 +257,8 @@ typedef struct wdgs_tiled_backward_resources { /* TiledBackwardResources (tiled-
 } wdgs_tiled_backward_resources;
 
 int wdgs_tiled_backward_create(wdgs_device* dev, const wdgs_tiled_backward_config* cfg, wdgs_tiled_backward** out);
+/* The point cloud changed size: see wdgs_tiled_forward_resize. */
+int wdgs_tiled_backward_resize(wdgs_tiled_backward* op, uint32_t num_points);
 int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op);
 /* encode: K15 loss gradient, clear accumulators, K16 backward raster, K17 geometry backward -> GaussianGradient[N]. */
 int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev,

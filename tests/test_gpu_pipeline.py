@@ -16,10 +16,11 @@ from harness import assert_bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _train(dev, depth, vpr, steps=14, densify_at=8):
+def _train(dev, depth, vpr, steps=14, densify_at=8, interval=1000, reuse_passes=True):
     cfg, g, sh, cameras, images = dp_common.dataset(dev)
     t = Trainer(dev, seed=9, views_per_rank=vpr, pipeline_depth=depth)
-    t.setDensifyPruneConfig(dict(schedule=dict(enabled=True, warmupIterations=densify_at, interval=1000, stopIterations=10 ** 6),
+    t.reuse_passes = reuse_passes
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=True, warmupIterations=densify_at, interval=interval, stopIterations=10 ** 6),
                                  metricViews=3, cloneThresholdCount=5, splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
@@ -47,6 +48,19 @@ def test_pipelined_steps_leave_the_same_bits(hip_device, vpr):
     assert_bits_equal(a["sh"], b["sh"], "sh: pipelined vs awaited")
     for k in a["state"]:
         assert_bits_equal(a["state"][k], b["state"][k], f"optimizer state {k}: pipelined vs awaited")
+
+
+@pytest.mark.parametrize("vpr", [1, 2])
+def test_resized_passes_equal_rebuilt_passes(hip_device, vpr):
+    """applyPointCloudSwap keeps the passes and resizes them (`wdgs_tiled_*_resize`); the reference destroys and rebuilds them
+    (trainer.ts:201-237).  Three rebuilds, the cloud growing and shrinking: both ways must leave the same bits."""
+    a = _train(hip_device, 1, vpr, steps=16, densify_at=4, interval=4, reuse_passes=True)
+    b = _train(hip_device, 1, vpr, steps=16, densify_at=4, interval=4, reuse_passes=False)
+    assert a["n"] == b["n"] != 6000
+    assert_bits_equal(a["g"], b["g"], "gaussians: resized vs rebuilt passes")
+    assert_bits_equal(a["sh"], b["sh"], "sh: resized vs rebuilt passes")
+    for k in a["state"]:
+        assert_bits_equal(a["state"][k], b["state"][k], f"optimizer state {k}: resized vs rebuilt passes")
 
 
 @pytest.mark.parametrize("vpr,depth", [(1, 1), (1, 2), (3, 1), (3, 2)])

@@ -160,6 +160,7 @@ SIGNATURES = {
     "wdgs_sorter_capacity": (_U, [_P]),
     "wdgs_tiled_forward_create": (_I, [_P, C.POINTER(TiledForwardConfig), C.POINTER(_P)]),
     "wdgs_tiled_forward_destroy": (_I, [_P]),
+    "wdgs_tiled_forward_resize": (_I, [_P, _U]),
     "wdgs_tiled_forward_encode": (_I, [_P, _P, _P, _P, _I]),
     "wdgs_tiled_forward_set_viewport": (_I, [_P, _U, _U]),
     "wdgs_tiled_forward_set_render_mode": (_I, [_P, _U]),
@@ -175,6 +176,7 @@ SIGNATURES = {
     "wdgs_tiled_rasterizer_get_n_contrib": (_I, [_P, C.POINTER(_P)]),
     "wdgs_tiled_rasterizer_get_tile_offsets": (_I, [_P, C.POINTER(_P)]),
     "wdgs_tiled_backward_create": (_I, [_P, C.POINTER(TiledBackwardConfig), C.POINTER(_P)]),
+    "wdgs_tiled_backward_resize": (_I, [_P, _U]),
     "wdgs_tiled_backward_destroy": (_I, [_P]),
     "wdgs_tiled_backward_encode": (_I, [_P, _P, _P, C.POINTER(TiledBackwardResources), _P]),
     "wdgs_tiled_backward_compute_loss_only": (_I, [_P, _P, _P]),

@@ -95,6 +95,7 @@ struct wdgs_tiled_forward {
     u32* splats;
     u32* depths;
     u32* block_counts;  // u32[ceil(N/256)]: tile entries per project_count workgroup, scanned in place into workgroup offsets
+    u32 points_capacity;  // Gaussians the per-Gaussian buffers above and the scanner hold (>= cfg.num_points: wdgs_tiled_forward_resize)
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
     wdgs_sorter* sorter;
     // Per-tile range table u32[tiles + 1].  The sort of tile-structured keys needs it half way (sort.hip, sort_segmented), so the
@@ -132,6 +133,7 @@ struct wdgs_tiled_backward {
     u32* metric_flags;   // u32[W*H]
     u32* metric_minmax;  // u32[2] + scratch
     u32 img_capacity;    // pixels allocated
+    u32 points_capacity; // Gaussians acc / gradients / metric_counts hold (>= cfg.num_points: wdgs_tiled_backward_resize)
 };
 
 struct wdgs_optimizer {
@@ -518,6 +520,29 @@ int wdgs_prefix_scanner_scan_ptr(wdgs_prefix_scanner* s, const void* in, void* o
 }
 
 // ---------------------------------------------------------------- TiledForwardPass
+// Tile entries a pass over n Gaussians may produce before it reports WDGS_E_CAPACITY.
+static uint64_t forward_tile_entry_cap(const wdgs_tiled_forward_config& cfg, u32 n) {
+    uint64_t cap;
+    if (cfg.compat_caps) {  // tiled-forward-pass.ts:137-154
+        uint64_t base = std::min<uint64_t>((uint64_t)n * 30, (uint64_t)n * 2048);
+        cap = std::min<uint64_t>(std::min<uint64_t>(base, 32ull * 1024 * 1024), 2097152ull);
+        cap = (cap + 3839) / 3840 * 3840;
+    } else if (cfg.max_tile_entries) {
+        cap = cfg.max_tile_entries;
+    } else {
+        cap = std::max<uint64_t>((uint64_t)n * 30, 1ull << 20);
+    }
+    return std::min<uint64_t>(align_up(cap, 4096), 0xFFFFF000ull);
+}
+static int forward_alloc_per_point(wdgs_tiled_forward* op, u32 capacity) {
+    wdgs_device* d = op->dev;
+    int r = wdgs_alloc((void**)&op->splats, (size_t)24 * capacity, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * capacity, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->block_counts, (size_t)4 * (ceil_div(capacity, 256) + 1), true, d->stream);
+    if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, capacity, &op->scanner);
+    if (r == WDGS_OK) op->points_capacity = capacity;
+    return r;
+}
 static void forward_set_viewport(wdgs_tiled_forward* op, u32 w, u32 h) {
     op->cfg.viewport_width = w;
     op->cfg.viewport_height = h;
@@ -547,17 +572,8 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->ranges_valid = false;
     op->encoded = false;
     const u32 n = cfg->num_points;
-    uint64_t cap;
-    if (cfg->compat_caps) {  // tiled-forward-pass.ts:137-154
-        uint64_t base = std::min<uint64_t>((uint64_t)n * 30, (uint64_t)n * 2048);
-        cap = std::min<uint64_t>(std::min<uint64_t>(base, 32ull * 1024 * 1024), 2097152ull);
-        cap = (cap + 3839) / 3840 * 3840;
-    } else if (cfg->max_tile_entries) {
-        cap = cfg->max_tile_entries;
-    } else {
-        cap = std::max<uint64_t>((uint64_t)n * 30, 1ull << 20);
-    }
-    cap = std::min<uint64_t>(align_up(cap, 4096), 0xFFFFF000ull);
+    const uint64_t cap = forward_tile_entry_cap(*cfg, n);
+    op->points_capacity = std::max(n, 1u);
     op->settings = RenderSettings{cfg->gaussian_scale != 0.f ? cfg->gaussian_scale : 1.0f, (float)cfg->sh_deg, 0.f, 0.f,
                                   cfg->point_size_px != 0.f ? cfg->point_size_px : 3.0f, cfg->render_mode ? 1.0f : 0.0f,
                                   cfg->max_splat_radius_px != 0.f ? cfg->max_splat_radius_px : 128.0f};
@@ -566,10 +582,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     int r = wdgs_alloc((void**)&op->stats, 16 + 64 * 4, true, d->stream);
     if (r == WDGS_OK && hipHostMalloc((void**)&op->host_stats, 16, hipHostMallocDefault) != hipSuccess) { wdgs_set_error("hipHostMalloc(16) failed"); r = WDGS_E_HIP; }
     if (r == WDGS_OK) std::memset(op->host_stats, 0, 16);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->splats, (size_t)24 * std::max(n, 1u), true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * std::max(n, 1u), true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->block_counts, (size_t)4 * (ceil_div(std::max(n, 1u), 256) + 1), true, d->stream);
-    if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, std::max(n, 1u), &op->scanner);
+    if (r == WDGS_OK) r = forward_alloc_per_point(op, std::max(n, 1u));
     if (r == WDGS_OK) r = wdgs_sorter_create(d, (u32)cap, op->stats, &op->sorter);
     if (r != WDGS_OK) { wdgs_tiled_forward_destroy(op); return r; }
     d->forwards.push_back(op);
@@ -593,6 +606,47 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     wdgs_prefix_scanner_destroy(op->scanner);
     wdgs_sorter_destroy(op->sorter);
     delete op;
+    return WDGS_OK;
+}
+
+// The point cloud changed size (densify / prune: applyPointCloudSwap, trainer.ts:201-237, which destroys the pass and builds a new
+// one).  Here the pass is kept: its per-Gaussian buffers and its sort buffers are reused when they are large enough and re-allocated
+// with 25 % headroom when they are not, so a training run re-allocates a few times at most.  After the call the pass is in the state
+// of a freshly created one for n points (zeroed buffers, nothing encoded); max_tile_entries follows the same formula as at creation.
+int wdgs_tiled_forward_resize(wdgs_tiled_forward* op, uint32_t n) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_resize: null op");
+    wdgs_device* d = op->dev;
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_tiled_forward_resize while recording a command buffer");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    WDGS_CHECK_HIP(wdgs_sync_lanes(d));
+    const u32 need = std::max(n, 1u);
+    if (need > op->points_capacity) {
+        free_dev(op->splats); free_dev(op->depths); free_dev(op->block_counts);
+        op->splats = op->depths = op->block_counts = nullptr;
+        wdgs_prefix_scanner_destroy(op->scanner);
+        op->scanner = nullptr;
+        op->points_capacity = 0;
+        WDGS_TRY(forward_alloc_per_point(op, (u32)std::min<uint64_t>((uint64_t)need + need / 4, 0xFFFFFFFFull)));
+    } else {
+        WDGS_CHECK_HIP(hipMemsetAsync(op->splats, 0, (size_t)24 * need, d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->depths, 0, (size_t)4 * need, d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->block_counts, 0, (size_t)4 * (ceil_div(need, 256) + 1), d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->scanner->input, 0, (size_t)4 * need, d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->scanner->output, 0, (size_t)4 * need, d->stream));
+    }
+    const uint64_t cap = forward_tile_entry_cap(op->cfg, n);
+    if (cap > wdgs_sorter_capacity(op->sorter)) {
+        wdgs_sorter_destroy(op->sorter);
+        op->sorter = nullptr;
+        const uint64_t roomy = op->cfg.compat_caps || op->cfg.max_tile_entries ? cap : std::min<uint64_t>(align_up(cap + cap / 4, 4096), 0xFFFFF000ull);
+        WDGS_TRY(wdgs_sorter_create(d, (u32)roomy, op->stats, &op->sorter));
+    }
+    op->tile_info.max_tile_entries = (u32)cap;
+    op->cfg.num_points = n;
+    WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16 + 64 * 4, d->stream));
+    std::memset(op->host_stats, 0, 16);
+    op->encoded = false;
+    op->ranges_valid = false;
     return WDGS_OK;
 }
 
@@ -794,6 +848,35 @@ static int backward_alloc_images(wdgs_tiled_backward* op, u32 w, u32 h) {
     return WDGS_OK;
 }
 
+static int backward_alloc_per_point(wdgs_tiled_backward* op, u32 capacity) {
+    wdgs_device* d = op->dev;
+    int r = wdgs_alloc((void**)&op->acc, (size_t)capacity * 48, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->gradients, (size_t)capacity * 32, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->metric_counts, (size_t)capacity * 4, true, d->stream);
+    if (r == WDGS_OK) op->points_capacity = capacity;
+    return r;
+}
+// Counterpart of wdgs_tiled_forward_resize for the backward pass's per-Gaussian buffers (accumulators, packed gradients, metric counts).
+int wdgs_tiled_backward_resize(wdgs_tiled_backward* op, uint32_t n) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_backward_resize: null op");
+    wdgs_device* d = op->dev;
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_tiled_backward_resize while recording a command buffer");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    WDGS_CHECK_HIP(wdgs_sync_lanes(d));
+    const u32 need = std::max(n, 1u);
+    if (need > op->points_capacity) {
+        free_dev(op->acc); free_dev(op->gradients); free_dev(op->metric_counts);
+        op->acc = nullptr; op->gradients = nullptr; op->metric_counts = nullptr;
+        op->points_capacity = 0;
+        WDGS_TRY(backward_alloc_per_point(op, (u32)std::min<uint64_t>((uint64_t)need + need / 4, 0xFFFFFFFFull)));
+    } else {
+        WDGS_CHECK_HIP(hipMemsetAsync(op->acc, 0, (size_t)need * 48, d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->gradients, 0, (size_t)need * 32, d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->metric_counts, 0, (size_t)need * 4, d->stream));
+    }
+    op->cfg.num_points = n;
+    return WDGS_OK;
+}
 int wdgs_tiled_backward_create(wdgs_device* d, const wdgs_tiled_backward_config* cfg, wdgs_tiled_backward** out) {
     WDGS_REQUIRE(d && cfg && out, WDGS_E_INVALID, "wdgs_tiled_backward_create: null argument");
     WDGS_REQUIRE(cfg->viewport_width > 0 && cfg->viewport_height > 0, WDGS_E_INVALID, "viewport must be non-empty");
@@ -806,10 +889,7 @@ int wdgs_tiled_backward_create(wdgs_device* d, const wdgs_tiled_backward_config*
     op->settings = RenderSettings{cfg->gaussian_scale != 0.f ? cfg->gaussian_scale : 1.0f, (float)cfg->sh_deg, (float)cfg->viewport_width,
                                   (float)cfg->viewport_height, cfg->point_size_px != 0.f ? cfg->point_size_px : 3.0f, 0.0f,
                                   cfg->max_splat_radius_px != 0.f ? cfg->max_splat_radius_px : 128.0f};
-    const size_t n = std::max(cfg->num_points, 1u);
-    int r = wdgs_alloc((void**)&op->acc, n * 48, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->gradients, n * 32, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->metric_counts, n * 4, true, d->stream);
+    int r = backward_alloc_per_point(op, std::max(cfg->num_points, 1u));
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->metric_minmax, 4096, true, d->stream);
     if (r == WDGS_OK) r = backward_alloc_images(op, cfg->viewport_width, cfg->viewport_height);
     if (r != WDGS_OK) { wdgs_tiled_backward_destroy(op); return r; }

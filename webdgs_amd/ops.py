@@ -336,6 +336,15 @@ class TiledForwardPass:
     def setCameraBuffer(self, buffer: HipBuffer) -> None:
         self.cameraBuffer = buffer
 
+    def setPointCloud(self, pointCloud: PointCloud) -> bool:
+        """Adopts a point cloud of another size (``wdgs_tiled_forward_resize``: buffers reused, or re-allocated with headroom) instead of
+        the destroy + construct of ``applyPointCloudSwap`` (trainer.ts:201-237).  False -- nothing changed -- if the SH degree differs."""
+        if pointCloud.sh_deg != self.pointCloud.sh_deg:
+            return False
+        check(self.device.lib.wdgs_tiled_forward_resize(self.handle, pointCloud.num_points))
+        self.pointCloud = pointCloud
+        return True
+
     def setGaussianScale(self, value: float) -> None:
         check(self.device.lib.wdgs_tiled_forward_set_gaussian_scale(self.handle, float(value)))
 
@@ -467,6 +476,14 @@ class TiledBackwardPass:
             return b.ptr if b is not None else None
         return _lib.TiledBackwardResources(p("splatBuffer"), p("tileOffsetsBuffer"), p("tileIndicesBuffer"), p("cameraBuffer"), p("alphaTexture"),
                                            p("nContribTexture"))
+
+    def setPointCloud(self, pointCloud: PointCloud) -> bool:
+        """See ``TiledForwardPass.setPointCloud`` (``wdgs_tiled_backward_resize``)."""
+        if pointCloud.sh_deg != self.pointCloud.sh_deg:
+            return False
+        check(self.device.lib.wdgs_tiled_backward_resize(self.handle, pointCloud.num_points))
+        self.pointCloud = pointCloud
+        return True
 
     def encode(self, encoder: Optional[HipEncoder], predictedTexture: HipBuffer, targetTexture: HipBuffer, forwardResources: dict, options=None) -> None:
         r = self._resources(forwardResources)

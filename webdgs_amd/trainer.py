@@ -61,6 +61,7 @@ class Trainer:
         # boundary); a capacity error then surfaces one step late -- the device-side guard has already kept that step's Adam from
         # running on incomplete gradients.  Densify steps, stop() and every read-back drain the pipeline first.
         self.pipeline_depth = max(1, min(int(pipeline_depth), 4))
+        self.reuse_passes = True  # applyPointCloudSwap resizes the passes instead of rebuilding them (False: the reference's teardown)
         self._tickets: list = []
         self._more_op_sets: list = []  # [forwardPass, rasterizer, backwardPass] of lanes 1.. (set 0 is the three above)
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
@@ -126,17 +127,28 @@ class Trainer:
         self.requestPointCloudSwap(ops.allocatePointCloudLike(self.device, self.pointCloud, dict(numPoints=numPoints)))
 
     def applyPointCloudSwap(self, request: dict) -> None:
-        """``trainer.ts:201-237``: tear down the op graph, adopt the new cloud (+ optimizer state), rebuild."""
+        """``trainer.ts:201-237``: adopt the new cloud (+ optimizer state) and bring the op graph to its size.  The reference destroys
+        every pass and constructs new ones; here the passes are kept and resized (``setPointCloud``: buffers reused, or re-allocated
+        with headroom when the cloud outgrew them) -- only the optimizer, which adopts the rebuilt state arrays, is new.  Passes that
+        cannot follow (another SH degree) are rebuilt as the reference does."""
+        self.drain()
         self.device.synchronize()
         oldParams = self.optimizer.getHyperparameters() if self.optimizer else None
-        for name in self._OP_NAMES:
-            op = getattr(self, name)
-            if op is not None:
-                op.destroy()
-            setattr(self, name, None)
-        self._destroy_more_op_sets()
+        if self.optimizer is not None:
+            self.optimizer.destroy()
+            self.optimizer = None
         old = self.pointCloud
         self.pointCloud = request["pointCloud"]
+        self._invalidate_command_buffers()
+        passes = [self.forwardPass, self.backwardPass, self.metricsForwardPass, self.metricsPass] + [op for more in self._more_op_sets for op in (more[0], more[2])]
+        kept = self.reuse_passes and old is not None and all(p.setPointCloud(self.pointCloud) for p in passes if p is not None)
+        if not kept:
+            for name in self._OP_NAMES:
+                op = getattr(self, name)
+                if op is not None:
+                    op.destroy()
+                setattr(self, name, None)
+            self._destroy_more_op_sets()
         self.optimizer = ops.Optimizer(self.device, self.pointCloud, oldParams or self.optimizerHyperparameters, request.get("optimizerInitialState"))
         self.optimizerHyperparameters = dict(self.optimizer.getHyperparameters())
         if old is not None and old is not self.pointCloud:
@@ -144,7 +156,6 @@ class Trainer:
             old.sh_buffer.destroy()
         self._dp_grad = self._dp_visible = self._dp_rows = self._dp_flag = None
         self._state_sliced = False
-        self._invalidate_command_buffers()
         self.ensurePipelines(self.lastViewportWidth, self.lastViewportHeight)
 
     def _invalidate_command_buffers(self) -> None:
