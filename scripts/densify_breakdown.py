@@ -46,7 +46,17 @@ for _ in range(20):
 for e in range(events):
     print(f"event {e}: {t.getPointCount()} points", flush=True)
     orig_sync = t.syncOptimizerState
+    if e == events - 1:  # per-kernel view of the last event (eager launches with events around them)
+        dev.setProfiling(True)
+        dev.kernelTimes(reset=True)
     timed("metric views + prepare + scatter (runDensifyPruneMultiView)", t.runDensifyPruneMultiView)
+    if e == events - 1:
+        dev.setProfiling(False)
+        tot = 0.0
+        for k, (n, ms) in sorted(dev.kernelTimes().items(), key=lambda kv: -kv[1][1]):
+            print(f"        {k:28s} launches {n:4d}  total {ms:8.3f} ms", flush=True)
+            tot += ms
+        print(f"        kernel sum {tot:.3f} ms", flush=True)
     req = t.consumePointCloudSwapRequest()
     if req is not None:
         timed("applyPointCloudSwap (destroy ops, new optimizer, new ops)", lambda: t.applyPointCloudSwap(req))

@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "wgslm.h"
+#include "blockcull.h"
 
 namespace {
 
@@ -84,38 +85,82 @@ __global__ __launch_bounds__(256) void metric_threshold_kernel(u32 npix, const u
 }
 
 // ------------------------------------------------------------------ K24-K25
+// metric-count.wgsl: every flagged pixel walks its first n_contrib tile entries and adds 1 to the count of each Gaussian whose
+// alpha at that pixel is >= 1/255 -- per pixel, with a global splat load per (pixel, entry) and one atomic per contributing pair.
+// Here, as in backward_raster.hip: a wave owns an 8x8 block and walks the entries its flagged pixels need in chunks of 64
+// (lane = entry), keeps the splats that can reach alpha >= 1/255 somewhere in the block (blockcull.h; conservative, so the counts do
+// not depend on it), and for each kept splat the 64 pixels vote: ONE atomic per (wave, splat) adds the number of contributing
+// pixels.  u32 sums are order-free, so the counts equal the per-pixel formulation bit for bit.
 __global__ __launch_bounds__(256) void metric_count_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
                                                             const u32* __restrict__ instances, u32 num_instances, const u32* __restrict__ splats,
                                                             u32 num_splats, const u32* __restrict__ flags, const u32* __restrict__ n_contrib,
                                                             u32* __restrict__ counts, u32 num_counts) {
-    const u32 tile_x = blockIdx.x % num_tiles_x, tile_y = blockIdx.x / num_tiles_x;
-    const u32 px = tile_x * 16u + (threadIdx.x & 15u), py = tile_y * 16u + (threadIdx.x >> 4);
-    const u32 W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
-    if (px >= W || py >= H) return;
-    const size_t p = (size_t)py * W + px;
-    if (flags[p] == 0u) return;
-    const u32 n = n_contrib[p];
-    if (n == 0u) return;
-    const u32 start = ranges[blockIdx.x];
-    if (start == 0xFFFFFFFFu) return;
+    __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, opacity, gaussian index (bits)
+    __shared__ float4 s_con_all[4][64];  // conic.x, 2*conic.y, conic.z, position of the entry in the tile's list (bits)
+    const u32 tile_id = blockIdx.x, sub = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
+    float4* const s_geo = s_geo_all[sub];  // wave-private: the four waves of a tile never synchronise
+    float4* const s_con = s_con_all[sub];
+    const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
+    const u32 px = bx + (lane & 7u), py = by + (lane >> 3);
+    const float vx = settings.viewport_x, vy = settings.viewport_y;
+    const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
+    const u32 start = ranges[tile_id];
+    u32 n_pix = 0u;
+    if (px < W && py < H && start != 0xFFFFFFFFu) {
+        const size_t p = (size_t)py * W + px;
+        if (flags[p] != 0u) n_pix = n_contrib[p];
+    }
+    // entries past the end of the list are never read (metric-count.wgsl breaks out of its loop there)
+    const u32 avail = (start != 0xFFFFFFFFu && start < num_instances) ? num_instances - start : 0u;
+    n_pix = min(n_pix, avail);
+    u32 wmax = n_pix;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
+    if (wmax == 0u) return;
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
-    for (u32 i = 0; i < n; i++) {
-        const u32 entry = start + i;
-        if (entry >= num_instances) break;
-        const u32 g = instances[entry];
-        if (g >= num_splats || g >= num_counts) continue;
-        const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)g * 6);
-        const uint2 w01 = sp[0], w23 = sp[1], w45 = sp[2];
-        const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * settings.viewport_x;
-        const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * settings.viewport_y;
-        const float dx = pxf - cx, dy = pyf - cy;
-        const float t1 = __builtin_fmaf(wd_unpack_lo(w23.x), dx, (2.0f * wd_unpack_hi(w23.x)) * dy);
-        const float power = __builtin_fmaf(t1, dx, (wd_unpack_lo(w23.y) * dy) * dy);
-        const float G = wd_exp(-0.5f * power);
-        const float og = wd_unpack_hi(w45.y) * G;
-        const float alpha = (og < 0.99f) ? og : 0.99f;
-        if (alpha < (1.0f / 255.0f)) continue;
-        atomicAdd(&counts[g], 1u);
+    const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (u32 lo = 0; lo < wmax; lo += 64u) {
+        const u32 pos = lo + lane;
+        bool ok = false;
+        u32 g = 0u;
+        float cx = 0.f, cy = 0.f, A = 0.f, B = 0.f, Cc = 0.f, opacity = 0.f;
+        if (pos < wmax) {
+            g = instances[start + pos];
+            if (g < num_splats && g < num_counts) {
+                const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)g * 6);
+                const uint2 w01 = sp[0], w23 = sp[1], w45 = sp[2];
+                cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
+                cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
+                A = wd_unpack_lo(w23.x); B = wd_unpack_hi(w23.x); Cc = wd_unpack_lo(w23.y);
+                opacity = wd_unpack_hi(w45.y);
+                ok = block_reaches_min_alpha(A, B, Cc, opacity, blk_x0 - cx, blk_x1 - cx, blk_y0 - cy, blk_y1 - cy);
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        const u32 n_list = (u32)__popcll(m);
+        if (ok) {
+            const u32 slot = (u32)__popcll(m & lt_mask);
+            s_geo[slot] = make_float4(cx, cy, opacity, __uint_as_float(g));
+            s_con[slot] = make_float4(A, 2.0f * B, Cc, __uint_as_float(pos));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 i = 0; i < n_list; i++) {
+            const float4 geo = s_geo[i];
+            const float4 con = s_con[i];
+            const float dx = pxf - geo.x, dy = pyf - geo.y;
+            const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
+            const float power = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
+            const float G = wd_exp(-0.5f * power);
+            const float og = geo.z * G;
+            const float alpha = (og < 0.99f) ? og : 0.99f;
+            const bool act = (__float_as_uint(con.w) < n_pix) && !(alpha < (1.0f / 255.0f));
+            const u32 votes = (u32)__popcll(__ballot(act));
+            if (lane == 0u && votes != 0u) atomicAdd(&counts[__float_as_uint(geo.w)], votes);
+        }
+        __builtin_amdgcn_wave_barrier();  // the records are re-written by the next chunk
     }
 }
 
@@ -246,10 +291,7 @@ WD_DEV void scatter_slot(const ScatterArgs& a, u32 dst, u32 src, u32 variant, u3
         *reinterpret_cast<uint2*>(go) = w01;
         *reinterpret_cast<uint2*>(go + 2) = w23;
         *reinterpret_cast<uint2*>(go + 4) = w45;
-        const uint4* si = reinterpret_cast<const uint4*>(a.in_sh + (size_t)src * 24);
-        uint4* so = reinterpret_cast<uint4*>(a.out_sh + (size_t)dst * 24);
-#pragma unroll
-        for (u32 k = 0; k < 6u; k++) so[k] = si[k];
+        // (the 96-byte SH row is copied by the wave, not by this lane: scatter_kernel)
     }
     if (!a.has_state) return;
     // ---- optimizer state (fp32 masters): perturbation computed from the fp32 values
@@ -282,28 +324,48 @@ WD_DEV void scatter_slot(const ScatterArgs& a, u32 dst, u32 src, u32 variant, u3
         a.out_opacity[(size_t)dst * 3 + 1] = 0.0f;
         a.out_opacity[(size_t)dst * 3 + 2] = 0.0f;
     }
-    {
-        const float4* pi = a.in_param_sh + (size_t)src * 12;
-        float4* po = a.out_param_sh + (size_t)dst * 12;
-#pragma unroll
-        for (u32 k = 0; k < 12u; k++) po[k] = pi[k];
-        const float4* si = a.in_state_sh + (size_t)src * 24;
-        float4* so = a.out_state_sh + (size_t)dst * 24;
-#pragma unroll 4
-        for (u32 k = 0; k < 24u; k++) so[k] = reset ? zero4 : si[k];
-    }
+    // (param_sh 192 B and state_sh 384 B are copied by the wave: scatter_kernel)
 }
 
+// Thread per source Gaussian for the parts that need arithmetic (the 24-byte working copy, pos / rot / scale / opacity masters); the
+// three wide rows -- SH 96 B, param_sh 192 B, state_sh 384 B, 79 % of the 852 bytes a Gaussian carries -- are then copied by the whole
+// wave, one output slot per iteration with one 16-byte piece per lane, so every access is a contiguous run instead of 64 lanes striding
+// 96..384 bytes apart (the per-lane form moved 1.7 GB at 1.5 TB/s).
 __global__ __launch_bounds__(256) void scatter_kernel(ScatterArgs a) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.in_points) return;
-    const u32 c = a.counts[idx];
-    if (c == 0u) return;
-    const u32 off = a.offsets[idx];
-    if (off >= a.out_points) return;
-    const u32 action = a.actions[idx];
-    scatter_slot(a, off, idx, 0u, action);
-    if (c == 2u && off + 1u < a.out_points) scatter_slot(a, off + 1u, idx, 1u, action);
+    const u32 lane = threadIdx.x & 63u;
+    u32 c = 0u, off = 0u, action = 0u;
+    if (idx < a.in_points) {
+        c = a.counts[idx];
+        off = a.offsets[idx];
+        if (off >= a.out_points) c = 0u;
+        if (c != 0u) {
+            action = a.actions[idx];
+            if (c != 2u || !(off + 1u < a.out_points)) c = 1u;  // (counts are 0, 1 or 2: keep, clone / split)
+            scatter_slot(a, off, idx, 0u, action);
+            if (c == 2u) scatter_slot(a, off + 1u, idx, 1u, action);
+        }
+    }
+    // lanes 0..5: SH row (uint4 x 6); 6..17: param_sh (float4 x 12); 18..41: state_sh (float4 x 24)
+    const u32 first = idx - lane;  // the wave's first source Gaussian
+    unsigned long long todo = __ballot(c != 0u);
+    while (todo) {
+        const u32 j = (u32)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const u32 cj = (u32)__shfl((int)c, (int)j, 64), offj = (u32)__shfl((int)off, (int)j, 64), actj = (u32)__shfl((int)action, (int)j, 64);
+        const size_t src = (size_t)first + j;
+        for (u32 variant = 0; variant < cj; variant++) {
+            const size_t dst = (size_t)offj + variant;
+            if (lane < 6u) {
+                reinterpret_cast<uint4*>(a.out_sh + dst * 24)[lane] = reinterpret_cast<const uint4*>(a.in_sh + src * 24)[lane];
+            } else if (a.has_state && lane < 18u) {
+                a.out_param_sh[dst * 12 + (lane - 6u)] = a.in_param_sh[src * 12 + (lane - 6u)];
+            } else if (a.has_state && lane < 42u) {
+                const bool reset = (a.reset_new_state != 0u) && ((variant == 1u) || (actj == 2u));
+                a.out_state_sh[dst * 24 + (lane - 18u)] = reset ? make_float4(0.f, 0.f, 0.f, 0.f) : a.in_state_sh[src * 24 + (lane - 18u)];
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -319,8 +381,11 @@ int launch_metric_map(wdgs_device* dev, u32 W, u32 H, const void* pred, const vo
     const u32 npix = W * H;
     if (npix == 0) return WDGS_OK;
     const u32 grid = std::min<u32>(ceil_div(npix, 256), (u32)dev->num_cus * 8);
+    // one workgroup per CU for the pass that ends in two atomics on the same pair of words: 2000 of them queue up behind each other
+    // at the L2 (40 of the kernel's 51 us at 960x540); min / max are order-free, so the grid does not change the result
+    const u32 grid_minmax = std::min<u32>(grid, (u32)dev->num_cus);
     WDGS_LAUNCH(dev, "metric_init", metric_init_kernel, dim3(1), dim3(64), 0, (u32*)minmax);
-    WDGS_LAUNCH(dev, "metric_error", metric_error_kernel, dim3(grid), dim3(256), 0, npix, (const u32*)pred, (const u32*)targ, err_scale, (u32*)err, (u32*)minmax);
+    WDGS_LAUNCH(dev, "metric_error", metric_error_kernel, dim3(grid_minmax), dim3(256), 0, npix, (const u32*)pred, (const u32*)targ, err_scale, (u32*)err, (u32*)minmax);
     WDGS_LAUNCH(dev, "metric_threshold", metric_threshold_kernel, dim3(grid), dim3(256), 0, npix, (const u32*)err, (const u32*)minmax, threshold, (u32*)flags);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
