@@ -246,6 +246,8 @@ def main() -> None:
         eager_elapsed = time.perf_counter() - t1
         dev.setProfiling(False)
         ktimes = dev.kernelTimes()
+        if not ktimes:
+            raise RuntimeError("bench: the per-kernel leg recorded no kernel (roofline would be empty)")
 
     stats = trainer.forwardPass.check()
     e_entries, v_visible = int(stats[0]), int(stats[1])

@@ -84,6 +84,31 @@ def test_overflowing_step_is_reported_and_changes_nothing(hip_device, vpr, depth
     t.destroy()
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+def test_kernel_times_are_collected_by_ticket_waits(hip_device, depth):
+    """bench.py's per-kernel leg: eager steps with an event pair around every launch; the pairs are folded into the totals by the
+    waits of the steps themselves (not only by a full synchronize), and none is lost when a wait finds later kernels unfinished."""
+    dev = hip_device
+    cfg, g, sh, cameras, images = dp_common.dataset(dev)
+    t = Trainer(dev, seed=9, pipeline_depth=depth, use_command_buffers=False)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset(cameras, images)
+    t.start()
+    t.step([0])
+    dev.synchronize()
+    dev.setProfiling(True)
+    dev.kernelTimes(reset=True)
+    for v in (0, 1, 2, 3, 0):
+        t.step([v])
+    t.drain()
+    dev.setProfiling(False)
+    times = dev.kernelTimes(reset=True)
+    t.destroy()
+    for name in ("project_count", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward", "adam_repack"):
+        assert name in times and times[name][0] == 5 and times[name][1] > 0.0, (name, times.get(name))
+
+
 def test_tickets(hip_device):
     dev = hip_device
     buf = dev.createBuffer(64 << 20)

@@ -220,18 +220,24 @@ int wdgs_device_lane_order(wdgs_device* d, int waiter, int signal) {
     return WDGS_OK;
 }
 
+// Folds the finished event pairs into the per-kernel totals.  Pairs whose kernels have not finished yet (a wait for an earlier ticket,
+// a query between steps) stay pending: events of one queue complete in order, so the scan stops at the first unfinished pair.
 static int collect_profile(wdgs_device* d) {
+    size_t done = 0;
     for (auto& p : d->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        const hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+        if (e == hipSuccess) {
             auto& t = d->totals[p.name];
             t.launches += 1;
             t.ms += ms;
         }
         d->event_pool.push_back(p.a);
         d->event_pool.push_back(p.b);
+        done++;
     }
-    d->pending.clear();
+    d->pending.erase(d->pending.begin(), d->pending.begin() + (long)done);
     return WDGS_OK;
 }
 
@@ -283,6 +289,7 @@ int wdgs_queue_wait(wdgs_device* d, uint64_t ticket) {
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_wait while recording a command buffer");
     // (a ticket older than the ring waits on the mark that took its slot: later in the same queue, so the wait still holds)
     WDGS_CHECK_HIP(hipEventSynchronize(d->ticket_events[ticket % WDGS_TICKET_RING]));
+    if (!d->pending.empty()) collect_profile(d);
     return deferred_checks(d);
 }
 
@@ -320,6 +327,7 @@ int wdgs_device_set_profiling(wdgs_device* d, int enabled) {
 
 int wdgs_device_get_kernel_times(wdgs_device* d, wdgs_kernel_time* out, uint32_t cap, uint32_t* count) {
     WDGS_REQUIRE(d && count, WDGS_E_INVALID, "null argument");
+    if (!d->pending.empty() && !d->capturing) collect_profile(d);  // (whatever has finished by now; a synchronize before the call makes that everything)
     u32 i = 0;
     for (auto& kv : d->totals) {
         if (out && i < cap) {
