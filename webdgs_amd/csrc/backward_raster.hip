@@ -59,7 +59,7 @@ WD_DEV int cvt_fixed(float scaled) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
+__global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc) {
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
     const f2 pxy = f2{(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
     const f2 g_rg = f2{g.x, g.y};
     const float g_b = g.z;
-    f2 ar_rg = f2{0.f, 0.f}, lc_rg = f2{0.f, 0.f};
-    float ar_b = 0.f, lc_b = 0.f, la = 0.f;
+    f2 ar_rg = f2{0.f, 0.f};  // accum_rec: the colour accumulated behind the current splat
+    float ar_b = 0.f;
 
     // chunk [lo, hi) of the tile list, lane j <-> entry lo + j; software pipeline: index two chunks ahead, Splat one ahead
     auto chunk_lo = [&](u32 hi_) { return (hi_ > 64u) ? hi_ - 64u : 0u; };
@@ -161,44 +161,61 @@ __global__ __launch_bounds__(256) void backward_rasterize_kernel(RenderSettings 
             const bool cand = ((int)(__float_as_uint(aux.x) < pix_n) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
             const float t1 = __builtin_fmaf(con.x, d.x, aux.z * d.y);
             const float power = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
-            const float G = wd_exp(-0.5f * power);
+            // exp with its range handling hoisted out of the common case (dmath.h wd_exp_inrange): an argument above 87 or a NaN -- an
+            // indefinite conic after fp16 rounding -- sends the whole wave through the full form; arguments below -80 are clamped, which
+            // only changes G on lanes whose alpha is far below 1/255 either way, and G is not used on those.
+            const float xe = -0.5f * power;
+            float G;
+            if (__builtin_expect(__any(!(xe <= 87.0f)), 0)) {
+                G = wd_exp(xe);
+            } else {
+                float xc;  // max(xe, -80): one v_max_f32 (fmaxf would first quiet a NaN that cannot occur on this path)
+                asm("v_max_f32 %0, 0xc2a00000, %1" : "=v"(xc) : "v"(xe));  // 0xc2a00000 = -80.0f
+                G = wd_exp_inrange(xc);
+            }
             const float og = con.w * G;
             const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
             const bool act = cand && !(alpha < (1.0f / 255.0f));
             if (!__any(act)) continue;
-            int f_mx = 0, f_my = 0, f_cx = 0, f_cy = 0, f_cz = 0, f_op = 0, f_r = 0, f_g = 0, f_b = 0;
-            if (act) {
-                // Pairs (f2) are plain component-wise scalar arithmetic; every product and sum below is the reference's own, in its
-                // order (tiled-backward-rasterize.wgsl:108-160).
-                T = wd_div(T, 1.0f - alpha);
-                const float oml = 1.0f - la;
-                // (multiply-adds below are FMAs where the parity oracle pins them: accum_rec, dL_dalpha, dpow)
-                ar_rg = f2{__builtin_fmaf(la, lc_rg.x, oml * ar_rg.x), __builtin_fmaf(la, lc_rg.y, oml * ar_rg.y)};
-                ar_b = __builtin_fmaf(la, lc_b, oml * ar_b);
-                const float aT = alpha * T;
-                const f2 frg = (aT * g_rg) * FIXED_SCALE;
-                f_r = cvt_fixed(frg.x);
-                f_g = cvt_fixed(frg.y);
-                f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
-                const f2 col_rg = f2{col.x, col.y};
-                const f2 dc_rg = col_rg - ar_rg;
-                // (the reference starts this sum from 0.0; that only decides the sign of an all-zero sum, which the fixed-point
-                // conversion of every product it feeds maps to 0 either way)
-                const float dL_dalpha = __builtin_fmaf(col.z - ar_b, g_b, __builtin_fmaf(dc_rg.y, g_rg.y, dc_rg.x * g_rg.x)) * T;
-                la = alpha; lc_rg = col_rg; lc_b = col.z;
-                const float dL_dG = con.w * dL_dalpha;
-                f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
-                const f2 dpow = f2{__builtin_fmaf(aux.y, d.x, aux.z * d.y), __builtin_fmaf(aux.w, d.y, aux.z * d.x)};  // (dpow/ddx, dpow/ddy)
-                const float mhG = -0.5f * G;
-                const f2 dG = mhG * dpow;
-                const f2 fm = (dL_dG * (-dG)) * FIXED_SCALE;
-                f_mx = cvt_fixed(fm.x);
-                f_my = cvt_fixed(fm.y);
-                const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;  // conic.x and conic.z terms
-                f_cx = cvt_fixed(fc.x);
-                f_cz = cvt_fixed(fc.y);
-                f_cy = cvt_fixed((dL_dG * (((mhG * 2.0f) * d.x) * d.y)) * FIXED_SCALE);
-            }
+            // No branch around the per-pixel arithmetic: a pixel that does not contribute runs it with alpha = 0 and dL/dalpha = 0,
+            // which leaves its state exactly as it was (T / 1 = T, accum_rec = 0 * colour + 1 * accum_rec) and makes every one of its
+            // nine fixed-point contributions 0 (products with a zero factor; an inf * 0 = NaN converts to 0 as well) -- two selects
+            // instead of nine zero-initialisations and an exec-mask round trip.  Contributing pixels see the reference's own products
+            // and sums, in its order (tiled-backward-rasterize.wgsl:108-160); pairs (f2) are component-wise scalar arithmetic.
+            const float alpha_m = act ? alpha : 0.0f;
+            // T in [1e-4, 1] (the forward pass stops before T falls below 1e-4), 1 - alpha in [0.01, 1]: the ordinary-operand division
+            const float oma = 1.0f - alpha_m;
+            T = wd_div_inrange(T, oma);
+            // (multiply-adds below are FMAs where the parity oracle pins them: accum_rec, dL_dalpha, dpow)
+            const float aT = alpha_m * T;
+            const f2 frg = (aT * g_rg) * FIXED_SCALE;
+            const int f_r = cvt_fixed(frg.x);
+            const int f_g = cvt_fixed(frg.y);
+            const int f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
+            const f2 col_rg = f2{col.x, col.y};
+            const f2 dc_rg = col_rg - ar_rg;
+            // (the reference starts this sum from 0.0; that only decides the sign of an all-zero sum, which the fixed-point
+            // conversion of every product it feeds maps to 0 either way)
+            const float dL_dalpha_all = __builtin_fmaf(col.z - ar_b, g_b, __builtin_fmaf(dc_rg.y, g_rg.y, dc_rg.x * g_rg.x)) * T;
+            const float dL_dalpha = act ? dL_dalpha_all : 0.0f;
+            // accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec (tiled-backward-rasterize.wgsl:120-123) is evaluated by
+            // the reference at the START of the next contributing iteration from the values kept in last_alpha / last_color; the same
+            // operation on the same operands is done here, while alpha and the colour are still in registers (the first iteration's
+            // update, from last_alpha = 0 and accum_rec = 0, is +0 either way).
+            ar_rg = f2{__builtin_fmaf(alpha_m, col_rg.x, oma * ar_rg.x), __builtin_fmaf(alpha_m, col_rg.y, oma * ar_rg.y)};
+            ar_b = __builtin_fmaf(alpha_m, col.z, oma * ar_b);
+            const float dL_dG = con.w * dL_dalpha;
+            const int f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
+            const f2 dpow = f2{__builtin_fmaf(aux.y, d.x, aux.z * d.y), __builtin_fmaf(aux.w, d.y, aux.z * d.x)};  // (dpow/ddx, dpow/ddy)
+            const float mhG = -0.5f * G;
+            const f2 dG = mhG * dpow;
+            const f2 fm = (dL_dG * (-dG)) * FIXED_SCALE;
+            const int f_mx = cvt_fixed(fm.x);
+            const int f_my = cvt_fixed(fm.y);
+            const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;  // conic.x and conic.z terms
+            const int f_cx = cvt_fixed(fc.x);
+            const int f_cz = cvt_fixed(fc.y);
+            const int f_cy = cvt_fixed((dL_dG * (((mhG * 2.0f) * d.x) * d.y)) * FIXED_SCALE);
             // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
             // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
             const int w0 = fold32(f_mx, f_cz), w1 = fold32(f_my, f_op), w2 = fold32(f_cx, f_r), w3 = fold32(f_cy, f_g);

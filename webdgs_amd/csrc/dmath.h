@@ -38,6 +38,27 @@ WD_DEV float wd_exp(float x) {
     return res;
 }
 
+// wd_exp for an argument the caller has brought into [-80, 87]: the same operations in the same order, minus the exponent clamp and
+// the two range selects, which cannot fire there (n is in [-115, 126]).  Bit-identical to wd_exp on that interval
+// (tests/test_gpu_math.py walks it); 14 instead of 20 instructions in the rasterization kernels' inner loops.
+WD_DEV float wd_exp_inrange(float x) {
+    const float LOG2E = wd_bits2f(0x3FB8AA3Bu);
+    const float LN2_HI = wd_bits2f(0x3F318000u);
+    const float LN2_LO = wd_bits2f(0xB95E8083u);
+    const float C2 = wd_bits2f(1056964604u), C3 = wd_bits2f(1042983495u), C4 = wd_bits2f(1026207148u),
+                C5 = wd_bits2f(1007230415u), C6 = wd_bits2f(984890875u);
+    const float n = __builtin_rintf(x * LOG2E);
+    float r = __builtin_fmaf(-n, LN2_HI, x);
+    r = __builtin_fmaf(-n, LN2_LO, r);
+    float p = __builtin_fmaf(C6, r, C5);
+    p = __builtin_fmaf(p, r, C4);
+    p = __builtin_fmaf(p, r, C3);
+    p = __builtin_fmaf(p, r, C2);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return p * wd_bits2f((uint32_t)((int)n + 127) << 23);
+}
+
 // Two-component float value with component-wise IEEE operations, written out as scalar instructions.  (On gfx950 a wave64 VALU
 // instruction issues at 32 lanes/cycle; v_pk_*_f32 costs two issue slots plus hazard nops, so packing two fp32 operations into
 // one instruction gains nothing -- measured: the same kernels run 2-16 % faster with scalar code and -fno-slp-vectorize.)
@@ -87,6 +108,18 @@ WD_DEV float wd_log(float x) {
 // rounded under -fhip-fp32-correctly-rounded-divide-sqrt (set explicitly in the Makefile).
 WD_DEV float wd_sqrt(float x) { return __builtin_sqrtf(x); }
 WD_DEV float wd_div(float a, float b) { return a / b; }
+// a / b, correctly rounded, for operands the caller knows to be ordinary: the Newton-Raphson core of the compiler's own IEEE sequence
+// without its operand pre-scaling (v_div_scale_f32) and special-case fix-up (v_div_fixup_f32), which only act when an operand, the
+// reciprocal or the quotient leaves the normal range.  Callers: T / (1 - alpha) with T in [1e-4, 1], 1 - alpha in [0.01, 1).
+// Bit-identical to wd_div there (tests/test_gpu_math.py); 8 instead of 11 instructions.
+WD_DEV float wd_div_inrange(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    return q;
+}
 // WGSL min/max: min(e1,e2) = e2 if e2 < e1 else e1; max(e1,e2) = e2 if e1 < e2 else e1 (pins +-0 ties and NaN).
 WD_DEV float wd_min(float a, float b) { return (b < a) ? b : a; }
 WD_DEV float wd_max(float a, float b) { return (a < b) ? b : a; }

@@ -42,6 +42,10 @@ __global__ void dmath_eval_kernel(u32 which, u32 n, const u32* __restrict__ in, 
         case 5: r = wd_to_u32(x); break;                                   // saturating f32 -> u32
         case 6: r = __float_as_uint(wd_sqrt(x)); break;
         case 7: r = __float_as_uint(wd_div(1.0f, x)); break;
+        // the in-range forms used by the rasterization kernels, and their full forms on the same operands (second operand: the neighbour)
+        case 8: r = __float_as_uint(wd_exp_inrange(fmaxf(x, -80.0f))); break;
+        case 9: r = __float_as_uint(wd_div_inrange(x, __uint_as_float(in[i ^ 1u]))); break;
+        case 10: r = __float_as_uint(wd_div(x, __uint_as_float(in[i ^ 1u]))); break;
         default: break;
     }
     out[i] = r;
@@ -51,8 +55,9 @@ __global__ void dmath_eval_kernel(u32 which, u32 n, const u32* __restrict__ in, 
 
 extern "C" int wdgs_debug_eval_math(wdgs_device* dev, uint32_t which, uint32_t count, const void* in_u32_dev, void* out_u32_dev) {
     WDGS_REQUIRE(dev && (count == 0 || (in_u32_dev && out_u32_dev)), WDGS_E_INVALID, "wdgs_debug_eval_math: null argument");
-    WDGS_REQUIRE(which <= 7u, WDGS_E_INVALID, "wdgs_debug_eval_math: unknown primitive %u", which);
+    WDGS_REQUIRE(which <= 10u, WDGS_E_INVALID, "wdgs_debug_eval_math: unknown primitive %u", which);
     if (count == 0) return WDGS_OK;
+    WDGS_REQUIRE(which < 9u || (count & 1u) == 0u, WDGS_E_INVALID, "wdgs_debug_eval_math: the two-operand primitives take an even count");
     WDGS_LAUNCH(dev, "dmath_eval", dmath_eval_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, which, count, (const u32*)in_u32_dev, (u32*)out_u32_dev);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
