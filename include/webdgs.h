@@ -30,7 +30,7 @@
  *   GaussianGradient 8 x u32 = 16 fp16: dpos.xyz dopacity | drot.wxyz | dlogsigma.xyz 0 | drgb 0  shaders/tiled-backward.wgsl:18-23
  *   OptVec4 {param,m,v: vec4f} 48 B; OptFloat {param,m,v} 12 B; param_sh 48 f32; state_sh 48 x (m,v)   renderers/optimizer.ts:7-11
  *   images          rgba8unorm, row-major, W*H*4 bytes (textures in the reference)
- *   grad accumulators INTERNAL: i32 x 12 per Gaussian {mean.x, mean.y, conic.x, conic.y, conic.z, opacity, r, g, b, 0, 0, 0}
+ *   grad accumulators INTERNAL: i32 x 12 per Gaussian {mean.x, mean.y, conic.x, conic.y, conic.z, opacity, r, g, b as four partial sums}
  *                   (the reference keeps four arrays, renderers/tiled-backward-pass.ts:249-252; same fixed-point x1e6 values)
  */
 #ifndef WEBDGS_H

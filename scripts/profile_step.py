@@ -27,7 +27,10 @@ for i in range(4):
     cameras.append(dict(camera=cams[i], width=cfg.width, height=cfg.height))
 trs.destroy(); tfw.destroy()
 t = Trainer(dev, seed=1, use_command_buffers=False)
-t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg)); t.setDataset(cameras, images); t.start()
+t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg)); t.setDataset(cameras, images)
+if os.environ.get("WDGS_PROFILE_FROZEN"):  # every learning rate 0: the same scene in every step (and in every build that is compared)
+    t.setOptimizerHyperparameters({k: 0.0 for k in t.getOptimizerHyperparameters() if k.startswith("lr_")})
+t.start()
 for _ in range(3):
     t.step()
 dev.setProfiling(True); dev.kernelTimes(reset=True)

@@ -84,7 +84,11 @@ def acc_to_reference_layout(acc12, n):
     gm = np.ascontiguousarray(a[:, 0:2]).reshape(-1)
     gc = np.zeros((n, 4), np.int32)
     gc[:, 0], gc[:, 1], gc[:, 3] = a[:, 2], a[:, 3], a[:, 4]
-    return gm, gc.reshape(-1), np.ascontiguousarray(a[:, 5]), np.ascontiguousarray(a[:, 6:9]).reshape(-1)
+    colors = np.empty((n, 3), np.int32)
+    colors[:, 0:2] = a[:, 6:8]
+    # blue is kept as four partial sums (words 8..11, one per 16-lane row of the producing waves); i32 sums wrap like atomicAdd
+    colors[:, 2] = (np.ascontiguousarray(a[:, 8:12]).view(np.uint32).sum(axis=1, dtype=np.uint64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    return gm, gc.reshape(-1), np.ascontiguousarray(a[:, 5]), colors.reshape(-1)
 
 
 def assert_bits_equal(a, b, what):

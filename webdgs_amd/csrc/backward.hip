@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const flo
     o1.x = wd_pack2(dL_dlog_scale.x, dL_dlog_scale.y);
     o1.y = wd_pack2(dL_dlog_scale.z, 0.0f);
     o1.z = wd_pack2(from_fixed(a1.z), from_fixed(a1.w));
-    o1.w = wd_pack2(from_fixed(a2.x), 0.0f);
+    // blue arrives as four partial sums, one per 16-lane row of the waves that produced it (backward_raster.hip); i32 sums wrap, as atomicAdd does
+    o1.w = wd_pack2(from_fixed((int)((unsigned)a2.x + (unsigned)a2.y + (unsigned)a2.z + (unsigned)a2.w)), 0.0f);
     uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
     op[0] = o0;
     op[1] = o1;

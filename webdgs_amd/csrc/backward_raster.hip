@@ -11,7 +11,8 @@
 //     neighbour with many;
 //   * the 9 per-pixel contributions are summed across the wave in registers by a halving butterfly
 //     (v_permlane32_swap, v_permlane16_swap, DPP row reduce: 28 VALU ops for all nine sums instead of 9 full reductions)
-//     and land in nine lanes that issue ONE atomic instruction per (wave, splat) -- instead of 9 per (pixel, splat);
+//     and land in twelve lanes (eight slots, and blue as one partial sum per 16-lane row) that issue ONE atomic instruction per
+//     (wave, splat) on twelve consecutive words -- instead of 9 per (pixel, splat);
 //   * a tile's four waves share a workgroup (one CU, one XCD), so its entries and splats come from that XCD's L2 (raster.hip).
 // The contributions keep the reference's semantics exactly: each is truncated to i32 at x1e6 per pixel
 // (common.wgsl:113-116) and integer addition is order-free, so the result is bit-reproducible and equal to the oracle's.
@@ -22,13 +23,22 @@
 
 namespace {
 
-constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity, rgb, 3 pad
+constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity, r, g, and blue as four partial sums (words 8..11)
 
 WD_DEV int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }       // quad_perm [1,0,3,2]
 WD_DEV int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }       // quad_perm [2,3,0,1]
 WD_DEV int dpp_half_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); }
 WD_DEV int dpp_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); }
 
+WD_DEV int dpp_ror4(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); }  // row_ror:4: a rotation by one quad within the row
+WD_DEV int dpp_ror8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); }  // row_ror:8
+// every lane of each quad ends up with the quad's sum
+WD_DEV int quad_sum(int v0) {
+    unsigned v = (unsigned)v0;  // wrapping two's-complement sums, like atomicAdd on atomic<i32>
+    v += (unsigned)dpp_xor1((int)v);
+    v += (unsigned)dpp_xor2((int)v);
+    return (int)v;
+}
 // every lane of each 16-lane row ends up with the row's sum
 WD_DEV int row_sum(int v0) {
     unsigned v = (unsigned)v0;  // wrapping two's-complement sums, like atomicAdd on atomic<i32>
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettin
     const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
     const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const u32 quad_lane = lane & 3u;
 
     const u32 range_start = ranges[tile_id];
     const u32 range_end = ranges[tile_id + 1u];
@@ -220,16 +231,24 @@ __global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettin
             // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
             const int w0 = fold32(f_mx, f_cz), w1 = fold32(f_my, f_op), w2 = fold32(f_cx, f_r), w3 = fold32(f_cy, f_g);
             // fold16: rows 0..3 of u0 carry slots 0,2,4,6; rows of u1 carry slots 1,3,5,7 (per column)
-            const int u0 = row_sum(fold16(w0, w2)), u1 = row_sum(fold16(w1, w3));
-            int t8 = row_sum(f_b);
-            t8 = fold32(t8, t8);
-            t8 = fold16(t8, t8);  // every lane: total of slot 8
-            const u32 col_in_row = lane & 15u;
-            if (col_in_row < 2u || lane == 2u) {
-                const u32 slot = (lane == 2u) ? 8u : 2u * (lane >> 4) + col_in_row;
-                const int v = (lane == 2u) ? t8 : (col_in_row == 0u ? u0 : u1);
+            const int u0 = quad_sum(fold16(w0, w2)), u1 = quad_sum(fold16(w1, w3)), q8 = quad_sum(f_b);
+            // Every lane of a quad now holds its quad's sum of each of the three registers.  Lane j of the quad keeps one of them
+            // (j = 0: u0, 1: u1, 2: blue), so the remaining row reduction -- quads 0..3 of a 16-lane row -- is done ONCE on the merged
+            // register (two rotations by whole quads) instead of once per register.  Blue is not folded across the four rows: row r
+            // adds its partial sum to slot 8 + r (the accumulator row has twelve words; geometry_backward adds the four up), so the
+            // twelve atomic lanes of a splat hit twelve different consecutive words.
+            int m = (quad_lane == 0u) ? u0 : (quad_lane == 1u ? u1 : q8);
+            m = (int)((unsigned)m + (unsigned)dpp_ror4(m));
+            m = (int)((unsigned)m + (unsigned)dpp_ror8(m));
+            if ((lane & 15u) < 3u) {
+                const u32 row = lane >> 4;
+                const u32 slot = (quad_lane == 2u) ? 8u + row : 2u * row + quad_lane;
                 const u32 gidx = __float_as_uint(col.w);
-                if (v != 0) atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + slot], v);
+#ifdef WDGS_EXPERIMENT_NO_ATOMICS  // timing experiment only (results are wrong): what the kernel costs without its global atomics
+                asm volatile("" ::"v"(m), "v"(gidx), "v"(slot));
+#else
+                if (m != 0) atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + slot], m);
+#endif
             }
         }
         __builtin_amdgcn_wave_barrier();  // all lanes are done reading the records before the next chunk overwrites them

@@ -38,9 +38,9 @@ WD_DEV float wd_exp(float x) {
     return res;
 }
 
-// wd_exp for an argument the caller has brought into [-80, 87]: the same operations in the same order, minus the exponent clamp and
-// the two range selects, which cannot fire there (n is in [-115, 126]).  Bit-identical to wd_exp on that interval
-// (tests/test_gpu_math.py walks it); 14 instead of 20 instructions in the rasterization kernels' inner loops.
+// wd_exp for an argument the caller has brought into [-86, 87]: the same operations in the same order, minus the exponent clamp and
+// the two range selects, which cannot fire there (n is in [-124, 126]).  Bit-identical to wd_exp on that interval
+// (tests/test_gpu_math.py walks it); 13 instead of 19 instructions in the rasterization kernels' inner loops.
 WD_DEV float wd_exp_inrange(float x) {
     const float LOG2E = wd_bits2f(0x3FB8AA3Bu);
     const float LN2_HI = wd_bits2f(0x3F318000u);

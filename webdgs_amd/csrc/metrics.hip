@@ -43,7 +43,7 @@ __global__ void dmath_eval_kernel(u32 which, u32 n, const u32* __restrict__ in, 
         case 6: r = __float_as_uint(wd_sqrt(x)); break;
         case 7: r = __float_as_uint(wd_div(1.0f, x)); break;
         // the in-range forms used by the rasterization kernels, and their full forms on the same operands (second operand: the neighbour)
-        case 8: r = __float_as_uint(wd_exp_inrange(fmaxf(x, -80.0f))); break;
+        case 8: r = __float_as_uint(wd_exp_inrange(x)); break;
         case 9: r = __float_as_uint(wd_div_inrange(x, __uint_as_float(in[i ^ 1u]))); break;
         case 10: r = __float_as_uint(wd_div(x, __uint_as_float(in[i ^ 1u]))); break;
         default: break;
