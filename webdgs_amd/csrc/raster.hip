@@ -114,10 +114,22 @@ __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings,
                     if (active) {
                         const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
                         const float q = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
-                        const float G = wd_exp(-0.5f * q);
-                        // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G in [0, inf]), so the hardware
-                        // min/max equal WGSL's select-based clamp.
-                        const float alpha = fminf(fmaxf(G * con.w, 0.0f), 0.99f);
+                        // exp with its range handling hoisted out of the common case (dmath.h wd_exp_inrange): an argument above 87 or a
+                        // NaN -- an indefinite conic after fp16 rounding -- sends the wave through the full form.  Below -86, where wd_exp
+                        // returns 0, the argument is clamped instead: alpha is then at most exp(-86) = 4.5e-38 rather than 0, a weight that
+                        // every colour sum and the alpha sum absorb without a trace (the smallest weight that matters is above 1e-10 of
+                        // the sums; alone, it quantises to 0 and leaves T = 1 - A = 1); the 1/255 test for n_contrib is far away.
+                        // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G in [0, inf]), so the hardware min/max equal
+                        // WGSL's select-based clamp, and with a finite G the lower clamp is the identity and is left out.
+                        const float xe = -0.5f * q;
+                        float alpha;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(xe <= 87.0f)) != 0ull, 0)) {
+                            alpha = fminf(fmaxf(wd_exp(xe) * con.w, 0.0f), 0.99f);
+                        } else {
+                            float xc;  // max(xe, -86): one v_max_f32 (fmaxf would first quiet a NaN that cannot occur on this path)
+                            asm("v_max_f32 %0, 0xc2ac0000, %1" : "=v"(xc) : "v"(xe));  // 0xc2ac0000 = -86.0f
+                            alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
+                        }
                         const float w = alpha * (1.0f - A);
                         cr = __builtin_fmaf(col.x, w, cr);
                         cg = __builtin_fmaf(col.y, w, cg);
