@@ -95,3 +95,14 @@ def test_inrange_forms_equal_the_full_forms_where_the_kernels_use_them(hip_devic
     pb = pairs.view(np.uint32)
     short, full = _device(hip_device, 9, pb)[0::2], _device(hip_device, 10, pb)[0::2]
     _same(short, full, "wd_div_inrange vs wd_div", pb[0::2])
+    # the loss kernel's operands: numerators of either sign from 1e-20 to 1e3 and exact zeros, denominators 25 and [1e-8, 1e3]
+    n = 10_000_000
+    a = (np.exp(rng.uniform(np.log(1e-20), np.log(1e3), n)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    a[rng.random(n) < 0.02] = 0.0
+    # (not -0: the short form returns +0 for -0 / b; the kernel's numerators are sums that start from +0 and a product with a positive factor)
+    b = np.where(rng.random(n) < 0.4, 25.0, np.exp(rng.uniform(np.log(1e-8), np.log(1e3), n))).astype(np.float32)
+    pairs = np.empty(2 * n, np.float32)
+    pairs[0::2], pairs[1::2] = a, b
+    pb = pairs.view(np.uint32)
+    short, full = _device(hip_device, 9, pb)[0::2], _device(hip_device, 10, pb)[0::2]
+    _same(short, full, "wd_div_inrange vs wd_div on the loss kernel's operand range", pb[0::2])

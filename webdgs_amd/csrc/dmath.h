@@ -110,8 +110,10 @@ WD_DEV float wd_sqrt(float x) { return __builtin_sqrtf(x); }
 WD_DEV float wd_div(float a, float b) { return a / b; }
 // a / b, correctly rounded, for operands the caller knows to be ordinary: the Newton-Raphson core of the compiler's own IEEE sequence
 // without its operand pre-scaling (v_div_scale_f32) and special-case fix-up (v_div_fixup_f32), which only act when an operand, the
-// reciprocal or the quotient leaves the normal range.  Callers: T / (1 - alpha) with T in [1e-4, 1], 1 - alpha in [0.01, 1).
-// Bit-identical to wd_div there (tests/test_gpu_math.py); 8 instead of 11 instructions.
+// reciprocal or the quotient leaves the normal range.  Callers: T / (1 - alpha) with T in [1e-4, 1], 1 - alpha in [0.01, 1]; the window
+// means, variances and the SSIM quotient of loss.hip (numerators 0 or of either sign up to 1e2, denominators 25 or at least 1e-8).
+// Bit-identical to wd_div there (tests/test_gpu_math.py), a numerator of -0 excepted (it yields +0; none of the callers can produce
+// one); 8 instead of 11 instructions.
 WD_DEV float wd_div_inrange(float a, float b) {
     float r = __builtin_amdgcn_rcpf(b);
     r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);

@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
         f2 sx2a[PPT], sx2b[PPT], sy2a[PPT], sy2b[PPT], sxya[PPT], sxyb[PPT], ma[PPT], mb[PPT], na[PPT], nb[PPT];
 #pragma unroll
         for (u32 k = 0; k < PPT; k++) {
-            mx[k][0] = wd_div(mxa[k].x, n); mx[k][1] = wd_div(mxa[k].y, n); mx[k][2] = wd_div(mxb[k].x, n);
-            my[k][0] = wd_div(mya[k].x, n); my[k][1] = wd_div(mya[k].y, n); my[k][2] = wd_div(myb[k].x, n);
+            // (window sums of values in [0, 1] over 25; below, sums of squares over 25 and a quotient whose denominator is at least
+            // c1 * c2 > 0: ordinary operands, so the division without operand scaling and special-case fix-up -- dmath.h)
+            mx[k][0] = wd_div_inrange(mxa[k].x, n); mx[k][1] = wd_div_inrange(mxa[k].y, n); mx[k][2] = wd_div_inrange(mxb[k].x, n);
+            my[k][0] = wd_div_inrange(mya[k].x, n); my[k][1] = wd_div_inrange(mya[k].y, n); my[k][2] = wd_div_inrange(myb[k].x, n);
             ma[k] = f2{mx[k][0], mx[k][1]}; mb[k] = f2{mx[k][2], 0.f};
             na[k] = f2{my[k][0], my[k][1]}; nb[k] = f2{my[k][2], 0.f};
             sx2a[k] = sx2b[k] = sy2a[k] = sy2b[k] = sxya[k] = sxyb[k] = f2{0.f, 0.f};
@@ -130,12 +132,14 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
         if (dssim) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float vx = wd_div(sx2[k][c], n), vy = wd_div(sy2[k][c], n), vxy = wd_div(sxy[k][c], n);
+                const float vx = wd_div_inrange(sx2[k][c], n), vy = wd_div_inrange(sy2[k][c], n), vxy = wd_div_inrange(sxy[k][c], n);
                 const float num1 = 2.0f * mx[k][c] * my[k][c] + cfg.c1;
                 const float num2 = 2.0f * vxy + cfg.c2;
                 const float den1 = mx[k][c] * mx[k][c] + my[k][c] * my[k][c] + cfg.c1;
                 const float den2 = vx + vy + cfg.c2;
-                const float ssim = wd_div(num1 * num2, den1 * den2);
+                // (a caller may set c1 = c2 = 0: then a flat window makes the denominator 0 and the full form's special cases are needed)
+                const float den = den1 * den2;
+                const float ssim = (cfg.c1 > 0.0f && cfg.c2 > 0.0f) ? wd_div_inrange(num1 * num2, den) : wd_div(num1 * num2, den);
                 g[c] = ((1.0f - ssim) * 0.5f) * d[c];
             }
         }
