@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettin
             const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;  // conic.x and conic.z terms
             const int f_cx = cvt_fixed(fc.x);
             const int f_cz = cvt_fixed(fc.y);
-            const int f_cy = cvt_fixed((dL_dG * (((mhG * 2.0f) * d.x) * d.y)) * FIXED_SCALE);
+            // conic.y term: the reference's ((mhG * 2) * dx) * dy, scaled by dL_dG and 1e6.  A factor 2 commutes with every rounding, so it
+            // is taken out of the chain -- which then starts from the mhG * dx of the conic.x term -- and folded into the scale (2e6 is exact).
+            const int f_cy = cvt_fixed((dL_dG * ((mhG * d.x) * d.y)) * (2.0f * FIXED_SCALE));
             // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
             // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
             const int w0 = fold32(f_mx, f_cz), w1 = fold32(f_my, f_op), w2 = fold32(f_cx, f_r), w3 = fold32(f_cy, f_g);

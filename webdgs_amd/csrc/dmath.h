@@ -56,7 +56,9 @@ WD_DEV float wd_exp_inrange(float x) {
     p = __builtin_fmaf(p, r, C2);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
-    return p * wd_bits2f((uint32_t)((int)n + 127) << 23);
+    // p * 2^n with n in [-124, 126] and p in [0.7, 1.42]: exact either way, and v_ldexp_f32 is one instruction where building the power
+    // of two and multiplying by it are two
+    return __builtin_ldexpf(p, (int)n);
 }
 
 // Two-component float value with component-wise IEEE operations, written out as scalar instructions.  (On gfx950 a wave64 VALU
