@@ -287,3 +287,43 @@ def test_dp_step_with_one_view_equals_reference_step(hip_device):
     finally:
         for p in (a, b, tp):
             p.destroy()
+
+
+def test_resized_passes_behave_like_fresh_ones(hip_device):
+    """wdgs_tiled_forward_resize / wdgs_tiled_backward_resize (what applyPointCloudSwap uses instead of destroy + construct): a pass
+    taken from 5 000 to 9 000 Gaussians (re-allocates, with headroom), on to 9 700 (fits the headroom) and down to 3 000 (fits) must
+    produce, stage by stage, the bits of a pass constructed for that cloud -- forward, composite, gradients, accumulators."""
+    dev = hip_device
+    big_cfg = harness.small_config("c1", num_points=9_700, width=160, height=128)
+    g, sh, cam = harness.scene(big_cfg)
+    target = None
+    pipe = harness.HipPipeline(dev, harness.small_config("c1", num_points=5_000, width=160, height=128), g[:5_000], sh[:5_000], cam)
+    try:
+        pipe.forward()
+        for n in (9_000, 9_700, 3_000):
+            cfg = harness.small_config("c1", num_points=n, width=160, height=128)
+            pc = ops.createPointCloud(dev, g[:n], sh[:n], cfg.sh_deg)
+            assert pipe.fwd.setPointCloud(pc) and pipe.bwd.setPointCloud(pc)
+            pipe.pc, pipe.cfg = pc, cfg
+            fresh = harness.HipPipeline(dev, cfg, g[:n], sh[:n], cam)
+            try:
+                for p in (pipe, fresh):
+                    p.forward()
+                a, b = pipe.collect_forward(), fresh.collect_forward()
+                assert a["total_entries"] == b["total_entries"] > 0
+                assert pipe.fwd.getResources()["maxTileEntries"] == fresh.fwd.getResources()["maxTileEntries"]
+                for k in a:
+                    harness.assert_bits_equal(np.asarray(a[k]), np.asarray(b[k]), f"{n} Gaussians, resized vs fresh pass: {k}")
+                if target is None:
+                    target = dev.bufferFrom(np.full(cfg.width * cfg.height, 0xFF406080, np.uint32))
+                for p in (pipe, fresh):
+                    p.bwd.encode(None, p.rast.getOutputTextureView(), target, p.backward_resources())
+                dev.synchronize()
+                harness.assert_bits_equal(pipe.bwd.getGradientsBuffer().read(np.uint32), fresh.bwd.getGradientsBuffer().read(np.uint32), f"{n}: gradients")
+                harness.assert_bits_equal(pipe.bwd.getAccumulatorsBuffer().read(np.int32), fresh.bwd.getAccumulatorsBuffer().read(np.int32), f"{n}: accumulators")
+            finally:
+                fresh.destroy()
+        other_deg = ops.createPointCloud(dev, g[:100], sh[:100], 3 if big_cfg.sh_deg != 3 else 1)
+        assert not pipe.fwd.setPointCloud(other_deg), "another SH degree: the pass cannot follow and says so"
+    finally:
+        pipe.destroy()
