@@ -8,15 +8,19 @@ Workload: config c3 ("c3-perf": 1 M synthetic Gaussians, 1920x1080, SH degree 3;
 same HIP forward from the perturbed scene.  A training view = project -> scan -> emit -> sort -> ranges -> composite -> loss ->
 backward raster -> geometry backward.
 
-  N = 1   BASELINE config c3, the reference's own step: ONE view + fused Adam + re-pack per Trainer.step(), per-step host sync
-          (trainer.ts:568-660); 8 circle cameras.  `value` = steps (= views) per second.
+  N = 1   BASELINE config c3, the reference's own step: ONE view + fused Adam + re-pack per Trainer.step() (trainer.ts:568-660);
+          8 circle cameras.  `value` = steps (= views) per second.
   N > 1   BASELINE config c4's shape: 64 circle cameras, `--views-per-rank` (default 8) views per rank per global step -- 64 global
           views at N = 8 -- summed locally in fp32, then ONE exchange per global step: reduce-scatter of the 60 B/Gaussian gradient
           block, Adam + re-pack on the owned 1/N slice, all-gather of the re-packed 32 B rows (webdgs_amd/parallel.py).  Weak
-          scaling: the per-rank work (8 views) is fixed as N grows.  `value` = views per second of the whole job.
+          scaling: the per-rank work (8 views) is fixed as N grows.  `value` = views per second of the whole job.  A rank deals its
+          views to `--lanes` device lanes (default 3) so one view's bandwidth-bound stages run beside another's rasterization kernels.
           (`--views-per-rank 8` at N = 1 gives the single-GPU rate of the same 8-view step, the like-for-like base of the curve.)
 
-The timed region is K Trainer.step() calls between a barrier + torch.cuda.synchronize() on both sides, max over ranks.  After it:
+The timed region is K Trainer.step() calls between a barrier + torch.cuda.synchronize() on both sides, max over ranks.  Submission
+(`--pipeline-depth`, default 2): a step awaits the PREVIOUS step's completion ticket, so the host submits step k+1 while step k runs; every
+one of the K steps has finished when the clock stops.  The reference awaits inside every step (trainer.ts:639-645); that form is timed right
+after as `ms_per_step_awaiting_every_step` (and is what `--pipeline-depth 1` makes the headline).  After the timed region:
 an eager pass with hipEvents around every launch on the launch stream (per-kernel averages, roofline of the dominant kernel), at
 N = 1 a `sustained` leg (620 steps at the reference's densify defaults, crossing the first two densify events) and the
 `cpu_baseline` (the oracle's train step built -O3 -march=native on this box's host cores).  ONE JSON line on rank 0.
