@@ -304,3 +304,46 @@ def test_c5_from_a_loaded_ply_with_the_50k_densify_equals_the_oracle_trainer(hip
         _compare(t, o, "c5: step + 50k-capped densify")
     finally:
         t.destroy()
+
+
+def test_c2_long_run_is_the_same_whichever_way_it_is_driven(hip_device):
+    """BASELINE c2 (100 k Gaussians, 640x480) for 1 250 iterations at the reference's densify schedule -- eight densify events,
+    the cloud shrinking from 100 k -- driven two ways: as the reference drives it (every step awaited, passes destroyed and rebuilt
+    at every swap, one lane) and as bench.py drives it (a step awaits the previous one, passes resized, command buffers re-recorded).
+    Integer accumulation and fixed summation orders make the whole trajectory deterministic, so point cloud, point count and
+    optimizer state must come out bit-identical."""
+    from webdgs_amd.trainer import Trainer
+    import bench
+    dev = hip_device
+    cfg = synth.CONFIGS["c2"]
+    g, sh = synth.make_gaussians(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    cameras, images = bench.make_dataset(dev, cfg, tg, tsh, synth.circle_cameras(cfg, 8))
+
+    def run(depth, reuse, command_buffers, vpr=1, lanes=1, iterations=1250):
+        t = Trainer(dev, seed=77, pipeline_depth=depth, use_command_buffers=command_buffers, views_per_rank=vpr, overlap_views=lanes)
+        t.reuse_passes = reuse
+        t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+        t.setDataset(cameras, images)
+        t.setMaxIterations(10 ** 9)
+        t.start()
+        sizes = [t.getPointCount()]
+        while t.getIteration() < iterations:
+            t.step()
+            if t.getPointCount() != sizes[-1]:
+                sizes.append(t.getPointCount())
+        t.drain()
+        dev.synchronize()
+        out = dict(sizes=sizes, g=_digest(t.pointCloud.gaussian_3d_buffer.read(np.uint32)), sh=_digest(t.pointCloud.sh_buffer.read(np.uint32)),
+                   state={k: _digest(b.read(np.uint32)) for k, b in t.optimizer.getStateBuffers().items()})
+        t.destroy()
+        return out
+
+    a = run(2, True, True)
+    b = run(1, False, True)
+    assert len(a["sizes"]) >= 8 and a["sizes"][-1] != cfg.num_points, a["sizes"]
+    assert a == b, (a["sizes"], b["sizes"])
+    # the batched step (c4's shape, four views per step): three lanes, pipelined, resized passes vs one lane, awaited, rebuilt passes
+    c = run(2, True, True, vpr=4, lanes=3, iterations=720)
+    d = run(1, False, True, vpr=4, lanes=1, iterations=720)
+    assert len(c["sizes"]) >= 3 and c == d, (c["sizes"], d["sizes"])
