@@ -163,6 +163,28 @@ class TorchExchange(Exchange):
     def _idle(self) -> bool:
         return self.world_size <= 1 and not self.force
 
+    # The collectives run in place -- rank r's output is slice r of the input, NCCL's in-place layout -- so a step moves no byte it
+    # does not have to.  Should a c10d build refuse aliased arguments, the exchange falls back, once and loudly, to a staging tensor
+    # (the same values; one extra device copy of the slice).
+    _in_place = True
+
+    def _out_of_place(self, error: Exception) -> None:
+        import sys
+        print(f"[webdgs_amd.parallel] in-place collective refused ({error}); staging through a scratch tensor from now on", file=sys.stderr, flush=True)
+        self._in_place = False
+
+    def _reduce_scatter(self, t: torch.Tensor, count: int) -> None:
+        mine = t[self.rank * count:(self.rank + 1) * count]
+        if self._in_place:
+            try:
+                dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM, group=self.group)
+                return
+            except RuntimeError as e:
+                self._out_of_place(e)
+        out = torch.empty_like(mine)
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group)
+        mine.copy_(out)
+
     def _pre(self):
         if self.fenced:
             self.device.torch_stream.synchronize()
@@ -180,8 +202,8 @@ class TorchExchange(Exchange):
         f = self._t(flag_ptr, 1, torch.int32)
         self._pre()
         if self.backend == "nccl":
-            dist.reduce_scatter_tensor(g[r * slice_pts * GRAD_FLOATS:(r + 1) * slice_pts * GRAD_FLOATS], g, op=dist.ReduceOp.SUM, group=self.group)
-            dist.reduce_scatter_tensor(v[r * slice_pts:(r + 1) * slice_pts], v, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce_scatter(g, slice_pts * GRAD_FLOATS)
+            self._reduce_scatter(v, slice_pts)
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
@@ -196,7 +218,13 @@ class TorchExchange(Exchange):
         mine = t[r * slice_pts * 8:(r + 1) * slice_pts * 8]
         self._pre()
         if self.backend == "nccl":
-            dist.all_gather_into_tensor(t, mine, group=self.group)
+            if self._in_place:
+                try:
+                    dist.all_gather_into_tensor(t, mine, group=self.group)
+                except RuntimeError as e:
+                    self._out_of_place(e)
+            if not self._in_place:
+                dist.all_gather_into_tensor(t, mine.clone(), group=self.group)
         else:
             dist.all_gather([t[i * slice_pts * 8:(i + 1) * slice_pts * 8] for i in range(w)], mine.clone(), group=self.group)
         self._post()
