@@ -10,13 +10,14 @@
 //     into 3 KB of wave-private LDS; no workgroup barrier exists, so a block with few contributors never waits for a
 //     neighbour with many;
 //   * the 9 per-pixel contributions are summed across the wave in registers by a halving butterfly
-//     (v_permlane32_swap, v_permlane16_swap, DPP row reduce: 28 VALU ops for all nine sums instead of 9 full reductions)
+//     (v_permlane32_swap, v_permlane16_swap, DPP quad sums, one merged row rotation: 22 VALU ops for all nine sums instead of 9 full reductions)
 //     and land in twelve lanes (eight slots, and blue as one partial sum per 16-lane row) that issue ONE atomic instruction per
 //     (wave, splat) on twelve consecutive words -- instead of 9 per (pixel, splat);
 //   * a tile's four waves share a workgroup (one CU, one XCD), so its entries and splats come from that XCD's L2 (raster.hip).
 // The contributions keep the reference's semantics exactly: each is truncated to i32 at x1e6 per pixel
 // (common.wgsl:113-116) and integer addition is order-free, so the result is bit-reproducible and equal to the oracle's.
-// Bound: fp32 VALU issue (exp, one IEEE division, about 45 further lane-ops per contributing pair).
+// Bound: fp32 VALU issue -- about 129 wave-instructions per (wave, splat) with a contributing pixel: the pinned exp (14), one division (8),
+// the per-pixel gradient arithmetic (about 55), the reduction (22) and the bookkeeping around them; DESIGN.md section 4 has the counters.
 #include "common.h"
 #include "dmath.h"
 #include "blockcull.h"
