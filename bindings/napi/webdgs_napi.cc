@@ -529,6 +529,9 @@ static napi_value commDestroy(napi_env env, napi_callback_info info) { ARGS(1); 
 
 // ---- additions of round 2: recording abort, pinned read-back, scanner / sorter, optimizer guard, sliced data-parallel exchange ------
 static napi_value encoderAbort(napi_env env, napi_callback_info info) { ARGS(1); WDGS_OK_OR_THROW(wdgs_encoder_abort((wdgs_device*)get_ptr(env, argv[0]))); return js_undefined(env); }
+// resize instead of rebuild (include/webdgs.h: wdgs_tiled_forward_resize / wdgs_tiled_backward_resize): (passHandle, numPoints)
+static napi_value tiledForwardResize(napi_env env, napi_callback_info info) { ARGS(2); WDGS_OK_OR_THROW(wdgs_tiled_forward_resize((wdgs_tiled_forward*)get_ptr(env, argv[0]), get_u32(env, argv[1]))); return js_undefined(env); }
+static napi_value tiledBackwardResize(napi_env env, napi_callback_info info) { ARGS(2); WDGS_OK_OR_THROW(wdgs_tiled_backward_resize((wdgs_tiled_backward*)get_ptr(env, argv[0]), get_u32(env, argv[1]))); return js_undefined(env); }
 // tickets (include/webdgs.h: wdgs_queue_mark / wdgs_queue_wait): the ticket travels as a double (exact below 2^53)
 static napi_value queueMark(napi_env env, napi_callback_info info) {
     ARGS(1);
@@ -687,7 +690,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(commUniqueId); EXPORT_FN(commCreate); EXPORT_FN(commAllreduceGradients); EXPORT_FN(commAllreduceCounts); EXPORT_FN(commDestroy);
     EXPORT_FN(encoderAbort); EXPORT_FN(hostAlloc); EXPORT_FN(bufferReadAsync); EXPORT_FN(prefixScanner); EXPORT_FN(dynamicSorter);
     EXPORT_FN(optimizerSetGuard); EXPORT_FN(optimizerStepF32Range); EXPORT_FN(optimizerStateChanged); EXPORT_FN(storeGradients); EXPORT_FN(guardAccumulate);
-    EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder); EXPORT_FN(queueMark); EXPORT_FN(queueWait);
+    EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder); EXPORT_FN(queueMark); EXPORT_FN(queueWait); EXPORT_FN(tiledForwardResize); EXPORT_FN(tiledBackwardResize);
     EXPORT_FN(applyRepackedRows); EXPORT_FN(commExchangeGradients); EXPORT_FN(commAllgatherRows); EXPORT_FN(commBroadcast); EXPORT_FN(commInfo);
     return exports;
 }

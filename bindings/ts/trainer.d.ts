@@ -11,7 +11,7 @@ export interface TrainingImage { texture: HipBuffer; width: number; height: numb
 export interface PointCloudSwapRequest { pointCloud: PointCloud; optimizerInitialState?: OptimizerInitialState; }
 
 export class Trainer {
-  constructor(device: HipDevice, trainingConfig?: TrainingConfig, options?: { random?: () => number; useCommandBuffers?: boolean; maxTileEntries?: number });
+  constructor(device: HipDevice, trainingConfig?: TrainingConfig, options?: { random?: () => number; useCommandBuffers?: boolean; maxTileEntries?: number; reusePasses?: boolean });
   random: () => number;
   setPointCloud(pointCloud: PointCloud): void;
   requestPointCloudSwap(pointCloud: PointCloud, optimizerInitialState?: OptimizerInitialState): void;

@@ -85,6 +85,7 @@ class Trainer {
     this.random = (options && options.random) || Math.random;
     this.useCommandBuffers = !(options && options.useCommandBuffers === false);
     this.maxTileEntries = (options && options.maxTileEntries) || 0;
+    this.reusePasses = !(options && options.reusePasses === false);   // applyPointCloudSwap resizes the passes instead of rebuilding them
     this.forwardPass = null; this.rasterizer = null; this.backwardPass = null; this.optimizer = null; this.pointCloud = null;
     this.metricsForwardPass = null; this.metricsRasterizer = null; this.metricsPass = null;
     this.metricsViewportWidth = 0; this.metricsViewportHeight = 0; this.metricsTarget = null;
@@ -115,12 +116,19 @@ class Trainer {
     this.device.synchronize();
     const oldParams = this.optimizer ? this.optimizer.getHyperparameters() : null;
     this.invalidateCommandBuffers();
-    for (const name of ['forwardPass', 'rasterizer', 'backwardPass', 'metricsForwardPass', 'metricsRasterizer', 'metricsPass', 'optimizer']) {
-      if (this[name]) this[name].destroy();
-      this[name] = null;
-    }
+    if (this.optimizer) { this.optimizer.destroy(); this.optimizer = null; }
     const old = this.pointCloud;
     this.pointCloud = request.pointCloud;
+    // The reference destroys every pass and constructs new ones; the passes here can follow a cloud of another size
+    // (setPointCloud: buffers reused, or re-allocated with headroom), so only the optimizer -- which adopts the rebuilt state -- is new.
+    const passes = [this.forwardPass, this.backwardPass, this.metricsForwardPass, this.metricsPass].filter((p) => p);
+    const kept = this.reusePasses && old && !this.recreateBackward && passes.every((p) => p.setPointCloud(this.pointCloud));
+    if (!kept) {
+      for (const name of ['forwardPass', 'rasterizer', 'backwardPass', 'metricsForwardPass', 'metricsRasterizer', 'metricsPass']) {
+        if (this[name]) this[name].destroy();
+        this[name] = null;
+      }
+    }
     this.optimizer = new hip.Optimizer(this.device, this.pointCloud, oldParams || this.optimizerHyperparameters, request.optimizerInitialState);
     this.optimizerHyperparameters = this.optimizer.getHyperparameters();
     if (old && old !== this.pointCloud) { old.gaussian_3d_buffer.destroy(); old.sh_buffer.destroy(); }

@@ -69,6 +69,8 @@ export class TiledForwardPass {
   readonly nativeHandle: bigint;
   encode(encoder: HipEncoder | null, options?: { skipSort?: boolean }): void;
   setCameraBuffer(buffer: HipBuffer): void;
+  /** Resize instead of rebuild (include/webdgs.h wdgs_tiled_forward_resize); false if the SH degree differs. */
+  setPointCloud(pointCloud: PointCloud): boolean;
   setRenderMode(mode: RenderMode): void; setPointSize(value: number): void; setGaussianScale(value: number): void; setViewport(width: number, height: number): void;
   getResources(): TiledForwardResources;
   getSortedIndicesBuffer(): HipBuffer; getSortedKeysBuffer(): HipBuffer; getTileOffsetsBuffer(): HipBuffer; getStatsBuffer(): HipBuffer;
@@ -94,6 +96,8 @@ export class TiledBackwardPass {
   computeMetricCounts(encoder: HipEncoder | null, resources: TiledBackwardResources, options?: { clear?: boolean; numInstances?: number }): void;
   normalizeMetricCounts(encoder: HipEncoder | null, options: { divisor: number }): void;
   setViewport(width: number, height: number): void;
+  /** Resize instead of rebuild (include/webdgs.h wdgs_tiled_backward_resize); false if the SH degree differs. */
+  setPointCloud(pointCloud: PointCloud): boolean;
   getGradientsBuffer(): HipBuffer; getMetricCountsBuffer(): HipBuffer; getLossTextureView(): HipBuffer; getMetricMapTextureView(): HipBuffer;
   destroy(): void;
 }

@@ -133,6 +133,11 @@ class TiledForwardPass {                 // tiled-forward-pass.ts:62
     addon.tiledForwardEncode(this.handle, this.pointCloud.gaussian_3d_buffer.ptr, this.pointCloud.sh_buffer.ptr, this.cameraBuffer.ptr, options && options.skipSort ? 1 : 0);
   }
   setCameraBuffer(buffer) { this.cameraBuffer = buffer; }
+  /** Adopts a point cloud of another size (wdgs_tiled_forward_resize) instead of destroy + construct; false if the SH degree differs. */
+  setPointCloud(pointCloud) {
+    if ((pointCloud.sh_deg || 0) !== (this.pointCloud.sh_deg || 0)) return false;
+    addon.tiledForwardResize(this.handle, pointCloud.num_points); this.pointCloud = pointCloud; return true;
+  }
   setRenderMode(mode) { addon.tiledForwardSet(this.handle, 0, mode === 'gaussian' ? 1 : 0); }
   setPointSize(value) { addon.tiledForwardSet(this.handle, 1, value); }
   setGaussianScale(value) { addon.tiledForwardSet(this.handle, 2, value); }
@@ -180,6 +185,11 @@ class TiledBackwardPass {                // tiled-backward-pass.ts:71
   }
   encode(_encoder, predictedTexture, targetTexture, r) {
     addon.tiledBackwardEncode(this.handle, predictedTexture.ptr, targetTexture.ptr, resourcePtrs(r), this.pointCloud.gaussian_3d_buffer.ptr);
+  }
+  /** See TiledForwardPass.setPointCloud (wdgs_tiled_backward_resize). */
+  setPointCloud(pointCloud) {
+    if ((pointCloud.sh_deg || 0) !== (this.pointCloud.sh_deg || 0)) return false;
+    addon.tiledBackwardResize(this.handle, pointCloud.num_points); this.pointCloud = pointCloud; return true;
   }
   computeLossOnly(_encoder, predicted, target) { addon.tiledBackwardMetric(this.handle, 0, predicted.ptr, target.ptr, 0); }
   computeMetricMap(_encoder, predicted, target, options) { addon.tiledBackwardMetric(this.handle, 1, predicted.ptr, target.ptr, dflt(options && options.threshold, 0.5)); }
