@@ -160,13 +160,19 @@ class Trainer:
 
     def _invalidate_command_buffers(self) -> None:
         """Recorded kernels bake pointers, viewport, hyper-parameters and loss weights: any change drops the recordings."""
+        deferred = None
         if self._tickets and self.device.handle:  # steps in flight replay these recordings: wait before destroying them
             self._tickets = []
-            self.device.synchronize()
+            try:
+                self.device.synchronize()
+            except ops.CapacityError as e:  # (reported once the recordings are gone: the caller must still hear of it)
+                deferred = e
         for c in self._cmd_cache.values():
             c.destroy()
         self._cmd_cache = {}
         self._eager_steps = 0
+        if deferred is not None:
+            raise deferred
 
     def setDataset(self, cameras: list, images: list) -> None:
         """``cameras[i]`` pairs with ``images[i]`` (trainer.ts:575-577).  Accepted shapes: the reference's own --
