@@ -263,6 +263,22 @@ int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op);
 /* encode: K15 loss gradient, clear accumulators, K16 backward raster, K17 geometry backward -> GaussianGradient[N]. */
 int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev,
                                const wdgs_tiled_backward_resources* res, const void* gaussians_dev);
+/* The two halves of encode, for a batched step (views_per_rank > 1; no counterpart in the reference, whose step has one view):
+ * encode_raster = K15 + clear + K16, encode_geometry = K17.  With `into`, K17 also adds the view's gradient -- the fp16-rounded values
+ * it has just packed -- to the step's fp32 block (f32[N][14] + visibility counts, `first` stores instead of adding) and folds the
+ * forward pass's overflow word into the step's guard word: what wdgs_store_gradients / wdgs_accumulate_gradients +
+ * wdgs_guard_accumulate do in two more launches.  The sums into the block must follow the previous view's (wdgs_device_lane_order). */
+typedef struct wdgs_view_accumulate {
+    void* sums;                /* f32[N][14] */
+    void* visible;             /* u32[N] */
+    const void* tile_counts;   /* forward pass: u32[N] */
+    void* guard;               /* u32: the step's guard word */
+    const void* overflow_word; /* u32: the forward pass's overflow word (stats_buffer + 8) */
+    int first;                 /* first view of the step: store, do not add */
+} wdgs_view_accumulate;
+int wdgs_tiled_backward_encode_raster(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev,
+                                      const wdgs_tiled_backward_resources* res);
+int wdgs_tiled_backward_encode_geometry(wdgs_tiled_backward* op, const void* camera_dev, const void* gaussians_dev, const wdgs_view_accumulate* into);
 int wdgs_tiled_backward_compute_loss_only(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev);
 int wdgs_tiled_backward_compute_metric_map(wdgs_tiled_backward* op, const void* predicted_rgba8_dev, const void* target_rgba8_dev, float threshold);
 int wdgs_tiled_backward_compute_metric_counts(wdgs_tiled_backward* op, const wdgs_tiled_backward_resources* res, uint32_t num_instances, int clear);

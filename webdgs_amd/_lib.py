@@ -60,6 +60,11 @@ class TiledBackwardResources(C.Structure):
                 ("alpha_texture", C.c_void_p), ("n_contrib_texture", C.c_void_p)]
 
 
+class ViewAccumulate(C.Structure):
+    _fields_ = [("sums", C.c_void_p), ("visible", C.c_void_p), ("tile_counts", C.c_void_p), ("guard", C.c_void_p), ("overflow_word", C.c_void_p),
+                ("first", C.c_int)]
+
+
 class AdamHyperparameters(C.Structure):
     _fields_ = [("lr_pos", C.c_float), ("lr_color", C.c_float), ("lr_opacity", C.c_float), ("lr_scale", C.c_float), ("lr_rot", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float)]
@@ -179,6 +184,8 @@ SIGNATURES = {
     "wdgs_tiled_backward_resize": (_I, [_P, _U]),
     "wdgs_tiled_backward_destroy": (_I, [_P]),
     "wdgs_tiled_backward_encode": (_I, [_P, _P, _P, C.POINTER(TiledBackwardResources), _P]),
+    "wdgs_tiled_backward_encode_raster": (_I, [_P, _P, _P, C.POINTER(TiledBackwardResources)]),
+    "wdgs_tiled_backward_encode_geometry": (_I, [_P, _P, _P, C.POINTER(ViewAccumulate)]),
     "wdgs_tiled_backward_compute_loss_only": (_I, [_P, _P, _P]),
     "wdgs_tiled_backward_compute_metric_map": (_I, [_P, _P, _P, _F]),
     "wdgs_tiled_backward_compute_metric_counts": (_I, [_P, C.POINTER(TiledBackwardResources), _U, _I]),

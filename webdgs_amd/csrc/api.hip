@@ -18,6 +18,8 @@ int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdg
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*);
+int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*, void*, void*, const void*, void*,
+                                        const void*, u32);
 int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
                        const void*);
 int launch_adam_repack_f32(wdgs_device*, u32, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*,
@@ -916,19 +918,37 @@ int wdgs_tiled_backward_compute_loss_only(wdgs_tiled_backward* op, const void* p
     WDGS_REQUIRE(op && pred && targ, WDGS_E_INVALID, "wdgs_tiled_backward_compute_loss_only: null argument");
     return launch_loss_grad(op->dev, op->cfg.viewport_width, op->cfg.viewport_height, pred, targ, op->cfg.training, op->loss_image);
 }
+static int backward_encode_raster(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res) {
+    wdgs_device* d = op->dev;
+    const u32 w = op->cfg.viewport_width, h = op->cfg.viewport_height, n = op->cfg.num_points;
+    WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image));
+    WDGS_CHECK_HIP(hipMemsetAsync(op->acc, 0, (size_t)std::max(n, 1u) * 48, d->stream));  // clearBuffer x4, tiled-backward-pass.ts:624-627
+    return launch_backward_rasterize(d, op->settings, ceil_div(w, 16), ceil_div(h, 16), res->tile_offsets_buffer, res->tile_indices_buffer, res->splat_buffer,
+                                     res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc);
+}
 int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res,
                                const void* gaussians) {
     WDGS_REQUIRE(op && pred && targ && res && gaussians, WDGS_E_INVALID, "wdgs_tiled_backward_encode: null argument");
     WDGS_REQUIRE(res->splat_buffer && res->tile_offsets_buffer && res->tile_indices_buffer && res->camera_buffer && res->alpha_texture && res->n_contrib_texture,
                  WDGS_E_INVALID, "wdgs_tiled_backward_encode: incomplete resources");
-    wdgs_device* d = op->dev;
-    const u32 w = op->cfg.viewport_width, h = op->cfg.viewport_height, n = op->cfg.num_points;
-    WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image));
-    WDGS_CHECK_HIP(hipMemsetAsync(op->acc, 0, (size_t)std::max(n, 1u) * 48, d->stream));  // clearBuffer x4, tiled-backward-pass.ts:624-627
-    WDGS_TRY(launch_backward_rasterize(d, op->settings, ceil_div(w, 16), ceil_div(h, 16), res->tile_offsets_buffer, res->tile_indices_buffer, res->splat_buffer,
-                                       res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc));
-    WDGS_TRY(launch_geometry_backward(d, n, res->camera_buffer, op->settings, gaussians, op->acc, op->gradients));
-    return WDGS_OK;
+    WDGS_TRY(backward_encode_raster(op, pred, targ, res));
+    return launch_geometry_backward(op->dev, op->cfg.num_points, res->camera_buffer, op->settings, gaussians, op->acc, op->gradients);
+}
+// The two halves of wdgs_tiled_backward_encode, for a batched step: K15 + clear + K16 may run (and be recorded) on any lane at any
+// time; K17 of view k also adds the view's gradient to the step's fp32 block, which has to follow view k-1's K17.
+int wdgs_tiled_backward_encode_raster(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res) {
+    WDGS_REQUIRE(op && pred && targ && res, WDGS_E_INVALID, "wdgs_tiled_backward_encode_raster: null argument");
+    WDGS_REQUIRE(res->splat_buffer && res->tile_offsets_buffer && res->tile_indices_buffer && res->alpha_texture && res->n_contrib_texture, WDGS_E_INVALID,
+                 "wdgs_tiled_backward_encode_raster: incomplete resources");
+    return backward_encode_raster(op, pred, targ, res);
+}
+int wdgs_tiled_backward_encode_geometry(wdgs_tiled_backward* op, const void* camera, const void* gaussians, const wdgs_view_accumulate* into) {
+    WDGS_REQUIRE(op && camera && gaussians, WDGS_E_INVALID, "wdgs_tiled_backward_encode_geometry: null argument");
+    if (!into) return launch_geometry_backward(op->dev, op->cfg.num_points, camera, op->settings, gaussians, op->acc, op->gradients);
+    WDGS_REQUIRE(into->sums && into->visible && into->tile_counts && into->guard && into->overflow_word, WDGS_E_INVALID,
+                 "wdgs_tiled_backward_encode_geometry: incomplete accumulate target");
+    return launch_geometry_backward_accumulate(op->dev, op->cfg.num_points, camera, op->settings, gaussians, op->acc, op->gradients, into->sums, into->visible,
+                                               into->tile_counts, into->guard, into->overflow_word, into->first ? 1u : 2u);
 }
 int wdgs_tiled_backward_compute_metric_map(wdgs_tiled_backward* op, const void* pred, const void* targ, float threshold) {
     WDGS_REQUIRE(op && pred && targ, WDGS_E_INVALID, "wdgs_tiled_backward_compute_metric_map: null argument");

@@ -13,10 +13,25 @@ constexpr u32 ACC_STRIDE = 12;  // i32 per Gaussian: mean.xy, conic.xyz, opacity
 
 WD_DEV float from_fixed(int v) { return wd_div((float)v, 1000000.0f); }
 
+// Where a batched step wants a view's gradient: the fp32 block the views of the step are summed in (parallel.py), its visibility counts
+// and its guard word.  mode 1 stores (the first view of the step: no clearing pass), mode 2 adds.
+struct ViewAccumulate {
+    float* sums;              // f32[N][14]
+    u32* visible;             // u32[N]
+    const u32* tile_counts;   // the forward pass's tile count of each Gaussian: 0 = not in this view
+    u32* guard;               // guard word of the step
+    const u32* overflow;      // the forward pass's overflow word of this view
+    u32 mode;
+};
+
+// ACC: the view's gradient also goes into the step's fp32 block -- the values that accumulate_gradients / store_gradients
+// (optimizer.hip) would read back from the packed fp16 gradient, taken from the registers that were just packed.
+template <bool ACC>
 __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
                                                                  const u32* __restrict__ gaussians, const int* __restrict__ acc,
-                                                                 u32* __restrict__ gradients) {
+                                                                 u32* __restrict__ gradients, ViewAccumulate va) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ACC && idx == 0u) *va.guard = (va.mode == 1u ? 0u : *va.guard) | (*va.overflow != 0u ? 1u : 0u);  // guard_accumulate (optimizer.hip)
     if (idx >= n) return;
     const int4* ap = reinterpret_cast<const int4*>(acc + (size_t)idx * ACC_STRIDE);
     const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
@@ -154,14 +169,44 @@ __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const flo
     uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
     op[0] = o0;
     op[1] = o1;
+    if (ACC) {
+        const bool vis = va.tile_counts[idx] != 0u;
+        float* a = va.sums + (size_t)idx * 14;  // 56-byte rows: 8-byte aligned
+        float2* a2p = reinterpret_cast<float2*>(a);
+        // the fp16-rounded values, in the block's order: pos.xyz, opacity, rot.wxyz, scale.xyz, colour.rgb
+        const float g[14] = {wd_unpack_lo(o0.x), wd_unpack_hi(o0.x), wd_unpack_lo(o0.y), wd_unpack_hi(o0.y), wd_unpack_lo(o0.z), wd_unpack_hi(o0.z), wd_unpack_lo(o0.w),
+                             wd_unpack_hi(o0.w), wd_unpack_lo(o1.x), wd_unpack_hi(o1.x), wd_unpack_lo(o1.y), wd_unpack_lo(o1.z), wd_unpack_hi(o1.z), wd_unpack_lo(o1.w)};
+        if (va.mode == 1u) {
+#pragma unroll
+            for (u32 k = 0; k < 7u; k++) a2p[k] = vis ? make_float2(g[2 * k], g[2 * k + 1]) : make_float2(0.f, 0.f);
+            va.visible[idx] = vis ? 1u : 0u;
+        } else if (vis) {
+#pragma unroll
+            for (u32 k = 0; k < 7u; k++) {
+                const float2 s = a2p[k];
+                a2p[k] = make_float2(s.x + g[2 * k], s.y + g[2 * k + 1]);
+            }
+            va.visible[idx] += 1u;
+        }
+    }
 }
 
 }  // namespace
 
 int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc, void* gradients) {
     if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st, (const u32*)gaussians,
-                (const int*)acc, (u32*)gradients);
+    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<false>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st, (const u32*)gaussians,
+                (const int*)acc, (u32*)gradients, ViewAccumulate{});
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_geometry_backward_accumulate(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc,
+                                        void* gradients, void* sums, void* visible, const void* tile_counts, void* guard, const void* overflow, u32 mode) {
+    // (n == 0 still runs one workgroup: the guard word must be written)
+    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<true>, dim3(std::max(ceil_div(n, 256), 1u)), dim3(256), 0, n, (const float*)camera, st,
+                (const u32*)gaussians, (const int*)acc, (u32*)gradients,
+                (ViewAccumulate{(float*)sums, (u32*)visible, (const u32*)tile_counts, (u32*)guard, (const u32*)overflow, mode}));
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

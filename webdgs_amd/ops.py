@@ -489,6 +489,21 @@ class TiledBackwardPass:
         r = self._resources(forwardResources)
         check(self.device.lib.wdgs_tiled_backward_encode(self.handle, predictedTexture.ptr, targetTexture.ptr, C.byref(r), self.pointCloud.gaussian_3d_buffer.ptr))
 
+    def encodeRaster(self, encoder: Optional[HipEncoder], predictedTexture: HipBuffer, targetTexture: HipBuffer, forwardResources: dict) -> None:
+        """First half of ``encode`` (K15 loss gradient, clear, K16 backward raster): ``wdgs_tiled_backward_encode_raster``."""
+        r = self._resources(forwardResources)
+        check(self.device.lib.wdgs_tiled_backward_encode_raster(self.handle, predictedTexture.ptr, targetTexture.ptr, C.byref(r)))
+
+    def encodeGeometry(self, encoder: Optional[HipEncoder], cameraBuffer: HipBuffer, accumulate: Optional[dict] = None) -> None:
+        """Second half of ``encode`` (K17).  ``accumulate`` (a batched step): ``dict(sums, visible, tileCounts, guard, stats, first)`` --
+        K17 then also adds this view's gradient to the step's fp32 block and folds the forward pass's overflow word (``stats`` + 8
+        bytes) into the guard word, instead of ``storeGradients`` / ``accumulateGradients`` + ``guardAccumulate`` afterwards."""
+        into = None
+        if accumulate is not None:
+            a = accumulate
+            into = C.byref(_lib.ViewAccumulate(a["sums"].ptr, a["visible"].ptr, a["tileCounts"].ptr, a["guard"].ptr, a["stats"].ptr + 8, 1 if a["first"] else 0))
+        check(self.device.lib.wdgs_tiled_backward_encode_geometry(self.handle, cameraBuffer.ptr, self.pointCloud.gaussian_3d_buffer.ptr, into))
+
     def computeLossOnly(self, encoder, predictedTexture: HipBuffer, targetTexture: HipBuffer) -> None:
         check(self.device.lib.wdgs_tiled_backward_compute_loss_only(self.handle, predictedTexture.ptr, targetTexture.ptr))
 

@@ -337,7 +337,7 @@ class Trainer:
     def _ops_of(self, op_set: int) -> tuple:
         return tuple(self._more_op_sets[op_set - 1]) if op_set > 0 else (self.forwardPass, self.rasterizer, self.backwardPass)
 
-    def _encode_view(self, encoder, index: int, op_set: int = 0) -> None:
+    def _encode_view(self, encoder, index: int, op_set: int = 0, geometry: bool = True) -> None:
         forwardPass, rasterizer, backwardPass = self._ops_of(op_set)
         image = self.images[index]
         cam = self._camera_buffers[index]  # camera.set_preset + update_buffer (trainer.ts:583-586): the view's resident block
@@ -347,7 +347,10 @@ class Trainer:
         res = dict(splatBuffer=forwardPass.getResources()["splatBuffer"], tileOffsetsBuffer=rasterizer.getTileOffsetsBuffer(),
                    tileIndicesBuffer=forwardPass.getSortedIndicesBuffer(), cameraBuffer=cam,
                    alphaTexture=rasterizer.getAlphaTextureView(), nContribTexture=rasterizer.getNContribTextureView())
-        backwardPass.encode(encoder, rasterizer.getOutputTextureView(), image["texture"], res)
+        if geometry:
+            backwardPass.encode(encoder, rasterizer.getOutputTextureView(), image["texture"], res)
+        else:  # a batched step: K17 follows separately, in view order, and adds to the step's fp32 block (_step_batched)
+            backwardPass.encodeRaster(encoder, rasterizer.getOutputTextureView(), image["texture"], res)
 
     def warmupCommandBuffers(self) -> int:
         """Records every view's command buffers up front (the first pass over a dataset does this anyway; calling it before a timed
@@ -445,8 +448,8 @@ class Trainer:
 
     def _step_batched(self, mine: list) -> None:
         """[views -> fp32 block] -> exchange -> [Adam on the owned slice] -> all-gather -> [apply the other ranks' rows].  One
-        recorded command buffer per (view, op set) plus one each for Adam and apply, whatever the batch's composition; the sums into
-        the fp32 block are two small eager launches per view, ordered across the lanes."""
+        recorded command buffer per (view, op set) -- K1..K16 -- plus one each for Adam and apply, whatever the batch's composition;
+        K17 is launched eagerly per view, ordered across the lanes, and adds the view's gradient to the fp32 block itself."""
         n, w = self.pointCloud.num_points, self.world_size
         sl = parallel.slice_points(n, w)
         if self._dp_grad is None:  # (allocated before any recording is opened; sized world*slice so the collectives run in place)
@@ -469,13 +472,14 @@ class Trainer:
                 forwardPass, _, backwardPass = self._ops_of(s)
                 if lanes:
                     dev.selectLane(s)
-                self._run(("view", v, s), lambda encoder, v=v, s=s: self._encode_view(encoder, v, s))
+                self._run(("view", v, s), lambda encoder, v=v, s=s: self._encode_view(encoder, v, s, geometry=False))
                 if lanes and k > 0:
                     dev.laneOrder(s, (k - 1) % L)  # the fp32 block is filled in view order: this view's sums follow the previous view's
-                # the first view overwrites the fp32 block (no clearing pass), the others add to it
-                (ops.storeGradients if k == 0 else ops.accumulateGradients)(dev, n, backwardPass.getGradientsBuffer(), forwardPass.getResources()["tileCountsBuffer"],
-                                                                            self._dp_grad, self._dp_visible)
-                ops.guardAccumulate(dev, self._dp_flag, forwardPass.getStatsBuffer(), 8, overwrite=(k == 0))
+                # K17, outside the recording (its accumulate target depends on the view's place in the batch): the first view
+                # overwrites the fp32 block (no clearing pass), the others add to it; the guard word collects the views' overflow words
+                backwardPass.encodeGeometry(None, self._camera_buffers[v], dict(sums=self._dp_grad, visible=self._dp_visible, first=(k == 0),
+                                                                                tileCounts=forwardPass.getResources()["tileCountsBuffer"],
+                                                                                guard=self._dp_flag, stats=forwardPass.getStatsBuffer()))
         finally:
             if lanes:
                 dev.lib.wdgs_encoder_abort(dev.handle)  # (a no-op unless an encode above failed mid-recording)
