@@ -289,6 +289,51 @@ def test_dp_step_with_one_view_equals_reference_step(hip_device):
             p.destroy()
 
 
+def test_geometry_backward_that_accumulates_equals_the_separate_launches(hip_device):
+    """A batched step's K17 (encodeRaster + encodeGeometry(accumulate=...)) adds the view's gradient to the step's fp32 block and folds the
+    overflow word into the guard itself.  Three views from three cameras, an overflowing one among them: block, visibility counts,
+    guard word and the packed gradients must equal encode + storeGradients / accumulateGradients + guardAccumulate bit for bit."""
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=8000, width=160, height=120)
+    g, sh, _ = harness.scene(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    cams = synth.circle_cameras(cfg, 3)
+    n = cfg.num_points
+    results = []
+    for fused in (False, True):
+        sums, vis, guard = dev.createBuffer(4 * 14 * n), dev.createBuffer(4 * n), dev.createBuffer(16)
+        guard.write(np.array([7, 0, 0, 0], np.uint32))  # a stale word: the first view must overwrite it
+        grads = []
+        for k, cam in enumerate(cams):
+            tp = harness.HipPipeline(dev, cfg, tg, tsh, cam)
+            tp.forward()
+            target = dev.bufferFrom(tp.rast.getOutputTextureView().read(np.uint8))
+            tp.destroy()
+            p = harness.HipPipeline(dev, cfg, g, sh, cam, max_tile_entries=4096 if k == 1 else 0)  # view 1 overflows its tile list
+            try:
+                p.fwd.encode(None); p.rast.encode(None, cfg.width, cfg.height)
+                res, stats, counts = p.backward_resources(), p.fwd.getStatsBuffer(), p.fwd.getResources()["tileCountsBuffer"]
+                if fused:
+                    p.bwd.encodeRaster(None, p.rast.getOutputTextureView(), target, res)
+                    p.bwd.encodeGeometry(None, p.camera, dict(sums=sums, visible=vis, tileCounts=counts, guard=guard, stats=stats, first=(k == 0)))
+                else:
+                    p.bwd.encode(None, p.rast.getOutputTextureView(), target, res)
+                    (ops.storeGradients if k == 0 else ops.accumulateGradients)(dev, n, p.bwd.getGradientsBuffer(), counts, sums, vis)
+                    ops.guardAccumulate(dev, guard, stats, 8, overwrite=(k == 0))
+                try:
+                    dev.synchronize()
+                except _lib.CapacityError:
+                    assert k == 1
+                grads.append(p.bwd.getGradientsBuffer().read(np.uint32))
+            finally:
+                p.destroy()
+        results.append(dict(sums=sums.read(np.uint32), vis=vis.read(np.uint32), guard=guard.read(np.uint32, count=1), grads=np.stack(grads)))
+    a, b = results
+    assert int(a["guard"][0]) == 1 and a["vis"].max() == 3 and a["sums"].any()
+    for k in a:
+        assert_bits_equal(a[k], b[k], f"fused K17 vs separate launches: {k}")
+
+
 def test_resized_passes_behave_like_fresh_ones(hip_device):
     """wdgs_tiled_forward_resize / wdgs_tiled_backward_resize (what applyPointCloudSwap uses instead of destroy + construct): a pass
     taken from 5 000 to 9 000 Gaussians (re-allocates, with headroom), on to 9 700 (fits the headroom) and down to 3 000 (fits) must
