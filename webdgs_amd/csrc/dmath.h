@@ -121,8 +121,12 @@ WD_DEV float wd_div_inrange(float a, float b) {
     r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
     float q = a * r;
     q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
-    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
-    return q;
+    const float e = __builtin_fmaf(-b, q, a);
+    // the last fused multiply-add as a three-address instruction: left to itself the compiler emits a destructive v_fmac_f32 on q and,
+    // when the quotient replaces the dividend in a loop-carried register (T = T / x), a v_mov_b32 to get it there
+    float out;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(out) : "v"(e), "v"(r), "v"(q));
+    return out;
 }
 // WGSL min/max: min(e1,e2) = e2 if e2 < e1 else e1; max(e1,e2) = e2 if e1 < e2 else e1 (pins +-0 ties and NaN).
 WD_DEV float wd_min(float a, float b) { return (b < a) ? b : a; }
