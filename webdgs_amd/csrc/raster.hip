@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings,
                 const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;
                 if (GAUSSIAN_MODE) {
                     const bool active = ((int)inside & (int)!(A > 0.99f)) != 0;
-                    if (!__any(active)) continue;
+                    // (no wave-wide "nobody is active" early-out: after the compaction nearly every splat has an active pixel, and the
+                    // test cost two VALU operations per iteration; an iteration without one falls through the empty exec mask below)
                     const float4 con = s_con[i];
                     const float4 col = s_col[i];
                     u32 entry_pos = __float_as_uint(col.w);
