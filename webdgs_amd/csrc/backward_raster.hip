@@ -177,14 +177,10 @@ __global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettin
             // indefinite conic after fp16 rounding -- sends the whole wave through the full form; arguments below -80 are clamped, which
             // only changes G on lanes whose alpha is far below 1/255 either way, and G is not used on those.
             const float xe = -0.5f * power;
-            float G;
-            if (__builtin_expect(__any(!(xe <= 87.0f)), 0)) {
-                G = wd_exp(xe);
-            } else {
-                float xc;  // max(xe, -80): one v_max_f32 (fmaxf would first quiet a NaN that cannot occur on this path)
-                asm("v_max_f32 %0, 0xc2a00000, %1" : "=v"(xc) : "v"(xe));  // 0xc2a00000 = -80.0f
-                G = wd_exp_inrange(xc);
-            }
+            float xc;  // max(xe, -80): one v_max_f32 (fmaxf would first quiet a NaN, which the test below sends to the full form)
+            asm("v_max_f32 %0, 0xc2a00000, %1" : "=v"(xc) : "v"(xe));  // 0xc2a00000 = -80.0f
+            float G = wd_exp_inrange(xc);
+            if (__builtin_expect(__any(!(xe <= 87.0f)), 0)) G = wd_exp(xe);
             const float og = con.w * G;
             const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
             const bool act = cand && !(alpha < (1.0f / 255.0f));

@@ -123,14 +123,10 @@ __global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings,
                         // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G in [0, inf]), so the hardware min/max equal
                         // WGSL's select-based clamp, and with a finite G the lower clamp is the identity and is left out.
                         const float xe = -0.5f * q;
-                        float alpha;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(xe <= 87.0f)) != 0ull, 0)) {
-                            alpha = fminf(fmaxf(wd_exp(xe) * con.w, 0.0f), 0.99f);
-                        } else {
-                            float xc;  // max(xe, -86): one v_max_f32 (fmaxf would first quiet a NaN that cannot occur on this path)
-                            asm("v_max_f32 %0, 0xc2ac0000, %1" : "=v"(xc) : "v"(xe));  // 0xc2ac0000 = -86.0f
-                            alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
-                        }
+                        float xc;  // max(xe, -86): one v_max_f32 (fmaxf would first quiet a NaN, which the test below sends to the full form)
+                        asm("v_max_f32 %0, 0xc2ac0000, %1" : "=v"(xc) : "v"(xe));  // 0xc2ac0000 = -86.0f
+                        float alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(xe <= 87.0f)) != 0ull, 0)) alpha = fminf(fmaxf(wd_exp(xe) * con.w, 0.0f), 0.99f);
                         const float w = alpha * (1.0f - A);
                         cr = __builtin_fmaf(col.x, w, cr);
                         cg = __builtin_fmaf(col.y, w, cg);
