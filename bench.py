@@ -52,6 +52,8 @@ def algorithmic_bytes(kernel: str, n: int, v: int, e: int, p: int, t: int, k_coe
         "backward_rasterize": 4 * e + 24 * v + 24 * p + 40 * v,
         "geometry_backward": 96 * n,
         "adam_repack": 4 * n + 416 * v + 100 * n,
+        # K17 + K18 + K19 in one pass (single-view step): the packed gradient is written (32 N) but not read back
+        "geometry_backward_adam": 96 * n + 4 * n + 416 * v + 100 * n - 32 * n,
     }
     return float(table.get(kernel, 0))
 
@@ -268,7 +270,7 @@ def main() -> None:
         gname = kernel_group(name)
         gl, gms = groups.get(gname, (0, 0.0))
         groups[gname] = (gl + launches, gms + ms)
-    per_view_kernels = ("project_count", "scan", "emit", "sort", "tile_ranges", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward",
+    per_view_kernels = ("project_count", "scan", "emit", "sort", "tile_ranges", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward", "geometry_backward_adam",
                         "store_gradients", "accumulate_gradients", "guard_accumulate")
     per_step = {k: v[1] / max(1, args.steps) / (vpr if k in per_view_kernels else 1) for k, v in groups.items()}
     dom = max(per_step, key=per_step.get) if per_step else None

@@ -330,6 +330,11 @@ int wdgs_optimizer_destroy(wdgs_optimizer* op);
 int wdgs_optimizer_init_from_point_cloud(wdgs_optimizer* op, const void* gaussians_dev, const void* sh_dev);
 /* step(encoder, pointCloud, gradientsBuffer, tileCountsBuffer): iteration++, K18 Adam, K19 re-pack into gaussians/sh. */
 int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, const void* gradients_dev, const void* tile_counts_dev);
+/* The same step fused with K17: after wdgs_tiled_backward_encode_raster(bwd, ...) for the view, one pass over the Gaussians computes the
+ * geometry backward (the packed gradient is still written to bwd's gradient buffer), then Adam and the re-pack of the same Gaussian from
+ * the fp16-rounded values in registers -- optimizer.step() of trainer.ts:635 without a second pass over N and a read-back of the gradient. */
+int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera_dev, void* gaussians_dev, void* sh_dev,
+                                      const void* tile_counts_dev);
 /* Data-parallel variant: gradients are fp32 sums over views, 14 f32 per Gaussian in GaussianGradient
  * component order {pos3, opacity, rot4, logsigma3, rgb3}, plus u32 visibility counts (Adam runs where count > 0). */
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, const void* grad_f32_dev, const void* visible_counts_dev);

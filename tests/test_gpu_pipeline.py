@@ -105,7 +105,7 @@ def test_kernel_times_are_collected_by_ticket_waits(hip_device, depth):
     dev.setProfiling(False)
     times = dev.kernelTimes(reset=True)
     t.destroy()
-    for name in ("project_count", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward", "adam_repack"):
+    for name in ("project_count", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward_adam"):
         assert name in times and times[name][0] == 5 and times[name][1] > 0.0, (name, times.get(name))
 
 

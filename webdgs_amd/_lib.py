@@ -205,6 +205,7 @@ SIGNATURES = {
     "wdgs_optimizer_destroy": (_I, [_P]),
     "wdgs_optimizer_init_from_point_cloud": (_I, [_P, _P, _P]),
     "wdgs_optimizer_step": (_I, [_P, _P, _P, _P, _P]),
+    "wdgs_optimizer_step_with_geometry": (_I, [_P, _P, _P, _P, _P, _P]),
     "wdgs_optimizer_step_f32": (_I, [_P, _P, _P, _P, _P]),
     "wdgs_accumulate_gradients": (_I, [_P, _U, _P, _P, _P, _P]),
     "wdgs_store_gradients": (_I, [_P, _U, _P, _P, _P, _P]),

@@ -1,0 +1,103 @@
+// Adam on one Gaussian (K18) and its fp16 re-pack (K19): shared by optimizer.hip and by the kernel that runs them straight after the geometry
+// backward of the same Gaussian (backward.hip).  See optimizer.hip for the layout notes.
+#pragma once
+#include "common.h"
+#include "wgslm.h"
+
+struct Adam3 { float p, m, v; };
+WD_DEV Adam3 adam_step(const wdgs_adam_hyperparameters& h, float param, float grad, float m, float v, float lr) {
+    const float m_new = h.beta1 * m + (1.0f - h.beta1) * grad;
+    const float v_new = h.beta2 * v + (1.0f - h.beta2) * grad * grad;
+    const float step = wd_div(-lr * m_new, wd_sqrt(v_new) + h.epsilon);
+    return Adam3{param + step, m_new, v_new};
+}
+
+struct Grad14 { float pos[3], opac, rot[4], scale[3], color[3]; };
+
+WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
+    const uint4* gp = reinterpret_cast<const uint4*>(gradients + (size_t)idx * 8);
+    const uint4 a = gp[0], b = gp[1];
+    Grad14 g;
+    g.pos[0] = wd_unpack_lo(a.x); g.pos[1] = wd_unpack_hi(a.x); g.pos[2] = wd_unpack_lo(a.y); g.opac = wd_unpack_hi(a.y);
+    g.rot[0] = wd_unpack_lo(a.z); g.rot[1] = wd_unpack_hi(a.z); g.rot[2] = wd_unpack_lo(a.w); g.rot[3] = wd_unpack_hi(a.w);
+    g.scale[0] = wd_unpack_lo(b.x); g.scale[1] = wd_unpack_hi(b.x); g.scale[2] = wd_unpack_lo(b.y);
+    g.color[0] = wd_unpack_lo(b.z); g.color[1] = wd_unpack_hi(b.z); g.color[2] = wd_unpack_lo(b.w);
+    return g;
+}
+
+// Adam on one Gaussian's 14 trained scalars (SH: DC only) followed by the fp16 re-pack of that Gaussian.
+// rows_out (nullable): the re-packed row -- 6 Gaussian words, SH word 0, low half of SH word 1 -- also goes to rows_out[idx*8 ..],
+// the 32-byte form in which a data-parallel rank publishes the Gaussians it owns (wdgs_comm_allgather_rows).
+WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_pos,
+                            float4* __restrict__ opt_rot, float4* __restrict__ opt_scale, float* __restrict__ opt_opacity,
+                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ rows_out = nullptr) {
+    float4 P = opt_pos[(size_t)idx * 3];
+    float4 R = opt_rot[(size_t)idx * 3];
+    float4 S = opt_scale[(size_t)idx * 3];
+    float op = opt_opacity[(size_t)idx * 3];
+    float* d = dc + (size_t)idx * 9;
+    float c0 = d[0], c1 = d[1], c2 = d[2];
+    if (update) {
+        {
+            const float4 m = opt_pos[(size_t)idx * 3 + 1], v = opt_pos[(size_t)idx * 3 + 2];
+            const Adam3 rx = adam_step(h, P.x, g.pos[0], m.x, v.x, h.lr_pos), ry = adam_step(h, P.y, g.pos[1], m.y, v.y, h.lr_pos),
+                        rz = adam_step(h, P.z, g.pos[2], m.z, v.z, h.lr_pos);
+            P = make_float4(rx.p, ry.p, rz.p, 1.0f);
+            opt_pos[(size_t)idx * 3] = P;
+            opt_pos[(size_t)idx * 3 + 1] = make_float4(rx.m, ry.m, rz.m, 0.0f);
+            opt_pos[(size_t)idx * 3 + 2] = make_float4(rx.v, ry.v, rz.v, 0.0f);
+        }
+        {
+            const float4 m = opt_rot[(size_t)idx * 3 + 1], v = opt_rot[(size_t)idx * 3 + 2];
+            const Adam3 rx = adam_step(h, R.x, g.rot[0], m.x, v.x, h.lr_rot), ry = adam_step(h, R.y, g.rot[1], m.y, v.y, h.lr_rot),
+                        rz = adam_step(h, R.z, g.rot[2], m.z, v.z, h.lr_rot), rw = adam_step(h, R.w, g.rot[3], m.w, v.w, h.lr_rot);
+            const vec4 nr = normalize(V4(rx.p, ry.p, rz.p, rw.p));
+            R = make_float4(nr.x, nr.y, nr.z, nr.w);
+            opt_rot[(size_t)idx * 3] = R;
+            opt_rot[(size_t)idx * 3 + 1] = make_float4(rx.m, ry.m, rz.m, rw.m);
+            opt_rot[(size_t)idx * 3 + 2] = make_float4(rx.v, ry.v, rz.v, rw.v);
+        }
+        {
+            const float4 m = opt_scale[(size_t)idx * 3 + 1], v = opt_scale[(size_t)idx * 3 + 2];
+            const Adam3 rx = adam_step(h, S.x, g.scale[0], m.x, v.x, h.lr_scale), ry = adam_step(h, S.y, g.scale[1], m.y, v.y, h.lr_scale),
+                        rz = adam_step(h, S.z, g.scale[2], m.z, v.z, h.lr_scale);
+            S = make_float4(rx.p, ry.p, rz.p, 0.0f);
+            opt_scale[(size_t)idx * 3] = S;
+            opt_scale[(size_t)idx * 3 + 1] = make_float4(rx.m, ry.m, rz.m, 0.0f);
+            opt_scale[(size_t)idx * 3 + 2] = make_float4(rx.v, ry.v, rz.v, 0.0f);
+        }
+        {
+            const Adam3 r = adam_step(h, op, g.opac, opt_opacity[(size_t)idx * 3 + 1], opt_opacity[(size_t)idx * 3 + 2], h.lr_opacity);
+            op = r.p;
+            opt_opacity[(size_t)idx * 3] = r.p;
+            opt_opacity[(size_t)idx * 3 + 1] = r.m;
+            opt_opacity[(size_t)idx * 3 + 2] = r.v;
+        }
+        {
+            const Adam3 r0 = adam_step(h, c0, g.color[0], d[3], d[6], h.lr_color), r1 = adam_step(h, c1, g.color[1], d[4], d[7], h.lr_color),
+                        r2 = adam_step(h, c2, g.color[2], d[5], d[8], h.lr_color);
+            c0 = r0.p; c1 = r1.p; c2 = r2.p;
+            d[0] = r0.p; d[1] = r1.p; d[2] = r2.p;
+            d[3] = r0.m; d[4] = r1.m; d[5] = r2.m;
+            d[6] = r0.v; d[7] = r1.v; d[8] = r2.v;
+        }
+    }
+    // re-pack (update-gaussians.wgsl:41-75): whole Gaussian, SH word 0, low half of SH word 1
+    u32* gp = gaussians + (size_t)idx * 6;
+    *reinterpret_cast<uint2*>(gp) = make_uint2(wd_pack2(P.x, P.y), wd_pack2(P.z, op));
+    *reinterpret_cast<uint2*>(gp + 2) = make_uint2(wd_pack2(R.x, R.y), wd_pack2(R.z, R.w));
+    *reinterpret_cast<uint2*>(gp + 4) = make_uint2(wd_pack2(S.x, S.y), wd_pack2(S.z, 0.0f));
+    // SH word 0 and the LOW half of word 1 (the third DC coefficient) as a 4-byte and a 2-byte store.  The reference writes
+    // pack2x16float(c2, unpack2x16float(old).y): the neighbouring coefficient survives that round trip bit for bit (only a NaN
+    // payload could change, which WGSL leaves implementation-defined), so not touching it is the same result -- without fetching
+    // the 96-byte row's cache line just to copy 2 bytes back (it was 19 % of this kernel's HBM traffic).
+    u32* shp = sh_buffer + (size_t)idx * 24;
+    const u32 sh0 = wd_pack2(c0, c1), sh1lo = wd_f16bits(c2) & 0xFFFFu;
+    shp[0] = sh0;
+    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)sh1lo;
+    if (rows_out) {
+        uint4* ro = reinterpret_cast<uint4*>(rows_out + (size_t)idx * 8);
+        ro[0] = make_uint4(wd_pack2(P.x, P.y), wd_pack2(P.z, op), wd_pack2(R.x, R.y), wd_pack2(R.z, R.w));
+        ro[1] = make_uint4(wd_pack2(S.x, S.y), wd_pack2(S.z, 0.0f), sh0, sh1lo);
+    }
+}

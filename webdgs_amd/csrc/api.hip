@@ -18,6 +18,8 @@ int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdg
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*);
+int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, const void*, void*, const wdgs_adam_hyperparameters&, const void*,
+                                  const wdgs_optimizer_state&, void*, void*, const void*);
 int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*, void*, void*, const void*, void*,
                                         const void*, u32);
 int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
@@ -1068,6 +1070,16 @@ int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const voi
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
     return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh, op->guard);
+}
+// K17 + K18 + K19 in one pass over the Gaussians (the single-view step): `bwd` must have run wdgs_tiled_backward_encode_raster for this view.
+int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera, void* gaussians, void* sh, const void* tile_counts) {
+    WDGS_REQUIRE(op && bwd && camera && gaussians && sh && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step_with_geometry: null argument");
+    WDGS_REQUIRE(bwd->cfg.num_points == op->num_points, WDGS_E_STATE, "wdgs_optimizer_step_with_geometry: the backward pass holds %u Gaussians, the optimizer %u",
+                 bwd->cfg.num_points, op->num_points);
+    op->iteration++;  // optimizer.ts:301
+    op->dc_dirty = true;
+    return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->gradients, op->params, tile_counts, op->state,
+                                         op->dc, sh, op->guard);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");

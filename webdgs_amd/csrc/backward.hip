@@ -6,6 +6,7 @@
 // kept: W = view3x3 here vs its transpose in the forward (Q10), +0.5*viewport for both NDC axes (Q11), fp16 output (Q13).
 #include "common.h"
 #include "wgslm.h"
+#include "adam.h"
 
 namespace {
 
@@ -24,12 +25,27 @@ struct ViewAccumulate {
     u32 mode;
 };
 
-// ACC: the view's gradient also goes into the step's fp32 block -- the values that accumulate_gradients / store_gradients
-// (optimizer.hip) would read back from the packed fp16 gradient, taken from the registers that were just packed.
-template <bool ACC>
+// The reference's single-view step runs Adam and the re-pack (K18 + K19) right behind K17 on the gradient K17 has just written; here the
+// same thread goes on with its Gaussian: the fp16-rounded gradient is taken from the registers that were packed, the state of the
+// Gaussian is read, updated and re-packed (adam.h) -- no second pass over N, no read-back of the gradient.
+struct ViewAdam {
+    wdgs_adam_hyperparameters h;
+    const u32* tile_counts;
+    float4 *opt_pos, *opt_rot, *opt_scale;
+    float* opt_opacity;
+    float* dc;
+    u32* gaussians;  // the same buffer K17 reads: this thread's own 24-byte row, read above, re-packed below
+    u32* sh;
+    const u32* guard;
+};
+
+// MODE 1: the view's gradient also goes into the step's fp32 block -- the values that accumulate_gradients / store_gradients
+// (optimizer.hip) would read back from the packed fp16 gradient, taken from the registers that were just packed.  MODE 2: Adam.
+template <int MODE>
 __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
-                                                                 const u32* __restrict__ gaussians, const int* __restrict__ acc,
-                                                                 u32* __restrict__ gradients, ViewAccumulate va) {
+                                                                 const u32* gaussians, const int* __restrict__ acc,
+                                                                 u32* __restrict__ gradients, ViewAccumulate va, ViewAdam ad) {
+    constexpr bool ACC = MODE == 1;
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (ACC && idx == 0u) *va.guard = (va.mode == 1u ? 0u : *va.guard) | (*va.overflow != 0u ? 1u : 0u);  // guard_accumulate (optimizer.hip)
     if (idx >= n) return;
@@ -189,14 +205,39 @@ __global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const flo
             va.visible[idx] += 1u;
         }
     }
+    if (MODE == 2) {
+        // guard: a step whose tile-entry list overflowed is skipped (optimizer.hip: adam_repack_kernel)
+        if (ad.guard && *ad.guard != 0u) return;
+        const bool update = ad.tile_counts[idx] != 0u;
+        Grad14 g = {};
+        if (update) {
+            g.pos[0] = wd_unpack_lo(o0.x); g.pos[1] = wd_unpack_hi(o0.x); g.pos[2] = wd_unpack_lo(o0.y); g.opac = wd_unpack_hi(o0.y);
+            g.rot[0] = wd_unpack_lo(o0.z); g.rot[1] = wd_unpack_hi(o0.z); g.rot[2] = wd_unpack_lo(o0.w); g.rot[3] = wd_unpack_hi(o0.w);
+            g.scale[0] = wd_unpack_lo(o1.x); g.scale[1] = wd_unpack_hi(o1.x); g.scale[2] = wd_unpack_lo(o1.y);
+            g.color[0] = wd_unpack_lo(o1.z); g.color[1] = wd_unpack_hi(o1.z); g.color[2] = wd_unpack_lo(o1.w);
+        }
+        adam_and_repack(idx, update, g, ad.h, ad.opt_pos, ad.opt_rot, ad.opt_scale, ad.opt_opacity, ad.dc, ad.gaussians, ad.sh);
+    }
 }
 
 }  // namespace
 
+int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, const void* acc, void* gradients,
+                                  const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, void* dc, void* sh,
+                                  const void* guard) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "geometry_backward_adam", geometry_backward_kernel<2>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st,
+                (const u32*)gaussians, (const int*)acc, (u32*)gradients, ViewAccumulate{},
+                (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_pos, (float4*)state.opt_rot, (float4*)state.opt_scale, (float*)state.opt_opacity,
+                          (float*)dc, (u32*)gaussians, (u32*)sh, (const u32*)guard}));
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
 int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc, void* gradients) {
     if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<false>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st, (const u32*)gaussians,
-                (const int*)acc, (u32*)gradients, ViewAccumulate{});
+    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<0>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st, (const u32*)gaussians,
+                (const int*)acc, (u32*)gradients, ViewAccumulate{}, ViewAdam{});
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
@@ -204,9 +245,9 @@ int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const 
 int launch_geometry_backward_accumulate(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc,
                                         void* gradients, void* sums, void* visible, const void* tile_counts, void* guard, const void* overflow, u32 mode) {
     // (n == 0 still runs one workgroup: the guard word must be written)
-    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<true>, dim3(std::max(ceil_div(n, 256), 1u)), dim3(256), 0, n, (const float*)camera, st,
+    WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<1>, dim3(std::max(ceil_div(n, 256), 1u)), dim3(256), 0, n, (const float*)camera, st,
                 (const u32*)gaussians, (const int*)acc, (u32*)gradients,
-                (ViewAccumulate{(float*)sums, (u32*)visible, (const u32*)tile_counts, (u32*)guard, (const u32*)overflow, mode}));
+                (ViewAccumulate{(float*)sums, (u32*)visible, (const u32*)tile_counts, (u32*)guard, (const u32*)overflow, mode}), ViewAdam{});
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

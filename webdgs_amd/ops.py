@@ -637,6 +637,12 @@ class Optimizer:
     def step(self, encoder, coefficients: PointCloud, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer) -> None:
         check(self.device.lib.wdgs_optimizer_step(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradientsBuffer.ptr, tileCountsBuffer.ptr))
 
+    def stepWithGeometry(self, encoder, coefficients: PointCloud, backwardPass: "TiledBackwardPass", cameraBuffer: HipBuffer, tileCountsBuffer: HipBuffer) -> None:
+        """``step`` fused with K17 (``wdgs_optimizer_step_with_geometry``): call after ``backwardPass.encodeRaster`` for the view.  One
+        pass over the Gaussians: geometry backward (the packed gradient still lands in the pass's gradient buffer), Adam, re-pack."""
+        check(self.device.lib.wdgs_optimizer_step_with_geometry(self.handle, backwardPass.handle, cameraBuffer.ptr, coefficients.gaussian_3d_buffer.ptr,
+                                                                coefficients.sh_buffer.ptr, tileCountsBuffer.ptr))
+
     def stepF32(self, encoder, coefficients: PointCloud, gradF32: HipBuffer, visibleCounts: HipBuffer) -> None:
         """Data-parallel step on fp32 gradients summed over views."""
         check(self.device.lib.wdgs_optimizer_step_f32(self.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradF32.ptr, visibleCounts.ptr))

@@ -62,6 +62,7 @@ class Trainer:
         # running on incomplete gradients.  Densify steps, stop() and every read-back drain the pipeline first.
         self.pipeline_depth = max(1, min(int(pipeline_depth), 4))
         self.reuse_passes = True  # applyPointCloudSwap resizes the passes instead of rebuilding them (False: the reference's teardown)
+        self.fuse_geometry_adam = True  # the single-view step runs K17, Adam and the re-pack as one kernel (False: the reference's three)
         self._tickets: list = []
         self._more_op_sets: list = []  # [forwardPass, rasterizer, backwardPass] of lanes 1.. (set 0 is the three above)
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
@@ -439,8 +440,12 @@ class Trainer:
         tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
 
         def encode(encoder):
-            self._encode_view(encoder, view)
-            self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
+            if self.fuse_geometry_adam:  # K1..K16, then K17 + Adam + re-pack in one pass over the Gaussians
+                self._encode_view(encoder, view, geometry=False)
+                self.optimizer.stepWithGeometry(encoder, self.pointCloud, self.backwardPass, self._camera_buffers[view], tileCounts)
+            else:
+                self._encode_view(encoder, view)
+                self.optimizer.step(encoder, self.pointCloud, self.backwardPass.getGradientsBuffer(), tileCounts)
         if self._run(("step", view), encode):
             self.optimizer.advanceIteration(1)
         elif not self.use_command_buffers or self._eager_steps < 1:
