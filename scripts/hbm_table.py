@@ -13,6 +13,8 @@ dur = {}
 for r in csv.DictReader(open(stats)):
     m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(<[^()]*>)?\s*\((?!anonymous)", r["Name"])
     name = (m.group(1) if m else r["Name"])
+    if name == "geometry_backward_kernel":  # the template argument selects what K17 goes on to do with its gradient
+        name = {"<1>": "geometry_backward_accumulate_kernel", "<2>": "geometry_backward_adam_kernel"}.get((m.group(2) or "") if m else "", name)
     name = name[:-len("_kernel")] if name.endswith("_kernel") else name
     if name not in dur:
         dur[name] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)

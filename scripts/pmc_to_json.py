@@ -19,7 +19,10 @@ root, out = sys.argv[1], sys.argv[2]
 vals = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+        full = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        name = full.split("<")[0]
+        if name == "geometry_backward_kernel" and "<" in full:  # the template argument selects what K17 goes on to do with its gradient
+            name = {"<1>": "geometry_backward_accumulate_kernel", "<2>": "geometry_backward_adam_kernel"}.get(full[full.index("<"):], name)
         if name.endswith("_kernel"):
             name = name[: -len("_kernel")]
         vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
