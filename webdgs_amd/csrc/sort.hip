@@ -109,11 +109,20 @@ __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ c
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                     u32* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                                     const u32* __restrict__ count_ptr, u32 shift, u32 dmask, u32 num_parts,
-                                                                    const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals) {
+                                                                    const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals,
+                                                                    u32* __restrict__ ranges, u32 ranges_mode, u32 total_tiles) {
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
     const u32 base = part * SORT_TILE;
+    // The per-tile range table of a tile-structured sort (sort_segmented) is built by the two scatter passes themselves: the first one
+    // sets every entry to "empty" (and the terminator ranges[T] = E), the second one -- whose output is in tile order -- lowers
+    // ranges[tile] to the first position it writes for that tile (below).  ranges_mode: 0 none, 1 initialise, 2 lower.
+    if (ranges_mode == 1u) {
+        const u32 active = max((count + SORT_TILE - 1u) / SORT_TILE, 1u);  // partition 0 runs even for an empty list
+        if (part < active)
+            for (u32 t = part * SORT_THREADS + threadIdx.x; t <= total_tiles; t += active * SORT_THREADS) ranges[t] = (t == total_tiles) ? count : 0xFFFFFFFFu;
+    }
     if (base >= count) return;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -219,6 +228,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         const u32 pos = s_gdelta[(key >> shift) & dmask] + e;
         keys_out[pos] = key;
         vals_out[pos] = s_vals[e];
+        // In the partition's sorted order the entries of one tile are neighbours (same digit, and the input of this pass is ordered by
+        // the tile's low bits), so a tile's first entry here is the one whose predecessor belongs to another tile: about 130 per
+        // partition.  The smallest of those positions over all partitions is where the tile starts.
+        if (ranges_mode == 2u && (e == 0u || (s_keys[e - 1u] >> 16u) != (key >> 16u))) atomicMin(&ranges[(key >> 16u) - 1u], pos);
     }
 }
 
@@ -564,12 +577,15 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
         WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, dmask, s->num_parts,
                     s->counts);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        // (two passes: the first initialises the range table, the second fills it; any other pass count keeps the search kernel)
+        const u32 ranges_mode = (passes == 2u) ? p + 1u : 0u;
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, dmask, s->num_parts, s->counts, s->totals);
+                    s->vals[src ^ 1], s->count_ptr, shift, dmask, s->num_parts, s->counts, s->totals, ranges, ranges_mode, num_segments);
         src ^= 1;
         shift += width;
     }
-    WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(num_segments + 1, 4)), dim3(256), 0, s->keys[src], s->count_ptr, num_segments, ranges);
+    if (passes != 2u)
+        WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(num_segments + 1, 4)), dim3(256), 0, s->keys[src], s->count_ptr, num_segments, ranges);
     if (num_segments > 0)
         WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(num_segments), dim3(SEG_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
                     s->vals[src ^ 1], ranges, num_segments);
@@ -592,7 +608,7 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
                     s->counts);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, RADIX - 1u, s->num_parts, s->counts, s->totals);
+                    s->vals[src ^ 1], s->count_ptr, shift, RADIX - 1u, s->num_parts, s->counts, s->totals, (u32*)nullptr, 0u, 0u);
         src ^= 1;
     }
     WDGS_CHECK_HIP(hipGetLastError());
