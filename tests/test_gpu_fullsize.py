@@ -347,3 +347,40 @@ def test_c2_long_run_is_the_same_whichever_way_it_is_driven(hip_device):
     c = run(2, True, True, vpr=4, lanes=3, iterations=720)
     d = run(1, False, True, vpr=4, lanes=1, iterations=720)
     assert len(c["sizes"]) >= 3 and c == d, (c["sizes"], d["sizes"])
+
+
+def test_c3_batched_step_on_lanes_equals_one_lane(hip_device):
+    """BASELINE c3 / c4's per-rank step at full size -- 1 M Gaussians, 1920x1080, four views per step -- where the kernels of different
+    lanes really do run side by side for hundreds of microseconds: three lanes with the pipelined submission must leave the bits of
+    one lane with every step awaited (cloud and optimizer state after 6 steps)."""
+    from webdgs_amd.trainer import Trainer
+    import bench
+    dev = hip_device
+    cfg = synth.CONFIGS["c3"]
+    g, sh = synth.make_gaussians(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    cameras, images = bench.make_dataset(dev, cfg, tg, tsh, synth.circle_cameras(cfg, 4))
+
+    def run(lanes, depth):
+        t = Trainer(dev, seed=5, views_per_rank=4, overlap_views=lanes, pipeline_depth=depth)
+        t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+        t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+        t.setDataset(cameras, images)
+        t.start()
+        t.step([0, 1, 2, 3])
+        t.warmupCommandBuffers()
+        on_lanes = 0
+        for ids in ([3, 1, 0, 2], [2, 2, 1, 0], [0, 3, 3, 1], [1, 0, 2, 3], [3, 2, 1, 0], [0, 1, 2, 3]):
+            on_lanes += int(t._op_sets > 1 and all(("view", v, k % t._op_sets) in t._cmd_cache for k, v in enumerate(ids)))
+            t.step(ids)
+        t.drain()
+        dev.synchronize()
+        out = dict(g=_digest(t.pointCloud.gaussian_3d_buffer.read(np.uint32)), sh=_digest(t.pointCloud.sh_buffer.read(np.uint32)),
+                   state={k: _digest(b.read(np.uint32)) for k, b in t.optimizer.getStateBuffers().items()})
+        t.destroy()
+        return out, on_lanes
+
+    a, lanes_a = run(3, 2)
+    b, lanes_b = run(1, 1)
+    assert lanes_a == 6 and lanes_b == 0
+    assert a == b
