@@ -66,7 +66,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
         }
     }
     __syncthreads();
-    counts[(size_t)threadIdx.x * num_parts + part] = lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
+    // (only the rows of digits that exist: each count is a 4-byte store into a row of its own, i.e. a partial line write)
+    if (threadIdx.x <= dmask) counts[(size_t)threadIdx.x * num_parts + part] = lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
 }
 
 // One workgroup per digit: in-place exclusive scan of counts[digit][0 .. active_parts), row total -> totals[digit].
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         const u32 local_start = woff + inc - cnt_d;
         // global base of digit d = exclusive scan of the 256 digit totals, done here by every block (a dozen instructions)
         // rather than by a 1-block kernel between the row scan and the scatter (a 4.5 us bubble per pass)
-        const u32 tot_d = digit_totals[d];
+        const u32 tot_d = (d <= dmask) ? digit_totals[d] : 0u;  // (rows above the digit range are neither counted nor scanned)
         u32 tinc = tot_d;
 #pragma unroll
         for (u32 s = 1; s < 64; s <<= 1) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         u32 tbase = tinc - tot_d;
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) if (w < wave) tbase += s_wsum[w];
-        s_gdelta[d] = tbase + offsets[(size_t)d * num_parts + part] - local_start;
+        s_gdelta[d] = tbase + ((d <= dmask) ? offsets[(size_t)d * num_parts + part] : 0u) - local_start;
         u32 run = local_start;   // per-wave start of digit d inside the partition's sorted order
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) {
@@ -576,7 +577,7 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
         const u32 dmask = (1u << width) - 1u;
         WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, dmask, s->num_parts,
                     s->counts);
-        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(dmask + 1u), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
         // (two passes: the first initialises the range table, the second fills it; any other pass count keeps the search kernel)
         const u32 ranges_mode = (passes == 2u) ? p + 1u : 0u;
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
