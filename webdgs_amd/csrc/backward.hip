@@ -42,7 +42,7 @@ struct ViewAdam {
 // MODE 1: the view's gradient also goes into the step's fp32 block -- the values that accumulate_gradients / store_gradients
 // (optimizer.hip) would read back from the packed fp16 gradient, taken from the registers that were just packed.  MODE 2: Adam.
 template <int MODE>
-__global__ __launch_bounds__(256) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
+__global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
                                                                  const u32* gaussians, const int* __restrict__ acc,
                                                                  u32* __restrict__ gradients, ViewAccumulate va, ViewAdam ad) {
     constexpr bool ACC = MODE == 1;
