@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Invoked WITHOUT a launcher (`python bench.py --gpus N`, N > 1, no WORLD_SIZE in the environment) the process starts its N ranks itself:
+before it imports torch or touches a GPU it spawns `python -m torch.distributed.run ... bench.py <same flags>` as a CHILD process, relays
+that job's stdout (rank 0's JSON line), and exits with the child's return code (stderr tail on failure).
+
 Workload: config c3 ("c3-perf": 1 M synthetic Gaussians, 1920x1080, SH degree 3), ground truth rendered by the
 same HIP forward from the perturbed scene.  A training view = project -> scan -> emit -> sort -> ranges -> composite -> loss ->
 backward raster -> geometry backward.
@@ -140,7 +144,7 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: 
     return out
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -152,10 +156,213 @@ def main() -> None:
     ap.add_argument("--lanes", type=int, default=0, help="device lanes a batched step deals its views to (0 = the Trainer's default; 1 = no overlap)")
     ap.add_argument("--views-per-rank", type=int, default=0, help="views per rank per global step (default: 1 at N = 1, 8 at N > 1)")
     ap.add_argument("--sustained-steps", type=int, default=620, help="N = 1: length of the densify-inclusive leg (0 = skip)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the K-step block is repeated until this much time has been timed; the MEDIAN block is reported (0 = one block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the eager per-kernel pass (roofline becomes null)")
+    ap.add_argument("--no-single-gpu-base", action="store_true", help="N > 1: skip the like-for-like leg (the same batched step on rank 0 alone, no exchange)")
     ap.add_argument("--cpu-baseline-points", type=int, default=0, help="0 = full workload")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def self_launch(n_ranks: int, argv: list) -> int:
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a CHILD job (`python -m torch.distributed.run`, one rank per
+    GPU) before this process has imported torch or touched a GPU, relay the job's stdout, return its exit code.  Nothing is exec'ed and
+    no process that has initialised the GPU spawns another GPU program.  stderr of the job is kept in a temporary file and its tail is
+    printed when the job fails (torchrun's own banner would otherwise bury the one JSON line of a good run)."""
+    import signal
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n_ranks))))
+    env["WDGS_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    with tempfile.TemporaryFile(mode="w+") as err:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, text=True, env=env, start_new_session=True)
+        try:
+            for line in proc.stdout:  # rank 0's JSON line goes to stdout; backend chatter (gloo prints its connection banner there) to stderr
+                out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+                out.write(line)
+                out.flush()
+            rc = proc.wait()
+        except BaseException:  # Ctrl-C / a caller's timeout: take the whole job down (exactly the process group started above)
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                proc.wait(timeout=20)
+            except Exception:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+            raise
+        if rc != 0:
+            err.seek(0)
+            tail = err.read().splitlines()[-60:]
+            print(f"[bench] the {n_ranks}-rank job exited with code {rc}; last lines of its stderr:", file=sys.stderr)
+            for line in tail:
+                print("    " + line, file=sys.stderr)
+    return rc
+
+
+def launcher_selftest() -> None:
+    """WDGS_BENCH_SELFTEST=1: the body a rank runs in the launcher's CPU test (tests/test_bench_launcher.py) -- a gloo all-reduce of
+    ones instead of the GPU workload, one JSON line on rank 0.  WDGS_BENCH_SELFTEST=fail makes rank 1 exit non-zero."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if os.environ.get("WDGS_BENCH_SELFTEST") == "fail" and rank == world - 1:
+        print("selftest: this rank fails on purpose", file=sys.stderr, flush=True)
+        sys.exit(7)
+    ones = torch.ones(1, dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "n_ranks_seen": int(ones.item()), "self_launched": os.environ.get("WDGS_BENCH_SELF_LAUNCHED") == "1",
+                          "argv": sys.argv[1:]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int):
+    """The timed region: blocks of EXACTLY `steps` Trainer.step() calls, each bracketed by barrier + torch.cuda.synchronize() on both
+    sides.  One block is the contract's measurement; it is repeated until `min_seconds` have been timed (every rank takes the same
+    number of blocks: the count is fixed from the first block's max-over-ranks time) and the MEDIAN block is the one reported, so a
+    16 ms region on a shared box is not at the mercy of one noisy neighbour.  Returns (median block seconds, max over ranks;
+    device ms of that block; all block times)."""
+    import torch
+    from webdgs_amd import parallel
+
+    def one_block():
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(dev.torch_stream)
+        for _ in range(steps):
+            trainer.step()
+        trainer.drain()  # (pipeline depth 2: the last step's own await, with its deferred error check)
+        ev1.record(dev.torch_stream)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+    def max_over_ranks(values):
+        if world <= 1:
+            return list(values)
+        import torch.distributed as dist
+        t = torch.tensor(list(values), dtype=torch.float64, device=dev.torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    first, first_dev = one_block()
+    first = max_over_ranks([first])[0]
+    blocks, dev_ms = [first], [first_dev]
+    n_more = 0 if min_seconds <= 0 else min(400, max(0, int(np.ceil(min_seconds / max(first, 1e-6))) - 1))
+    for _ in range(n_more):
+        e, d = one_block()
+        blocks.append(e)
+        dev_ms.append(d)
+    blocks = [first] + max_over_ranks(blocks[1:]) if n_more else blocks
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i])
+    mid = order[(len(order) - 1) // 2]
+    return blocks[mid], dev_ms[mid], blocks
+
+
+def source_sha(kernel: str) -> str:
+    """sha256 (16 hex) of the HIP source file a kernel lives in: ties an offline PMC profile to the kernel it describes."""
+    import hashlib
+    f = None
+    for prefix, src in (("backward_rasterize", "backward_raster.hip"), ("rasterize", "raster.hip"), ("sort", "sort.hip"), ("segment_sort", "sort.hip"),
+                        ("tile_ranges", "sort.hip"), ("project_count", "project.hip"), ("emit", "project.hip"), ("update_stats", "project.hip"),
+                        ("geometry_backward", "backward.hip"), ("adam_repack", "optimizer.hip"), ("apply_rows", "optimizer.hip"), ("dc_", "optimizer.hip"),
+                        ("unpack", "optimizer.hip"), ("loss_grad", "loss.hip"), ("scan", "scan.hip"), ("metric", "densify.hip"), ("densify", "densify.hip")):
+        if kernel.startswith(prefix):
+            f = src
+            break
+    if not f:
+        return ""
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "webdgs_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return ""
+
+
+def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, tiles: int, k_coef: int, passes: int, config: str, pairs: int, raster_ms: float) -> dict:
+    """The `roofline` object for the dominant kernel.  The two rasterization kernels (K14 / K16) are bound by fp32 VALU issue (SURVEY
+    8(d)): for them `bound` = "valu_issue", achieved / peak are wave-instructions per second (a wave64 VALU instruction occupies its
+    SIMD-32 for 2 cycles: 1024 SIMDs x 2.4 GHz / 2), the HBM fraction is kept as `hbm_frac` and SURVEY 8(d)'s flop fraction
+    (F_fwd + F_bwd) / t / 157.3 TF as `flop_frac`.  VALU instruction counts and HBM traffic are PMC figures, which rocprofv3 collects in
+    passes of their own (scripts/pmc.sh -> profiles/*_pmc.json): they are taken from the newest profile whose recorded hash of the
+    kernel's source file equals the working tree's, and refused (null, with the reason) otherwise."""
+    dur_s = dur_ms / 1e3
+    abytes = algorithmic_bytes(dom, n, v, e, p_pix, tiles, k_coef, passes)
+    hbm_gbps = abytes / dur_s / 1e9 if dur_s > 0 else 0.0
+    roof = dict(bound="hbm", kernel=dom, achieved=round(hbm_gbps, 2), peak=8000.0, unit="GB/s", frac=round(hbm_gbps / 8000.0, 5), traffic=None,
+                avg_ms_per_launch=round(dur_ms, 4), algorithmic_bytes=abytes, hbm_frac=round(hbm_gbps / 8000.0, 5))
+    pmc_note = None
+    prof = pk = None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime, reverse=True):
+            cand = json.load(open(f))
+            if cand.get("workload", "c3") != config or dom not in cand.get("kernels", {}) and dom not in ("sort", "scan"):
+                continue
+            want, have = source_sha(dom), (cand.get("source_sha") or {}).get(dom)
+            if have is None:
+                pmc_note = f"{os.path.basename(f)} records no source hash for {dom}: refused"
+                continue
+            if have != want:
+                pmc_note = f"{os.path.basename(f)} was taken at another version of {dom}'s source ({have} != {want}): refused"
+                continue
+            prof, pk, pmc_note = cand, cand["kernels"], f"offline PMC profile {os.path.basename(f)}" + (f" @ {cand['head']}" if cand.get("head") else "")
+            break
+    except Exception as exc:  # a missing or malformed profile must never break the bench line
+        pmc_note = f"no PMC profile: {exc}"
+    if pk is not None:
+        names = {"sort": ("sort_hist", "sort_scan_rows", "sort_scatter", "sort_segments", "segment_sort", "emit_scatter"), "scan": ("scan_block_sums",)}.get(dom, (dom,))
+        launches = {"sort_hist": 1, "sort_scan_rows": 1, "sort_scatter": 1}
+        tr = sum(pk[nm].get("hbm_bytes", 0.0) * launches.get(nm, 1) for nm in names if nm in pk)
+        if tr > 0:
+            roof["traffic"] = round(tr)
+            roof["traffic_over_algorithmic"] = round(tr / abytes, 3) if abytes else None
+    roof["traffic_source"] = pmc_note
+    if dom in ("rasterize", "backward_rasterize"):
+        f_fwd, f_bwd = 256.0 * e * 23.0, 256.0 * e * 12.0 + pairs * 60.0   # SURVEY 8(d) "Algorithmic flops (raster)"
+        flops = f_fwd if dom == "rasterize" else f_bwd
+        roof["flop_frac"] = round(flops / dur_s / 157.3e12, 4) if dur_s > 0 else None
+        if raster_ms > 0:
+            roof["flop_frac_fwd_plus_bwd"] = round((f_fwd + f_bwd) / (raster_ms / 1e3) / 157.3e12, 4)
+        peak_issue = 1024 * 2.4e9 / 2.0  # wave-instructions per second the chip can issue
+        insts = pk[dom].get("SQ_INSTS_VALU") if pk is not None and dom in pk else None
+        roof.update(bound="valu_issue", unit="G wave-instr/s", peak=round(peak_issue / 1e9, 1))
+        if insts:
+            roof.update(achieved=round(insts / dur_s / 1e9, 1), frac=round(insts / dur_s / peak_issue, 4), valu_insts_per_launch=round(insts))
+        else:
+            roof.update(achieved=None, frac=None, note="VALU instruction count needs a PMC profile of this kernel version (scripts/pmc.sh); hbm_frac and flop_frac are live")
+    return roof
+
+
+def main() -> None:
+    args = parse_args()
+    if os.environ.get("WDGS_BENCH_SELFTEST") and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if os.environ.get("WDGS_BENCH_SELFTEST"):
+        launcher_selftest()
+        return
+    # `python bench.py --gpus N` with no launcher around it: become the launcher (before torch is imported or a GPU is touched)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # WDGS_BENCH_WATCHDOG=<seconds>: if the run is still going after that long, every thread's Python stack goes to stderr and the
     # process exits -- a hung collective then names itself instead of running into the caller's timeout
@@ -169,14 +376,19 @@ def main() -> None:
 
     rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        raise SystemExit(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or with no launcher at all)")
     # WDGS_FORCE_DEVICE (with WDGS_DIST_BACKEND=gloo): rehearse N > 1 on a single-GPU box; never set by the driver
     dev = ops.HipDevice(int(os.environ.get("WDGS_FORCE_DEVICE", local_rank)))
     vpr = args.views_per_rank or (1 if world == 1 else 8)
     n_dataset = args.views or (8 if world == 1 and vpr == 1 else 64)
+
+    # ranks that really answer: an all-reduce of ones over the job's backend (RCCL on a multi-GPU node)
+    n_ranks_seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        ones = torch.ones(1, dtype=torch.int32, device=dev.torch_device)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
 
     cfg = synth.CONFIGS[args.config]
     g, sh = synth.make_gaussians(cfg)
@@ -201,19 +413,10 @@ def main() -> None:
     # ---- timed region: recorded command buffers (HIP graphs), no per-kernel events.  Device time of the same region from two
     # events on the kernels' own stream (it is torch's current stream: ops.HipDevice).
     trainer.exchange_timing = world > 1
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(dev.torch_stream)
-    for _ in range(args.steps):
-        trainer.step()
-    trainer.drain()  # (pipeline depth 2: the last step's own await, with its deferred error check)
-    ev1.record(dev.torch_stream)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    elapsed = time.perf_counter() - t0
-    device_ms = ev0.elapsed_time(ev1)
+    elapsed, device_ms, blocks = timed_blocks(trainer, dev, args.steps, args.min_seconds, world)
+    #  the exchange events are read and switched off HERE, before the awaited leg below takes its own steps
+    exchange_ms = trainer.exchangeMilliseconds() / max(1, len(blocks)) if world > 1 else 0.0
+    trainer.exchange_timing = False
     # the same K steps with the reference's own await inside every step (depth 1), for comparison; not the headline
     awaited_ms = None
     if trainer.pipeline_depth > 1:
@@ -227,13 +430,11 @@ def main() -> None:
         parallel.barrier()
         awaited_ms = (time.perf_counter() - t_a) / args.steps * 1e3
         trainer.pipeline_depth = args.pipeline_depth
-    exchange_ms = trainer.exchangeMilliseconds() if world > 1 else 0.0
-    trainer.exchange_timing = False
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed, exchange_ms], dtype=torch.float64, device=dev.torch_device)
+        tt = torch.tensor([exchange_ms], dtype=torch.float64, device=dev.torch_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, exchange_ms = float(tt[0].item()), float(tt[1].item())
+        exchange_ms = float(tt[0].item())
 
     # ---- per-kernel durations: the same K steps again, launched eagerly with a hipEvent pair around every kernel on the
     # launch stream (events cannot bracket single kernels inside a replayed graph).  Kernels, grids and data are identical.
@@ -276,33 +477,8 @@ def main() -> None:
     dom = max(per_step, key=per_step.get) if per_step else None
     roofline = None
     if dom:
-        dur_s = per_step[dom] / 1e3
-        abytes = algorithmic_bytes(dom, n, v_visible, e_entries, p_pix, tiles, k_coef, passes)
-        achieved = abytes / dur_s / 1e9 if dur_s > 0 else 0.0
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 5), traffic=None,
-                        avg_ms_per_launch=round(per_step[dom], 4), algorithmic_bytes=abytes,
-                        note="K14/K16 are fp32-VALU-issue bound (SURVEY 8(d)); the binding resource is valu_issue_frac (counter-based, offline)")
-        # HBM traffic and VALU issue of that kernel come from PMC passes (scripts/pmc.sh -> profiles/*_pmc.json), which rocprofv3
-        # collects OFFLINE in runs of their own: the figures are labelled with the profile and the commit they were taken at, and are
-        # dropped when the profile does not carry the kernel or the workload.
-        try:
-            import glob
-            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-            if pmcs and args.config == "c3":
-                prof = json.load(open(pmcs[-1]))
-                pk = prof["kernels"]
-                launches = {"sort": passes}.get(dom, 1)
-                names = {"sort": ("sort_hist", "sort_scan_rows", "sort_scan_base", "sort_scatter"), "scan": ("scan_reduce", "scan_block_sums", "scan_downsweep")}.get(dom, (dom,))
-                tr = sum(pk[nm]["hbm_bytes"] if "hbm_bytes" in pk[nm] else pk[nm].get("hbm_bytes_corrected", 0) for nm in names if nm in pk) * launches
-                if tr > 0:
-                    roofline["traffic"] = round(tr)
-                    roofline["traffic_source"] = f"offline PMC profile {os.path.basename(pmcs[-1])}" + (f" @ {prof['head']}" if prof.get("head") else "")
-                if dom in pk and "SQ_INSTS_VALU" in pk[dom]:  # wave-instructions x 2 issue cycles / (CUs x 4 SIMDs) / clock, vs the live duration
-                    issue_s = pk[dom]["SQ_INSTS_VALU"] * 2.0 / (256 * 4) / 2.4e9
-                    roofline["valu_issue_frac"] = round(issue_s / dur_s, 4)
-                    roofline["valu_insts_per_launch"] = round(pk[dom]["SQ_INSTS_VALU"])
-        except Exception as exc:  # a missing or malformed profile must never break the bench line
-            roofline["traffic_note"] = f"no PMC profile: {exc}"
+        roofline = build_roofline(dom, per_step[dom], n, v_visible, e_entries, p_pix, tiles, k_coef, passes, args.config, pairs,
+                                  per_step.get("rasterize", 0.0) + per_step.get("backward_rasterize", 0.0))
 
     # every stage against the HBM roof (algorithmic bytes / live duration): the streaming stages are the ones it binds
     hbm_by_stage = {}
@@ -313,6 +489,30 @@ def main() -> None:
 
     ms_per_step = elapsed / args.steps * 1e3
     value = views_per_step * args.steps / elapsed
+
+    # ---- N > 1: the like-for-like base of the scaling curve -- the SAME batched step (views per rank, lanes, recorded command
+    # buffers, pipeline depth) on rank 0's GPU alone, without the exchange (the other ranks wait at the barrier).  The N = 1 bench line
+    # is the reference's one-view step, which is a different (slower per view) step: dividing by it would flatter the curve.
+    same_step = None
+    if world > 1 and not args.no_single_gpu_base:
+        trainer.use_command_buffers = True
+        parallel.barrier()
+        if rank == 0:
+            solo = Trainer(dev, seed=1234, world_size=1, rank=0, views_per_rank=vpr, overlap_views=args.lanes or None, pipeline_depth=args.pipeline_depth,
+                           exchange=parallel.Exchange())
+            solo.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+            solo.setDataset(cameras, images)
+            solo.setMaxIterations(10 ** 9)
+            solo.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+            solo.start()
+            for _ in range(args.warmup):
+                solo.step()
+            solo.warmupCommandBuffers()
+            s_el, s_dev, s_blocks = timed_blocks(solo, dev, args.steps, args.min_seconds, 1)
+            same_step = dict(views_per_s=round(vpr * args.steps / s_el, 3), ms_per_step=round(s_el / args.steps * 1e3, 4), views_per_step=vpr, lanes=solo._op_sets,
+                             blocks=len(s_blocks), note="rank 0's GPU alone: same views per rank, lanes, command buffers and pipeline depth; Adam on all N Gaussians, no exchange")
+            solo.destroy()
+        parallel.barrier()
 
     sustained = cpu_baseline = None
     if rank == 0 and world == 1:
@@ -328,14 +528,21 @@ def main() -> None:
             sl = parallel.slice_points(n, world)
             exch = dict(transport=trainer.exchange.name, ms_per_step=round(exchange_ms / args.steps, 4), frac_of_step=round(exchange_ms / args.steps / ms_per_step, 4),
                         bytes_sent_per_rank_per_step=int((world - 1) * sl * (60 + 32)),
-                        note="device time between the events that bracket the two collectives of a step (waiting for the slowest rank included)")
+                        note="device time between the events that bracket the two collectives of a step in the timed region (waiting for the slowest rank included)")
         out = {
             "metric": "training iters/sec (fwd+bwd+Adam), 1M Gaussians @1080p SH3" if args.config == "c3" else f"training iters/sec (fwd+bwd+Adam), {cfg.name}",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "device_ms_per_step": round(device_ms / args.steps, 4),
+            "timed_blocks": dict(blocks=len(blocks), steps_per_block=args.steps, seconds_timed=round(sum(blocks), 4), reported="median block",
+                                 ms_per_step_min=round(min(blocks) / args.steps * 1e3, 4), ms_per_step_max=round(max(blocks) / args.steps * 1e3, 4)),
             "ms_per_step_awaiting_every_step": round(awaited_ms, 4) if awaited_ms is not None else None,
             "eager_profiled_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4) if ktimes else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "head": head_commit(),
+            "n_ranks_seen": n_ranks_seen, "self_launched": os.environ.get("WDGS_BENCH_SELF_LAUNCHED") == "1",
+            "single_gpu_same_step": same_step,
+            "scaling_efficiency": round(value / (world * same_step["views_per_s"]), 4) if same_step else None,
+            # BASELINE c3 as written ("full train loop with densify/prune schedule"): the densify-inclusive rate of the `sustained` leg
+            "c3_as_written_iters_per_s": sustained["iters_per_s_overall"] if sustained else None,
             "config": {"workload": f"{cfg.name}: {n} Gaussians, {cfg.width}x{cfg.height}, SH deg {cfg.sh_deg}, fwd+bwd per view, {n_dataset} circle views"
                                    + (" (BASELINE c3: the reference's one-view step)" if views_per_step == 1 else f" (BASELINE c4 shape: {vpr} views per rank per global step)"),
                        "views_per_rank": vpr, "global_batch_views": views_per_step, "lanes": lanes,
@@ -347,7 +554,7 @@ def main() -> None:
                                      ("every step awaits its own completion, as the reference does" if args.pipeline_depth <= 1 else
                                       "a step awaits the PREVIOUS step's completion ticket (the host submits step k+1 while step k runs); all K steps "
                                       "finish inside the timed region; `ms_per_step_awaiting_every_step` is the reference's own await-per-step"),
-                       "densify_schedule": "reference defaults (warm-up 500): not reached in the timed region; see `sustained`" if views_per_step == 1 else "disabled in this leg",
+                       "densify_schedule": "reference defaults (warm-up 500): not reached in the timed region; see `sustained` / `c3_as_written_iters_per_s`" if views_per_step == 1 else "disabled in this leg",
                        "iter_definition": "value counts training VIEWS (fwd+bwd) per second; a step = views_per_rank x n_gpus views + 1 exchange + 1 Adam"},
             "kernel_ms_per_view": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
             "roofline": roofline, "hbm_roofline_by_stage": hbm_by_stage, "exchange": exch, "sustained": sustained, "cpu_baseline": cpu_baseline,

@@ -56,7 +56,12 @@ try:
     head = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
     head = ""
-json.dump(dict(source=os.path.basename(root.rstrip("/")), head=head, workload="c3",
+# hash of every kernel's source file at the time the counters were taken: bench.py refuses a profile whose hash for the dominant
+# kernel differs from the working tree's
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_sha  # noqa: E402
+shas = {k: source_sha(k) for k in list(res) + ["sort", "scan"] if source_sha(k)}
+json.dump(dict(source=os.path.basename(root.rstrip("/")), head=head, workload=(sys.argv[3] if len(sys.argv) > 3 else "c3"), source_sha=shas,
                note="mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes = 2*FETCH + WRITE (gfx950 line fills are 128 B, counted as 64)",
                calibration=calib, kernels=res), open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, "kernels:", len(res), "calibration:", {k: c["ratio"] for k, c in calib.items()})

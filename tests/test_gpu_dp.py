@@ -131,3 +131,27 @@ def test_rccl_backend_through_the_trainer(tmp_path):
                                            dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))))
     # both: the worker's own verdict AND a clean exit (teardown of the Trainer, the device, the process group and the interpreter)
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, _verdict(r)
+
+
+def test_bench_self_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a bare shell (no launcher, no WORLD_SIZE) starts its two ranks itself,
+    prints ONE JSON line carrying the like-for-like single-GPU base of the same batched step, the ranks an all-reduce of ones really
+    saw and the exchange time, and exits 0.  gloo + one shared GPU here (the 2-rank rehearsal); RCCL on a multi-GPU node."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_BENCH_WATCHDOG="500")
+    root = os.path.dirname(HERE)
+    r = _run_child([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "3", "--warmup", "1", "--views", "4",
+                    "--views-per-rank", "2", "--min-seconds", "0.05"], env, 560)
+    assert r.returncode == 0, _verdict(r)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, _verdict(r)
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["self_launched"] is True
+    assert out["config"]["views_per_rank"] == 2 and out["config"]["global_batch_views"] == 4
+    base = out["single_gpu_same_step"]
+    assert base["views_per_step"] == 2 and base["views_per_s"] > 0 and base["ms_per_step"] > 0
+    assert abs(out["scaling_efficiency"] - out["value"] / (2 * base["views_per_s"])) < 1e-3
+    assert out["exchange"]["ms_per_step"] > 0 and 0 < out["exchange"]["frac_of_step"] < 1.0  # (not double-counted: ADVICE r2)
+    assert out["timed_blocks"]["blocks"] >= 1 and out["steps"] == 3
+    assert out["roofline"]["kernel"] and out["roofline"]["hbm_frac"] is not None

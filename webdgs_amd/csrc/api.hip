@@ -249,15 +249,16 @@ static int collect_profile(wdgs_device* d) {
 // check) and a guarded optimizer step that skipped itself (sticky; set when the guard word of a batched / data-parallel step was
 // non-zero -- on this rank or, after the exchange summed it, on any other).  Reading consumes them.
 static int deferred_checks(wdgs_device* d) {
-    volatile u32* hg = d->host_guard;
-    const u32 skipped = hg[0];
-    hg[0] = 0u;
+    // The words are consumed with an atomic exchange: a wait for step k's ticket runs while step k+1 is in flight (pipeline depth 2),
+    // and a read followed by a plain store of 0 would lose a note the device writes between the two.  The device writes
+    // whole aligned words into pinned host memory; the exchange either sees the note (and reports it now) or leaves it for the next check.
+    const u32 skipped = __atomic_exchange_n(d->host_guard, 0u, __ATOMIC_ACQ_REL);
     u32 needed = 0u, cap = 0u;  // every pass's word is consumed; the first overflow found is the one reported
     for (wdgs_tiled_forward* f : d->forwards) {
         if (!f->encoded) continue;
-        volatile u32* st = f->host_stats;  // written by update_stats before the stream drained (no device round trip here)
-        const u32 v = st[2];               // sticky across the encodes since the last check: reading it here consumes it
-        st[2] = 0u;
+        // written by update_stats before the stream drained (no device round trip here); sticky across the encodes since the last
+        // check: the exchange consumes it
+        const u32 v = __atomic_exchange_n(f->host_stats + 2, 0u, __ATOMIC_ACQ_REL);
         if (v != 0u && needed == 0u) { needed = v; cap = f->tile_info.max_tile_entries; }
     }
     WDGS_REQUIRE(needed == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)", needed, cap);
@@ -757,7 +758,7 @@ int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
     WDGS_CHECK_HIP(wdgs_sync_lanes(op->dev));
     u32 st[4];
     for (int i = 0; i < 4; i++) st[i] = ((const volatile u32*)op->host_stats)[i];
-    ((volatile u32*)op->host_stats)[2] = 0u;  // the overflow word is sticky (set by any encode since the last check): consumed here
+    st[2] = __atomic_exchange_n(op->host_stats + 2, 0u, __ATOMIC_ACQ_REL);  // the overflow word is sticky (set by any encode since the last check): consumed here, atomically
     if (stats_out) std::memcpy(stats_out, st, sizeof(st));
     WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u", st[2], op->tile_info.max_tile_entries);
     return WDGS_OK;

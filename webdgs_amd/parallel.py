@@ -169,7 +169,13 @@ class TorchExchange(Exchange):
     _in_place = True
 
     def _out_of_place(self, error: Exception) -> None:
+        """Only a c10d build that REFUSES aliased input / output arguments (an argument check, raised before anything is enqueued)
+        switches the exchange to staging.  Any other error -- a transport failure, a timeout, an RCCL error -- is re-raised: retrying
+        a collective on one rank after such an error would leave the ranks issuing different collectives."""
         import sys
+        text = str(error).lower()
+        if not any(w in text for w in ("alias", "overlap", "in-place", "inplace", "same tensor", "input and output", "share storage", "partially")):
+            raise error
         print(f"[webdgs_amd.parallel] in-place collective refused ({error}); staging through a scratch tensor from now on", file=sys.stderr, flush=True)
         self._in_place = False
 

@@ -391,13 +391,19 @@ class Trainer:
                 self._step_single_view(mine[0])
             else:
                 self._step_batched(mine)
-        except BaseException:
+        except BaseException as orig:
             # a failed encode (capacity, first-use allocation inside a recording, a Python error) must not leave the stream in
             # capture mode or half-recorded command buffers behind: drop the recording and fall back to a clean eager state
             if self.device.handle:
                 self.device.lib.wdgs_encoder_abort(self.device.handle)
-            self._invalidate_command_buffers()
-            self._tickets = []
+            try:
+                self._invalidate_command_buffers()  # (waits for the steps still in flight before it destroys what they replay)
+            except ops.CapacityError as deferred:
+                # a step still in flight reported its own (deferred) overflow while the recordings were dropped: this step's error
+                # stays the one raised, the deferred one rides along as its cause
+                raise orig from deferred
+            finally:
+                self._tickets = []
             raise
         try:
             self._finish_step(n_views)
