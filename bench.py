@@ -69,6 +69,8 @@ def kernel_group(name: str) -> str:
         return "tile_ranges"
     if name.startswith("adam_repack"):
         return "adam_repack"
+    if name.startswith("emit"):  # emit, or emit fused with the sort's first pass (emit_scatter)
+        return "emit"
     return name
 
 
@@ -234,18 +236,52 @@ def launcher_selftest() -> None:
         dist.destroy_process_group()
 
 
-def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int):
+class TrainingSnapshot:
+    """Everything a block of steps changes -- point cloud, the six optimizer state arrays, the step counters, the view RNG -- kept in
+    device copies so that every repeated block of the timed region starts from the SAME state and therefore times the SAME K steps
+    (a training scene drifts: after 1300 steps c3's visible set has shrunk from 0.93 M to 0.22 M and a step costs 0.77 -> 1.17 ms).
+    The restore runs OUTSIDE the timed bracket (device-to-device copies on the kernels' stream + a reload of the optimizer's compact
+    SH-DC copy)."""
+
+    def __init__(self, trainer):
+        from webdgs_amd import parallel
+        self.t = trainer
+        dev = trainer.device
+        pc = trainer.pointCloud
+        bufs = dict(trainer.optimizer.getStateBuffers())  # (flushes the compact SH-DC copy into paramSH / stateSH first)
+        bufs.update(gaussians=pc.gaussian_3d_buffer, sh=pc.sh_buffer)
+        self.views = {k: parallel._tensor_at(dev, b.ptr, b.size, __import__("torch").uint8) for k, b in bufs.items() if b.size > 0}
+        self.copies = {k: v.clone() for k, v in self.views.items()}
+        self.iteration, self.rng = trainer.iteration, trainer._rng.getstate()
+        self.opt_iteration = trainer.optimizer.getIteration()
+
+    def restore(self) -> None:
+        t = self.t
+        t.drain()
+        for k, v in self.views.items():
+            v.copy_(self.copies[k])
+        t.optimizer.stateChanged()  # the compact SH-DC copy is reloaded from paramSH / stateSH
+        t.optimizer.advanceIteration((self.opt_iteration - t.optimizer.getIteration()) & 0xFFFFFFFF)
+        t.iteration = self.iteration
+        t._rng.setstate(self.rng)
+
+
+def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int, barrier=None):
     """The timed region: blocks of EXACTLY `steps` Trainer.step() calls, each bracketed by barrier + torch.cuda.synchronize() on both
     sides.  One block is the contract's measurement; it is repeated until `min_seconds` have been timed (every rank takes the same
     number of blocks: the count is fixed from the first block's max-over-ranks time) and the MEDIAN block is the one reported, so a
-    16 ms region on a shared box is not at the mercy of one noisy neighbour.  Returns (median block seconds, max over ranks;
-    device ms of that block; all block times)."""
+    16 ms region on a shared box is not at the mercy of one noisy neighbour.  Every block starts from the same training state
+    (TrainingSnapshot, restored outside the bracket): the blocks time the same K steps.  Returns (median block seconds, max over
+    ranks; device ms of that block; all block times)."""
     import torch
     from webdgs_amd import parallel
+    if barrier is None:
+        barrier = parallel.barrier
+    snap = TrainingSnapshot(trainer) if min_seconds > 0 else None
 
     def one_block():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        parallel.barrier()
+        barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record(dev.torch_stream)
@@ -254,11 +290,11 @@ def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int):
         trainer.drain()  # (pipeline depth 2: the last step's own await, with its deferred error check)
         ev1.record(dev.torch_stream)
         torch.cuda.synchronize()
-        parallel.barrier()
+        barrier()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1)
 
     def max_over_ranks(values):
-        if world <= 1:
+        if world <= 1 or not values:
             return list(values)
         import torch.distributed as dist
         t = torch.tensor(list(values), dtype=torch.float64, device=dev.torch_device)
@@ -270,10 +306,11 @@ def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int):
     blocks, dev_ms = [first], [first_dev]
     n_more = 0 if min_seconds <= 0 else min(400, max(0, int(np.ceil(min_seconds / max(first, 1e-6))) - 1))
     for _ in range(n_more):
+        snap.restore()
         e, d = one_block()
         blocks.append(e)
         dev_ms.append(d)
-    blocks = [first] + max_over_ranks(blocks[1:]) if n_more else blocks
+    blocks = [first] + max_over_ranks(blocks[1:])
     order = sorted(range(len(blocks)), key=lambda i: blocks[i])
     mid = order[(len(order) - 1) // 2]
     return blocks[mid], dev_ms[mid], blocks
@@ -508,7 +545,7 @@ def main() -> None:
             for _ in range(args.warmup):
                 solo.step()
             solo.warmupCommandBuffers()
-            s_el, s_dev, s_blocks = timed_blocks(solo, dev, args.steps, args.min_seconds, 1)
+            s_el, s_dev, s_blocks = timed_blocks(solo, dev, args.steps, args.min_seconds, 1, barrier=lambda: None)
             same_step = dict(views_per_s=round(vpr * args.steps / s_el, 3), ms_per_step=round(s_el / args.steps * 1e3, 4), views_per_step=vpr, lanes=solo._op_sets,
                              blocks=len(s_blocks), note="rank 0's GPU alone: same views per rank, lanes, command buffers and pipeline depth; Adam on all N Gaussians, no exchange")
             solo.destroy()

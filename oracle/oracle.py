@@ -193,6 +193,11 @@ def set_literal_order(on: bool) -> None:
     lib().orc_set_literal_order(ctypes.c_int(1 if on else 0))
 
 
+def set_k17_fix(flags: int) -> None:
+    """TEST-ONLY: undo SURVEY Q10 (bit 0) and / or Q11 (bit 1) inside the oracle's K17 (oracle_backward.cpp); 0 restores the reference's K17."""
+    lib().orc_set_k17_fix(ctypes.c_int(int(flags)))
+
+
 def unpack_gradients_f32(grads):
     """GaussianGradient[N] (8 u32 of fp16 pairs) -> f32[N,14] in component order pos3, opacity, rot4, log-sigma3, rgb3 (exact)."""
     h = np.ascontiguousarray(grads).view(np.float16).reshape(-1, 16).astype(np.float32)

@@ -250,6 +250,21 @@ void orc_backward_rasterize(const f32* settings_f, const u32* tile_offsets, cons
     }
 }
 
+// TEST-ONLY switches (tests/test_oracle_independent.py, default 0 = the reference's K17 as written).  They undo, one by one, the two
+// places where tiled-backward.wgsl disagrees with the forward pass it differentiates, so that a float64 finite-difference check can show
+// that these two are the ONLY deviations of the restated chain rule from the true gradient:
+//   bit 0  SURVEY Q10: rebuild the 2D covariance with W = transpose(view3x3), as the forward does (common.wgsl:90-95), instead of view3x3
+//          (tiled-backward.wgsl:134-140);
+//   bit 1  SURVEY Q11: dL/dndc.y = dL/dpx.y * (-0.5 * viewport.y), the derivative of px.y = (-0.5 ndc.y + 0.5) * viewport.y
+//          (tiled-forward.wgsl:237), instead of +0.5 * viewport.y (tiled-backward.wgsl:92).
+//   bit 2  "Q23" (found by the finite-difference check itself, not listed in SURVEY): K16 accumulates the FULL partial derivative with
+//          respect to conic.y (tiled-backward-rasterize.wgsl:163: -0.5 G * 2.0 * dx * dy), while K17's expressions for dL/da, dL/db,
+//          dL/dc (tiled-backward.wgsl:161-163) are the CUDA rasterizer's, which expect HALF of it (its K16 stores -0.5 G dx dy):
+//          the off-diagonal path is counted twice.  The switch halves dL/dconic.y on entry.
+// No product path and no parity test sets them.
+static int g_k17_fix = 0;
+void orc_set_k17_fix(int flags) { g_k17_fix = flags; }
+
 // K17 tiled-backward.wgsl:41-298.  gradients = GaussianGradient[n] (8 u32 each).
 void orc_geometry_backward(u32 n, const f32* camera_f, const f32* settings_f, const u32* gaussians,
                            const i32* grad_means_2d, const i32* grad_conics, const i32* grad_opacity, const i32* grad_colors,
@@ -261,8 +276,9 @@ void orc_geometry_backward(u32 n, const f32* camera_f, const f32* settings_f, co
 #pragma omp parallel for schedule(static)
     for (u32 idx = 0; idx < n; idx++) {
         vec2 dL_dmean2D_px = V2(from_fixed(grad_means_2d[(size_t)idx * 2u + 0u]), from_fixed(grad_means_2d[(size_t)idx * 2u + 1u]));
-        const vec3 dL_dconic = V3(from_fixed(grad_conics[(size_t)idx * 4u + 0u]), from_fixed(grad_conics[(size_t)idx * 4u + 1u]),
-                                  from_fixed(grad_conics[(size_t)idx * 4u + 3u]));
+        vec3 dL_dconic = V3(from_fixed(grad_conics[(size_t)idx * 4u + 0u]), from_fixed(grad_conics[(size_t)idx * 4u + 1u]),
+                            from_fixed(grad_conics[(size_t)idx * 4u + 3u]));
+        if (g_k17_fix & 4) dL_dconic.y = dL_dconic.y * 0.5f;  // (test-only: Q23 undone)
         const f32 dL_dopac = from_fixed(grad_opacity[idx]);
 
         const u32* g = gaussians + (size_t)idx * 6;
@@ -281,7 +297,8 @@ void orc_geometry_backward(u32 n, const f32* camera_f, const f32* settings_f, co
         const vec3 t = (view * V4(mean3D, 1.0f)).xyz();
 
         const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
-        const vec2 dL_dmean2D_ndc = dL_dmean2D_px * 0.5f * viewport;
+        vec2 dL_dmean2D_ndc = dL_dmean2D_px * 0.5f * viewport;
+        if (g_k17_fix & 2) dL_dmean2D_ndc.y = -dL_dmean2D_ndc.y;  // (test-only: Q11 undone)
 
         const mat4 view_proj = camera.proj * camera.view;
         const vec4 p_hom = view_proj * V4(mean3D, 1.0f);
@@ -305,7 +322,8 @@ void orc_geometry_backward(u32 n, const f32* camera_f, const f32* settings_f, co
         const mat3 J = M3(V3(focal_x / t.z, 0.0f, -(focal_x * t_clamped_x) / (t.z * t.z)),
                           V3(0.0f, focal_y / t.z, -(focal_y * t_clamped_y) / (t.z * t.z)),
                           V3(0.0f, 0.0f, 0.0f));
-        const mat3 W = M3(view[0].xyz(), view[1].xyz(), view[2].xyz());
+        const mat3 W_ref = M3(view[0].xyz(), view[1].xyz(), view[2].xyz());
+        const mat3 W = (g_k17_fix & 1) ? transpose(W_ref) : W_ref;  // (test-only: Q10 undone)
         const mat3 T_mat = W * J;
         const mat3 Vrk = M3(V3(cov3D_flat.v[0], cov3D_flat.v[1], cov3D_flat.v[2]),
                             V3(cov3D_flat.v[1], cov3D_flat.v[3], cov3D_flat.v[4]),

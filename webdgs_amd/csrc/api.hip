@@ -8,7 +8,10 @@
 #include "common.h"
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
-int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*);
+int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*, void*);
+int launch_emit_scatter(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, const void*, const void*, void*, void*, u32);
+int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges);
+extern "C" void sorter_set_final_out_index(wdgs_sorter* s, int i);
 int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*, void*, void*);
 int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
@@ -16,11 +19,12 @@ int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const
                      void*, void*);
 int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdgs_training_config&, void*);
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
-                              void*);
-int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*);
-int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, const void*, void*, const wdgs_adam_hyperparameters&, const void*,
+                              void*, void*);
+int launch_acc_clear_if_dirty(wdgs_device*, void*, u32, void*);
+int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*);
+int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
                                   const wdgs_optimizer_state&, void*, void*, const void*);
-int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, const void*, void*, void*, void*, const void*, void*,
+int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*, void*, void*, void*, const void*, void*,
                                         const void*, u32);
 int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
                        const void*);
@@ -99,6 +103,10 @@ struct wdgs_tiled_forward {
     u32* splats;
     u32* depths;
     u32* block_counts;  // u32[ceil(N/256)]: tile entries per project_count workgroup, scanned in place into workgroup offsets
+    // u32[256][ceil(N/256)] + u32[256]: tile entries per workgroup and tile COLUMN (project_count), scanned per column into the workgroup's
+    // offset inside the column, and the column totals -- the digit counts of the sort's first pass, which emit_scatter performs (project.hip)
+    u32* column_counts;
+    u32* column_totals;
     u32 points_capacity;  // Gaussians the per-Gaussian buffers above and the scanner hold (>= cfg.num_points: wdgs_tiled_forward_resize)
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
     wdgs_sorter* sorter;
@@ -129,7 +137,8 @@ struct wdgs_tiled_backward {
     wdgs_device* dev;
     wdgs_tiled_backward_config cfg;
     RenderSettings settings;
-    int* acc;            // i32[N*12]
+    int* acc;            // i32[N*12], followed by the state word below
+    u32* acc_dirty;      // device word behind the accumulators: 0 = all rows are zero (a consuming K17 left them so), 1 = they hold sums
     u32* gradients;      // GaussianGradient[N]
     float* loss_image;   // rgba32f
     u32* metric_counts;  // u32[N]
@@ -552,6 +561,8 @@ static int forward_alloc_per_point(wdgs_tiled_forward* op, u32 capacity) {
     int r = wdgs_alloc((void**)&op->splats, (size_t)24 * capacity, true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->depths, (size_t)4 * capacity, true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->block_counts, (size_t)4 * (ceil_div(capacity, 256) + 1), true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&op->column_counts, (size_t)4 * 256 * (ceil_div(capacity, 256) + 1), true, d->stream);
+    if (r == WDGS_OK && !op->column_totals) r = wdgs_alloc((void**)&op->column_totals, (size_t)4 * 256, true, d->stream);
     if (r == WDGS_OK) r = wdgs_prefix_scanner_create(d, capacity, &op->scanner);
     if (r == WDGS_OK) op->points_capacity = capacity;
     return r;
@@ -576,7 +587,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     wdgs_tiled_forward* op = new wdgs_tiled_forward();
     op->dev = d;
     op->cfg = *cfg;
-    op->stats = op->splats = op->depths = op->block_counts = nullptr;
+    op->stats = op->splats = op->depths = op->block_counts = op->column_counts = op->column_totals = nullptr;
     op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;
@@ -615,6 +626,8 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     free_dev(op->splats);
     free_dev(op->depths);
     free_dev(op->block_counts);
+    free_dev(op->column_counts);
+    free_dev(op->column_totals);
     free_dev(op->ranges);
     wdgs_prefix_scanner_destroy(op->scanner);
     wdgs_sorter_destroy(op->sorter);
@@ -634,8 +647,8 @@ int wdgs_tiled_forward_resize(wdgs_tiled_forward* op, uint32_t n) {
     WDGS_CHECK_HIP(wdgs_sync_lanes(d));
     const u32 need = std::max(n, 1u);
     if (need > op->points_capacity) {
-        free_dev(op->splats); free_dev(op->depths); free_dev(op->block_counts);
-        op->splats = op->depths = op->block_counts = nullptr;
+        free_dev(op->splats); free_dev(op->depths); free_dev(op->block_counts); free_dev(op->column_counts);
+        op->splats = op->depths = op->block_counts = op->column_counts = nullptr;
         wdgs_prefix_scanner_destroy(op->scanner);
         op->scanner = nullptr;
         op->points_capacity = 0;
@@ -678,33 +691,53 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     // The offsets scan (K2-K4) is spread over its neighbours: project_count leaves the entry count of each of its workgroups, one
     // single-workgroup kernel scans those N/256 sums (and publishes the stats block: update_stats, K5, as its epilogue), and emit adds
     // its own in-workgroup prefix -- writing the per-Gaussian offsets table on the way.  Three launches instead of five.
+    // The tile sort's first pass is folded into its neighbours when the grid allows it (2..256 tile columns, <= 256 tile rows: any
+    // viewport up to 4096 x 4096): project_count also counts its workgroups' entries per tile COLUMN, the scan kernel turns those into
+    // per-column offsets, and emit writes its entries straight into column order (project.hip: emit_scatter) -- the keys are never
+    // written in emission order, histogrammed and scattered.  encode(skipSort) and compat_caps keep the reference's emission order.
+    const TileInfo& ti = op->tile_info;
+    const bool columns = !skip_sort && !op->cfg.compat_caps && n > 0 && ti.num_tiles_x >= 2u && ti.num_tiles_x <= 256u && ti.num_tiles_y <= 256u;
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
-                                  op->block_counts));
-    if (n > 0) {
-        WDGS_TRY(scan_block_sums_inplace(d, op->block_counts, ceil_div(n, 256), ScanStatsEpilogue{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries}));
+                                  op->block_counts, columns ? op->column_counts : nullptr));
+    const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries};
+    if (columns) {
+        WDGS_TRY(forward_scan(d, op->block_counts, ceil_div(n, 256), op->column_counts, op->column_totals, ti.num_tiles_x, ep));
+    } else if (n > 0) {
+        WDGS_TRY(scan_block_sums_inplace(d, op->block_counts, ceil_div(n, 256), ep));
     } else {
         WDGS_TRY(launch_update_stats(d, n, op->scanner->output, op->scanner->input, op->tile_info.max_tile_entries, op->stats, op->stats + 4, op->host_stats));
     }
-    WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->block_counts, op->settings, op->tile_info,
-                         wdgs_sorter_keys(op->sorter, 0), wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
     op->ranges_valid = false;
-    if (!skip_sort) {
-        // key = (tile_id + 1) << 16 | depth16: only 16 + bits(total_tiles) bits are ever set
-        if (op->cfg.compat_caps) {
-            WDGS_TRY(wdgs_sorter_sort(op->sorter, 32u));  // the reference's four 8-bit passes over the whole key
-        } else {
-            const u32 tiles = op->tile_info.total_tiles;
-            if (tiles + 1 > op->ranges_capacity) {
-                WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledForwardPass.encode allocates its range table on first use: run one eager encode before recording");
-                (void)wdgs_sync_lanes(d);
-                free_dev(op->ranges);
-                op->ranges = nullptr;
-                WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(tiles + 1), true, d->stream));
-                op->ranges_capacity = tiles + 1;
+    if (!skip_sort && !op->cfg.compat_caps) {
+        const u32 tiles = op->tile_info.total_tiles;
+        if (tiles + 1 > op->ranges_capacity) {
+            WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledForwardPass.encode allocates its range table on first use: run one eager encode before recording");
+            (void)wdgs_sync_lanes(d);
+            free_dev(op->ranges);
+            op->ranges = nullptr;
+            WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(tiles + 1), true, d->stream));
+            op->ranges_capacity = tiles + 1;
+        }
+    }
+    if (columns) {
+        WDGS_TRY(launch_emit_scatter(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->block_counts, op->settings, op->tile_info,
+                                     op->column_counts, op->column_totals, wdgs_sorter_keys(op->sorter, 0), wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
+        // one stable pass on the tile row (it builds the range table), then the per-tile depth sort: the order of a stable sort of the full key
+        WDGS_TRY(sorter_sort_rows(op->sorter, ti.num_tiles_x, ti.num_tiles_y, op->ranges));
+        op->ranges_valid = true;
+    } else {
+        WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->block_counts, op->settings, op->tile_info,
+                             wdgs_sorter_keys(op->sorter, 0), wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
+        if (skip_sort) sorter_set_final_out_index(op->sorter, 0);  // the unsorted entries are in ping-pong 0
+        if (!skip_sort) {
+            // key = (tile_id + 1) << 16 | depth16: only 16 + bits(total_tiles) bits are ever set
+            if (op->cfg.compat_caps) {
+                WDGS_TRY(wdgs_sorter_sort(op->sorter, 32u));  // the reference's four 8-bit passes over the whole key
+            } else {
+                // tile passes, range table, per-tile depth sort (sort.hip): the order of a stable sort of the full key
+                WDGS_TRY(sorter_sort_segmented(op->sorter, bits_for(op->tile_info.total_tiles), op->tile_info.total_tiles, op->ranges));
+                op->ranges_valid = true;
             }
-            // tile passes, range table, per-tile depth sort (sort.hip): the order of a stable sort of the full key
-            WDGS_TRY(sorter_sort_segmented(op->sorter, bits_for(tiles), tiles, op->ranges));
-            op->ranges_valid = true;
         }
     }
     op->encoded = true;
@@ -863,7 +896,8 @@ static int backward_alloc_images(wdgs_tiled_backward* op, u32 w, u32 h) {
 
 static int backward_alloc_per_point(wdgs_tiled_backward* op, u32 capacity) {
     wdgs_device* d = op->dev;
-    int r = wdgs_alloc((void**)&op->acc, (size_t)capacity * 48, true, d->stream);
+    int r = wdgs_alloc((void**)&op->acc, (size_t)capacity * 48 + 16, true, d->stream);
+    if (r == WDGS_OK) op->acc_dirty = reinterpret_cast<u32*>(reinterpret_cast<char*>(op->acc) + (size_t)capacity * 48);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->gradients, (size_t)capacity * 32, true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&op->metric_counts, (size_t)capacity * 4, true, d->stream);
     if (r == WDGS_OK) op->points_capacity = capacity;
@@ -884,6 +918,7 @@ int wdgs_tiled_backward_resize(wdgs_tiled_backward* op, uint32_t n) {
         WDGS_TRY(backward_alloc_per_point(op, (u32)std::min<uint64_t>((uint64_t)need + need / 4, 0xFFFFFFFFull)));
     } else {
         WDGS_CHECK_HIP(hipMemsetAsync(op->acc, 0, (size_t)need * 48, d->stream));
+        WDGS_CHECK_HIP(hipMemsetAsync(op->acc_dirty, 0, 16, d->stream));
         WDGS_CHECK_HIP(hipMemsetAsync(op->gradients, 0, (size_t)need * 32, d->stream));
         WDGS_CHECK_HIP(hipMemsetAsync(op->metric_counts, 0, (size_t)need * 4, d->stream));
     }
@@ -925,9 +960,9 @@ static int backward_encode_raster(wdgs_tiled_backward* op, const void* pred, con
     wdgs_device* d = op->dev;
     const u32 w = op->cfg.viewport_width, h = op->cfg.viewport_height, n = op->cfg.num_points;
     WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image));
-    WDGS_CHECK_HIP(hipMemsetAsync(op->acc, 0, (size_t)std::max(n, 1u) * 48, d->stream));  // clearBuffer x4, tiled-backward-pass.ts:624-627
+    WDGS_TRY(launch_acc_clear_if_dirty(d, op->acc, n, op->acc_dirty));  // clearBuffer x4, tiled-backward-pass.ts:624-627 (a no-op behind a consuming K17)
     return launch_backward_rasterize(d, op->settings, ceil_div(w, 16), ceil_div(h, 16), res->tile_offsets_buffer, res->tile_indices_buffer, res->splat_buffer,
-                                     res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc);
+                                     res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc, op->acc_dirty);
 }
 int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res,
                                const void* gaussians) {
@@ -950,7 +985,7 @@ int wdgs_tiled_backward_encode_geometry(wdgs_tiled_backward* op, const void* cam
     if (!into) return launch_geometry_backward(op->dev, op->cfg.num_points, camera, op->settings, gaussians, op->acc, op->gradients);
     WDGS_REQUIRE(into->sums && into->visible && into->tile_counts && into->guard && into->overflow_word, WDGS_E_INVALID,
                  "wdgs_tiled_backward_encode_geometry: incomplete accumulate target");
-    return launch_geometry_backward_accumulate(op->dev, op->cfg.num_points, camera, op->settings, gaussians, op->acc, op->gradients, into->sums, into->visible,
+    return launch_geometry_backward_accumulate(op->dev, op->cfg.num_points, camera, op->settings, gaussians, op->acc, op->acc_dirty, op->gradients, into->sums, into->visible,
                                                into->tile_counts, into->guard, into->overflow_word, into->first ? 1u : 2u);
 }
 int wdgs_tiled_backward_compute_metric_map(wdgs_tiled_backward* op, const void* pred, const void* targ, float threshold) {
@@ -1079,7 +1114,7 @@ int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* b
                  bwd->cfg.num_points, op->num_points);
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
-    return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->gradients, op->params, tile_counts, op->state,
+    return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradients, op->params, tile_counts, op->state,
                                          op->dc, sh, op->guard);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {

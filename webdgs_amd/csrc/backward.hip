@@ -43,14 +43,23 @@ struct ViewAdam {
 // (optimizer.hip) would read back from the packed fp16 gradient, taken from the registers that were just packed.  MODE 2: Adam.
 template <int MODE>
 __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
-                                                                 const u32* gaussians, const int* __restrict__ acc,
+                                                                 const u32* gaussians, int* __restrict__ acc, u32* __restrict__ acc_dirty,
                                                                  u32* __restrict__ gradients, ViewAccumulate va, ViewAdam ad) {
     constexpr bool ACC = MODE == 1;
+    // The Trainer's forms (MODE 1, 2) CONSUME the accumulators: a row that held sums is put back to zero by the thread that read it and
+    // the state word says "clean", so the next view's clear has nothing to do (backward_raster.hip: acc_clear_if_dirty).  The plain
+    // form (MODE 0: TiledBackwardPass.encode) leaves the sums in place for readers.
+    constexpr bool CONSUME = MODE != 0;
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (ACC && idx == 0u) *va.guard = (va.mode == 1u ? 0u : *va.guard) | (*va.overflow != 0u ? 1u : 0u);  // guard_accumulate (optimizer.hip)
+    if (CONSUME && idx == 0u) *acc_dirty = 0u;
     if (idx >= n) return;
-    const int4* ap = reinterpret_cast<const int4*>(acc + (size_t)idx * ACC_STRIDE);
+    int4* ap = reinterpret_cast<int4*>(acc + (size_t)idx * ACC_STRIDE);
     const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    if (CONSUME && ((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w | a2.x | a2.y | a2.z | a2.w) != 0)) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        ap[0] = z; ap[1] = z; ap[2] = z;
+    }
     const vec2 dL_dmean2D_px = V2(from_fixed(a0.x), from_fixed(a0.y));
     const vec3 dL_dconic = V3(from_fixed(a0.z), from_fixed(a0.w), from_fixed(a1.x));
     const float dL_dopac = from_fixed(a1.y);
@@ -222,31 +231,31 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
 
 }  // namespace
 
-int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, const void* acc, void* gradients,
+int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, void* acc, void* acc_dirty, void* gradients,
                                   const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, void* dc, void* sh,
                                   const void* guard) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "geometry_backward_adam", geometry_backward_kernel<2>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st,
-                (const u32*)gaussians, (const int*)acc, (u32*)gradients, ViewAccumulate{},
+                (const u32*)gaussians, (int*)acc, (u32*)acc_dirty, (u32*)gradients, ViewAccumulate{},
                 (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_pos, (float4*)state.opt_rot, (float4*)state.opt_scale, (float*)state.opt_opacity,
                           (float*)dc, (u32*)gaussians, (u32*)sh, (const u32*)guard}));
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc, void* gradients) {
+int launch_geometry_backward(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, void* acc, void* gradients) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<0>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st, (const u32*)gaussians,
-                (const int*)acc, (u32*)gradients, ViewAccumulate{}, ViewAdam{});
+                (int*)acc, (u32*)nullptr, (u32*)gradients, ViewAccumulate{}, ViewAdam{});
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_geometry_backward_accumulate(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, const void* acc,
+int launch_geometry_backward_accumulate(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, const void* gaussians, void* acc, void* acc_dirty,
                                         void* gradients, void* sums, void* visible, const void* tile_counts, void* guard, const void* overflow, u32 mode) {
     // (n == 0 still runs one workgroup: the guard word must be written)
     WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<1>, dim3(std::max(ceil_div(n, 256), 1u)), dim3(256), 0, n, (const float*)camera, st,
-                (const u32*)gaussians, (const int*)acc, (u32*)gradients,
+                (const u32*)gaussians, (int*)acc, (u32*)acc_dirty, (u32*)gradients,
                 (ViewAccumulate{(float*)sums, (u32*)visible, (const u32*)tile_counts, (u32*)guard, (const u32*)overflow, mode}), ViewAdam{});
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;

@@ -18,6 +18,8 @@
 // (common.wgsl:113-116) and integer addition is order-free, so the result is bit-reproducible and equal to the oracle's.
 // Bound: fp32 VALU issue -- about 129 wave-instructions per (wave, splat) with a contributing pixel: the pinned exp (14), one division (8),
 // the per-pixel gradient arithmetic (about 55), the reduction (22) and the bookkeeping around them; DESIGN.md section 4 has the counters.
+#include <algorithm>
+
 #include "common.h"
 #include "dmath.h"
 #include "blockcull.h"
@@ -73,7 +75,9 @@ WD_DEV int cvt_fixed(float scaled) {
 __global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc) {
+                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty) {
+    // the accumulators hold sums from here on (acc_clear_if_dirty below, and the consuming forms of geometry_backward, backward.hip)
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *acc_dirty = 1u;
     __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, extent.x, extent.y
     __shared__ float4 s_con_all[4][64];  // conic.x, conic.y, conic.z, opacity
     __shared__ float4 s_col_all[4][64];  // r, g, b, gaussian index (bits)
@@ -257,14 +261,32 @@ __global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettin
     }
 }
 
+// clearBuffer x4 (tiled-backward-pass.ts:624-627) as a kernel that first looks at the accumulators' state word: the Trainer's forms of
+// K17 (geometry_backward_accumulate / geometry_backward_adam) put every row they have read back to zero -- only the ~18 % of rows a view
+// touches are non-zero -- and mark the buffer clean, so the next view's clear finds nothing to do (it used to be a 48 MB memset per view at
+// c3: 8-19 us).  After the plain K17 (TiledBackwardPass.encode, which leaves the sums readable) or a resize the word says dirty and the
+// whole buffer is cleared here.  The word is device state, so a recorded command buffer takes the right branch at every replay.
+__global__ __launch_bounds__(256) void acc_clear_if_dirty_kernel(int4* __restrict__ acc, u32 quads, const u32* __restrict__ acc_dirty) {
+    if (*acc_dirty == 0u) return;
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += gridDim.x * blockDim.x) acc[i] = z;
+}
+
 }  // namespace
 
+int launch_acc_clear_if_dirty(wdgs_device* dev, void* acc, u32 n, void* acc_dirty) {
+    const u32 quads = std::max(n, 1u) * (ACC_STRIDE / 4u);
+    WDGS_LAUNCH(dev, "acc_clear", acc_clear_if_dirty_kernel, dim3(std::min(ceil_div(quads, 256u * 8u), 2048u)), dim3(256), 0, (int4*)acc, quads, (const u32*)acc_dirty);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
 int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 num_tiles_x, u32 num_tiles_y, const void* ranges, const void* instances,
-                              const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc) {
+                              const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc, void* acc_dirty) {
     const u32 tiles = num_tiles_x * num_tiles_y;
     if (tiles == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel, dim3(tiles), dim3(256), 0, st, num_tiles_x, (const u32*)ranges, (const u32*)instances,
-                (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc);
+                (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -103,6 +103,14 @@ struct KernelScope {
         hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (dev)->stream, __VA_ARGS__);  \
     } while (0)
 
+// Workgroup number for launch slot b of a grid of g.  Slots b, b + 8, b + 16, ... are observed to run on one XCD (round-robin dispatch
+// over the chip's 8 XCDs); this numbering gives XCD k the CONTIGUOUS range of workgroups [start_k, start_k + count_k), so that
+// workgroups writing neighbouring addresses meet in one L2.  A bijection of [0, g) for every g; a speed choice only.
+__device__ __forceinline__ u32 xcd_contiguous(u32 b, u32 g) {
+    const u32 k = b & 7u, j = b >> 3, q = g >> 3, r = g & 7u;
+    return k * q + min(k, r) + j;
+}
+
 static inline u32 ceil_div(u32 a, u32 b) { return (a + b - 1u) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
@@ -121,6 +129,8 @@ struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u3
 int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep);
 
 int scan_block_sums_inplace(wdgs_device* dev, u32* block_sums, u32 num_blocks, const ScanStatsEpilogue& ep);
+// scan_block_sums_inplace + the row scans of the per-workgroup tile-column counts (column_counts[columns][num_blocks] -> offsets in place, totals)
+int forward_scan(wdgs_device* dev, u32* block_sums, u32 num_blocks, u32* column_counts, u32* column_totals, u32 columns, const ScanStatsEpilogue& ep);
 
 struct RenderSettings { float gaussian_scaling, sh_deg, viewport_x, viewport_y, point_size_px, gaussian_mode, max_splat_radius_px; };
 struct TileInfo { u32 num_tiles_x, num_tiles_y, total_tiles, max_tile_entries; };

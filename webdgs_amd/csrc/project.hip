@@ -104,10 +104,18 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
                                                              const float* __restrict__ camera_f, RenderSettings settings, TileInfo ti,
                                                              u32* __restrict__ splats, u32* __restrict__ depths,
                                                              u32* __restrict__ tile_counts, u32* __restrict__ visible_shards,
-                                                             u32* __restrict__ block_counts) {
+                                                             u32* __restrict__ block_counts, u32* __restrict__ column_counts /*[num_tiles_x][gridDim.x]*/) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool visible = false;
     u32 num_tiles_out = 0u;
+    // column_counts (nullable): tile entries of this workgroup's Gaussians per tile COLUMN -- the digit counts of the first pass of the
+    // tile sort, produced here where the boxes are, so that emit can write its entries straight into column order (emit_scatter below).
+    __shared__ u32 s_col[256];
+    u32 box_x0 = 1u, box_x1 = 0u, box_rows = 0u;
+    if (column_counts) {
+        s_col[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     if (idx < n) {
         do {
             const u32* g = gaussians + (size_t)idx * 6;
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
             depths[idx] = ordered_uint(world_to_view.z);
             num_tiles_out = num_tiles;
             visible = true;
+            box_x0 = tb.min_x; box_x1 = tb.max_x; box_rows = tb.max_y - tb.min_y + 1u;
         } while (false);
         tile_counts[idx] = num_tiles_out;
     }
@@ -182,6 +191,8 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
     // so the count goes to 64 shard words (one add per workgroup); update_stats folds the shards into stats[1].
     // block_counts[b] = tile entries of this workgroup's 256 Gaussians: the first level of the offsets scan, produced where the counts
     // are (the scan of these ~N/256 sums and the emit kernel's own in-workgroup prefix replace a reduce and a down-sweep launch).
+    if (column_counts)
+        for (u32 x = box_x0; x <= box_x1; x++) atomicAdd(&s_col[x], box_rows);  // (an invisible Gaussian has an empty range)
     __shared__ u32 s_vis[4], s_cnt[4];
     const unsigned long long mask = __ballot(visible);
     u32 wsum = num_tiles_out;
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
         if (c) atomicAdd(&visible_shards[blockIdx.x & 63u], c);
         if (block_counts) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
+    if (column_counts && threadIdx.x < ti.num_tiles_x) column_counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_col[threadIdx.x];
 }
 
 // stats[0] = total tile entries (update_stats, src/shaders/update-stats.wgsl:19-35); stats[2] = overflow flag.
@@ -302,13 +314,227 @@ __global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict_
     }
 }
 
+
+// K6 emit fused with the FIRST stable pass of the tile sort.  The sort key's tile field is tile = ty * num_tiles_x + tx; the forward
+// pass sorts it as a two-digit mixed-radix number (tx, then ty: sort.hip).  The digit counts of the first pass per workgroup are known
+// before a single key exists -- project_count counted its Gaussians' entries per tile column, forward_scan turned them into each
+// workgroup's offset inside each column -- so emit does not write its entries in emission order for a histogram and a scatter pass to
+// read back (8E + 4E + 16E bytes): it ranks them by column in LDS and writes them where the first pass would have put them (8E bytes).
+//
+// Order.  A stable pass keeps entries of one column in emission order; what the later passes need of that order is only that the
+// entries of one TILE stay in ascending Gaussian order (two entries of one Gaussian never share a tile).  Entries are ranked in the
+// workgroup's emission order (Gaussian-major), workgroups own consecutive Gaussians and consecutive slices of every column: same order.
+//
+// A workgroup expands its 256 Gaussians' entries in chunks of at most ES_CHUNK.  Owner of entry e = the last Gaussian whose count
+// prefix is <= e: every Gaussian marks the chunk position where its entries start, an inclusive max-scan over the positions (8 per
+// thread + one block scan) resolves every entry's owner at once -- instead of a dependent 8-step search per entry.  Wave w then ranks a
+// contiguous quarter of the chunk in rounds of 64 (ballot match on the column, per-wave column counters: the scheme of sort_scatter), the
+// chunk is reordered in LDS into column runs and leaves with consecutive lanes writing consecutive addresses.  Workgroups are numbered
+// so that neighbours -- which write neighbouring slices of every column run -- sit on the same XCD and meet in its L2.  The per-Gaussian
+// offsets table the reference exposes (getTileOffsetsBuffer) is written as a by-product, as emit does.
+constexpr u32 ES_CHUNK = 2048;
+constexpr u32 ES_ROUNDS = ES_CHUNK / 256;
+__global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __restrict__ splats, const u32* __restrict__ depths,
+                                                            const u32* __restrict__ tile_counts, u32* __restrict__ tile_offsets,
+                                                            const u32* __restrict__ block_offsets, RenderSettings settings, TileInfo ti,
+                                                            const u32* __restrict__ column_offsets /*[num_tiles_x][gridDim.x], scanned*/,
+                                                            const u32* __restrict__ column_totals, u32 inv_ntx /*2^32 / num_tiles_x, rounded up*/,
+                                                            u32* __restrict__ keys, u32* __restrict__ values, u32 capacity) {
+    __shared__ u32 s_pre[256];                     // exclusive prefix of the entry counts over the workgroup's Gaussians
+    __shared__ u32 s_box[256];                     // min_x | min_y << 8 | width << 16  (all < 256 on this path)
+    __shared__ u32 s_inv[256], s_dep[256];
+    __shared__ __align__(16) unsigned short s_own[ES_CHUNK];  // owner (Gaussian of the workgroup, + 1) of every entry of the chunk
+    __shared__ u32 whist[4][256];                  // per-wave column counters, then per-wave column starts inside the chunk
+    __shared__ u32 s_gbase[256];                   // where this workgroup's next entry of column c goes (global)
+    __shared__ u32 s_delta[256];                   // global position = s_delta[column] + position in the chunk's column order
+    __shared__ u32 s_keys[ES_CHUNK], s_vals[ES_CHUNK];
+    __shared__ u32 s_wsum[4], s_tsum[4];
+    const u32 wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    const u32 idx = wg * 256u + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 ntx = ti.num_tiles_x;
+    u32 cnt = 0u, ox = 0u, oy = 0u, width = 1u, depth16 = 0u;
+    if (idx < n) {
+        const u32 num_tiles = tile_counts[idx];
+        if (num_tiles != 0u) {
+            const uint2 w01 = *reinterpret_cast<const uint2*>(splats + (size_t)idx * 6);
+            const vec2 ndc = V2(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x));
+            const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+            const vec2 ext = V2(wd_min(wd_unpack_lo(w01.y), cap), wd_min(wd_unpack_hi(w01.y), cap));
+            const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+            const TileBox tb = tile_box(ndc, ext, viewport, ti.num_tiles_x, ti.num_tiles_y, false);
+            if (tb.valid) {  // the same box project_count counted
+                width = tb.max_x - tb.min_x + 1u;
+                cnt = width * (tb.max_y - tb.min_y + 1u);
+                ox = tb.min_x; oy = tb.min_y;
+                depth16 = depths[idx] >> 16u;
+            }
+        }
+    }
+    // exclusive prefix of the counts over the workgroup
+    u32 inc = cnt;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63u) s_wsum[wave] = inc;
+    // global start of column c for this workgroup: exclusive scan of the column totals (done by every workgroup: a dozen instructions,
+    // instead of a one-workgroup kernel in between) + the workgroup's offset inside the column
+    const u32 col = threadIdx.x;
+    const u32 tot_c = (col < ntx) ? column_totals[col] : 0u;
+    const u32 off_c = (col < ntx) ? column_offsets[(size_t)col * gridDim.x + wg] : 0u;
+    u32 tinc = tot_c;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(tinc, d, 64);
+        if (lane >= d) tinc += t;
+    }
+    if (lane == 63u) s_tsum[wave] = tinc;
+    __syncthreads();
+    u32 woff = 0u, total = 0u, tbase = tinc - tot_c;
+#pragma unroll
+    for (u32 w = 0; w < 4u; w++) {
+        const u32 v = s_wsum[w];
+        woff += (w < wave) ? v : 0u;
+        total += v;
+        tbase += (w < wave) ? s_tsum[w] : 0u;
+    }
+    const u32 pre = woff + inc - cnt;
+    if (idx < n) tile_offsets[idx] = block_offsets[wg] + pre;
+    if (total == 0u) return;  // (uniform)
+    s_pre[threadIdx.x] = pre;
+    s_box[threadIdx.x] = ox | (oy << 8u) | (width << 16u);
+    s_inv[threadIdx.x] = 0xFFFFFFFFu / width + 1u;  // floor(k / width) == umulhi(k, inv) for k * width < 2^32 (k <= 2048 here)
+    s_dep[threadIdx.x] = depth16;
+    s_gbase[col] = tbase + off_c;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const u32 wg_first = wg * 256u;
+    auto column_of = [&](u32 key) { const u32 t = (key >> 16u) - 1u; return t - __umulhi(t, inv_ntx) * ntx; };
+    for (u32 c0 = 0u; c0 < total; c0 += ES_CHUNK) {
+        const u32 n_here = min(ES_CHUNK, total - c0);
+        const u32 per_wave = ((n_here + 3u) / 4u + 63u) & ~63u;  // multiple of 64; 4 * per_wave >= n_here
+        const u32 rounds = per_wave / 64u;
+        // ---- owners: marks, then an inclusive max-scan over the chunk (thread t resolves entries [8t, 8t + 8))
+#pragma unroll
+        for (u32 w = 0; w < 4u; w++) whist[w][threadIdx.x] = 0u;
+        reinterpret_cast<uint4*>(s_own)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);   // 8 x u16
+        __syncthreads();
+        if (cnt != 0u && pre + cnt > c0 && pre < c0 + n_here) s_own[max(pre, c0) - c0] = (unsigned short)(threadIdx.x + 1u);
+        __syncthreads();
+        {
+            const uint4 q = reinterpret_cast<const uint4*>(s_own)[threadIdx.x];
+            u32 o[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+#pragma unroll
+            for (u32 j = 1; j < 8u; j++) o[j] = max(o[j], o[j - 1u]);
+            u32 minc = o[7];  // inclusive max-scan of the per-thread maxima over the workgroup
+#pragma unroll
+            for (u32 d = 1; d < 64; d <<= 1) {
+                const u32 t = __shfl_up(minc, d, 64);
+                if (lane >= d) minc = max(minc, t);
+            }
+            if (lane == 63u) s_wsum[wave] = minc;
+            __syncthreads();
+            u32 carry = __shfl_up(minc, 1, 64);
+            if (lane == 0u) carry = 0u;
+#pragma unroll
+            for (u32 w = 0; w < 4u; w++) carry = max(carry, (w < wave) ? s_wsum[w] : 0u);
+#pragma unroll
+            for (u32 j = 0; j < 8u; j++) o[j] = max(o[j], carry);
+            reinterpret_cast<uint4*>(s_own)[threadIdx.x] = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+        }
+        __syncthreads();
+        // ---- rank by column: wave w owns entries [w * per_wave, (w + 1) * per_wave) of the chunk, 64 per round
+        u32 kk[ES_ROUNDS], vv[ES_ROUNDS], rk[ES_ROUNDS];
+#pragma unroll
+        for (u32 j = 0; j < ES_ROUNDS; j++) {
+            kk[j] = 0xFFFFFFFFu; vv[j] = 0u; rk[j] = 0u;
+            if (j < rounds) {  // (uniform per workgroup)
+                const u32 i = wave * per_wave + j * 64u + lane;
+                const bool valid = i < n_here;
+                const u32 o = valid ? (u32)s_own[i] - 1u : 0u;   // (every valid entry has an owner: the chunk starts inside or at a Gaussian)
+                const u32 k = c0 + (valid ? i : 0u) - s_pre[o];
+                const u32 box = s_box[o];
+                const u32 w = box >> 16u;
+                const u32 row = (w == 1u) ? k : __umulhi(k, s_inv[o]);  // (the reciprocal of 1 does not fit 32 bits)
+                const u32 cx = (box & 0xFFu) + (k - row * w);
+                const u32 tile_id = (((box >> 8u) & 0xFFu) + row) * ntx + cx;
+                kk[j] = valid ? (((tile_id + 1u) << 16u) | s_dep[o]) : 0xFFFFFFFFu;
+                vv[j] = wg_first + o;
+                const u32 digit = valid ? cx : 0u;
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (u32 b = 0; b < 8; b++) {
+                    const bool bit = (digit >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                // m = valid lanes of this wave holding the same column
+                const u32 pre_c = whist[wave][digit];
+                const u32 below = (u32)__popcll(m & lt_mask);
+                rk[j] = pre_c + below;
+                if (valid && below == 0u) whist[wave][digit] = pre_c + (u32)__popcll(m);  // group leader bumps the wave counter
+            }
+        }
+        __syncthreads();
+        {   // column starts inside the chunk's column order (exclusive scan of the column counts), per-wave starts, global deltas
+            u32 cnt_c = 0u;
+#pragma unroll
+            for (u32 w = 0; w < 4u; w++) cnt_c += whist[w][col];
+            u32 cinc = cnt_c;
+#pragma unroll
+            for (u32 d = 1; d < 64; d <<= 1) {
+                const u32 t = __shfl_up(cinc, d, 64);
+                if (lane >= d) cinc += t;
+            }
+            if (lane == 63u) s_wsum[wave] = cinc;
+            __syncthreads();
+            u32 lstart = cinc - cnt_c;
+#pragma unroll
+            for (u32 w = 0; w < 4u; w++) lstart += (w < wave) ? s_wsum[w] : 0u;
+            const u32 gb = s_gbase[col];
+            s_delta[col] = gb - lstart;
+            s_gbase[col] = gb + cnt_c;  // the next chunk's entries of this column follow
+            u32 run = lstart;
+#pragma unroll
+            for (u32 w = 0; w < 4u; w++) {
+                const u32 c = whist[w][col];
+                whist[w][col] = run;
+                run += c;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < ES_ROUNDS; j++) {
+            if (j < rounds) {
+                const u32 i = wave * per_wave + j * 64u + lane;
+                if (i < n_here) {
+                    const u32 lpos = whist[wave][column_of(kk[j])] + rk[j];
+                    s_keys[lpos] = kk[j];
+                    s_vals[lpos] = vv[j];
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 e = threadIdx.x; e < n_here; e += 256u) {
+            const u32 key = s_keys[e];
+            const u32 pos = s_delta[column_of(key)] + e;
+            if (pos < capacity) {  // (a truncated list is reported as WDGS_E_CAPACITY and never used: api.hip)
+                keys[pos] = key;
+                values[pos] = s_vals[e];
+            }
+        }
+        __syncthreads();  // the chunk has left: its LDS is reused
+    }
+}
+
 }  // namespace
 
 int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const void* sh, const void* camera, const RenderSettings& st,
-                         const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards, void* block_counts) {
+                         const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards, void* block_counts, void* column_counts) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "project_count", project_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh,
-                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts);
+                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts, (u32*)column_counts);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
@@ -316,6 +542,16 @@ int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const v
 int launch_update_stats(wdgs_device* dev, u32 n, const void* offsets, const void* counts, u32 capacity, void* stats, void* visible_shards, void* host_mirror) {
     WDGS_LAUNCH(dev, "update_stats", update_stats_kernel, dim3(1), dim3(64), 0, n, (const u32*)offsets, (const u32*)counts, capacity, (u32*)stats,
                 (u32*)visible_shards, (u32*)host_mirror);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_emit_scatter(wdgs_device* dev, u32 n, const void* splats, const void* depths, const void* counts, void* offsets, const void* block_offsets,
+                        const RenderSettings& st, const TileInfo& ti, const void* column_offsets, const void* column_totals, void* keys, void* values, u32 capacity) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "emit_scatter", emit_scatter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)splats, (const u32*)depths, (const u32*)counts,
+                (u32*)offsets, (const u32*)block_offsets, st, ti, (const u32*)column_offsets, (const u32*)column_totals, 0xFFFFFFFFu / ti.num_tiles_x + 1u /*num_tiles_x >= 2 on this path*/,
+                (u32*)keys, (u32*)values, capacity);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -64,19 +64,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const u32* __
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// One block scans the block sums in place (exclusive), 256 at a time with a running carry.
-// The optional epilogue is the reference's update_stats (src/shaders/update-stats.wgsl:19-35) for the tile-count scan of the
-// forward pass: the grand total IS the number of tile entries, so the same single-block kernel publishes the stats block
-// {entries (clamped to the capacity), visible splats (folded from the shard words, which it clears), overflow} and mirrors it
-// into pinned host memory -- one launch less between the projection and the emit.
-__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ total_out,
-                                                                       ScanStatsEpilogue ep) {
-    __shared__ u32 lds[4];
+// In-place exclusive scan of `count` values by ONE workgroup, SCAN_TILE per round with a running carry (16 consecutive values per
+// thread); returns the total (uniform).
+__device__ __forceinline__ u32 scan_inplace_by_block(u32* __restrict__ v, u32 count, u32* lds) {
     u32 carry = 0;
-    // SCAN_TILE sums per round, 16 consecutive ones per thread (the forward pass hands over N/256 of them: one round up to 1 M Gaussians)
-    for (u32 base = 0; base < num_blocks; base += SCAN_TILE) {
+    for (u32 base = 0; base < count; base += SCAN_TILE) {
         u32 x[SCAN_ITEMS];
-        load_items(block_sums, base, num_blocks, x);
+        load_items(v, base, count, x);
         u32 s = 0;
 #pragma unroll
         for (u32 j = 0; j < SCAN_ITEMS; j++) s += x[j];
@@ -85,27 +79,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __re
         const u32 first = base + threadIdx.x * SCAN_ITEMS;
 #pragma unroll
         for (u32 j = 0; j < SCAN_ITEMS; j++) {
-            if (first + j < num_blocks) block_sums[first + j] = run;
+            if (first + j < count) v[first + j] = run;
             run += x[j];
         }
         carry += total;
     }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
-    if (ep.stats) {
-        u32 vis = 0u;
-        if (threadIdx.x < 64u) {  // wave 0 folds the 64 visible-count shards
-            vis = ep.visible_shards[threadIdx.x];
-            ep.visible_shards[threadIdx.x] = 0u;
+    return carry;
+}
+
+// The optional epilogue is the reference's update_stats (src/shaders/update-stats.wgsl:19-35) for the tile-count scan of the
+// forward pass: the grand total IS the number of tile entries, so the same single-block kernel publishes the stats block
+// {entries (clamped to the capacity), visible splats (folded from the shard words, which it clears), overflow} and mirrors it
+// into pinned host memory -- one launch less between the projection and the emit.
+__device__ __forceinline__ void stats_epilogue(u32 carry, const ScanStatsEpilogue& ep) {
+    u32 vis = 0u;
+    if (threadIdx.x < 64u) {  // wave 0 folds the 64 visible-count shards
+        vis = ep.visible_shards[threadIdx.x];
+        ep.visible_shards[threadIdx.x] = 0u;
 #pragma unroll
-            for (u32 d = 32; d >= 1; d >>= 1) vis += (u32)__shfl_xor((int)vis, (int)d, 64);
+        for (u32 d = 32; d >= 1; d >>= 1) vis += (u32)__shfl_xor((int)vis, (int)d, 64);
+    }
+    if (threadIdx.x == 0) {
+        const u32 entries = min(carry, ep.capacity), overflow = (carry > ep.capacity) ? carry : 0u;  // consumers only touch [0, capacity)
+        ep.stats[0] = entries; ep.stats[1] = vis; ep.stats[2] = overflow;
+        if (ep.host_mirror) {  // word 2 is STICKY: set on overflow, cleared only by the host check, so no view of a multi-view step can hide another's overflow
+            ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; if (overflow) ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u;
         }
-        if (threadIdx.x == 0) {
-            const u32 entries = min(carry, ep.capacity), overflow = (carry > ep.capacity) ? carry : 0u;  // consumers only touch [0, capacity)
-            ep.stats[0] = entries; ep.stats[1] = vis; ep.stats[2] = overflow;
-            if (ep.host_mirror) {  // word 2 is STICKY: set on overflow, cleared only by the host check, so no view of a multi-view step can hide another's overflow
-                ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; if (overflow) ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u;
-            }
-        }
+    }
+}
+
+// One block scans the block sums in place (exclusive), 256 x 16 at a time with a running carry (the forward pass hands over N/256 of
+// them: one round up to 1 M Gaussians).
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ total_out,
+                                                                       ScanStatsEpilogue ep) {
+    __shared__ u32 lds[4];
+    const u32 carry = scan_inplace_by_block(block_sums, num_blocks, lds);
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+    if (ep.stats) stats_epilogue(carry, ep);
+}
+
+// The forward pass's scans in ONE launch: workgroup 0 is scan_block_sums above (per-workgroup entry counts -> workgroup offsets, stats
+// block); workgroup 1 + c scans row c of the per-workgroup tile-COLUMN counts project_count left (column_counts[c][0 .. num_blocks)) into
+// the offset of each workgroup's entries inside column c, and leaves the column's total -- what the first pass of a radix sort gets from
+// its histogram and row-scan kernels, here without reading a key.
+__global__ __launch_bounds__(SCAN_THREADS) void forward_scan_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ column_counts,
+                                                                    u32* __restrict__ column_totals, ScanStatsEpilogue ep) {
+    __shared__ u32 lds[4];
+    if (blockIdx.x == 0u) {
+        const u32 carry = scan_inplace_by_block(block_sums, num_blocks, lds);
+        stats_epilogue(carry, ep);
+    } else {
+        const u32 c = blockIdx.x - 1u;
+        const u32 total = scan_inplace_by_block(column_counts + (size_t)c * num_blocks, num_blocks, lds);
+        if (threadIdx.x == 0u) column_totals[c] = total;
     }
 }
 
@@ -152,6 +178,12 @@ void scan_scratch_destroy(ScanScratch* s) {
 // level of a scan whose first level (the sums) and last level (the in-workgroup prefix) live in the producer and consumer kernels.
 int scan_block_sums_inplace(wdgs_device* dev, u32* block_sums, u32 num_blocks, const ScanStatsEpilogue& ep) {
     WDGS_LAUNCH(dev, "scan_block_sums", scan_block_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, block_sums, num_blocks, (u32*)nullptr, ep);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int forward_scan(wdgs_device* dev, u32* block_sums, u32 num_blocks, u32* column_counts, u32* column_totals, u32 columns, const ScanStatsEpilogue& ep) {
+    WDGS_LAUNCH(dev, "scan_forward", forward_scan_kernel, dim3(1u + columns), dim3(SCAN_THREADS), 0, block_sums, num_blocks, column_counts, column_totals, ep);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

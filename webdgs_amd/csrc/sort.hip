@@ -31,12 +31,29 @@ constexpr u32 SORT_ITEMS = 16;
 constexpr u32 SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per partition
 constexpr u32 RADIX = 256;
 
-__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 shift, u32 dmask,
-                                                                 u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/) {
+// The digit a pass sorts on: bits [shift, shift + width) of the key ((key >> shift) & dmask) or, for the second pass of a forward-pass
+// sort (sorter_sort_rows below), the tile ROW of the key's tile field: floor(((key >> 16) - 1) / num_tiles_x) by a reciprocal multiply
+// (exact: tile < 2^16, num_tiles_x <= 256).  row_inv = 0 selects the bit field; dmask is the largest digit either way.
+struct DigitOf {
+    u32 shift, dmask, row_inv;
+    __device__ __forceinline__ u32 operator()(u32 key) const { return row_inv ? __umulhi((key >> 16u) - 1u, row_inv) : ((key >> shift) & dmask); }
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, DigitOf digit_of,
+                                                                 u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/, u32* __restrict__ ranges_init,
+                                                                 u32 total_tiles) {
     __shared__ u32 lh[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
     const u32 base = part * SORT_TILE;
+    const u32 dmask = digit_of.dmask;
+    // ranges_init (nullable): the per-tile range table the scatter of this pass lowers (sort_scatter, ranges_mode 2) starts out "empty"
+    // with its terminator ranges[T] = E -- set here, by the kernel that runs before that scatter (partition 0 runs even for an empty list)
+    if (ranges_init) {
+        const u32 active = max((count + SORT_TILE - 1u) / SORT_TILE, 1u);
+        if (part < active)
+            for (u32 t = part * SORT_THREADS + threadIdx.x; t <= total_tiles; t += active * SORT_THREADS) ranges_init[t] = (t == total_tiles) ? count : 0xFFFFFFFFu;
+    }
     if (base >= count) return;
     const u32 wave = threadIdx.x >> 6;
 #pragma unroll
@@ -49,7 +66,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
             // the four keys of a lane are neighbours in memory and, in tile-ordered data, usually share their digit: merge equal
             // digits inside the lane first (same-address LDS atomics of one wave-instruction serialise; they were 86 % of this
             // kernel's LDS cycles: profiles/r01e_pmc.json)
-            const u32 d0 = (q.x >> shift) & dmask, d1 = (q.y >> shift) & dmask, d2 = (q.z >> shift) & dmask, d3 = (q.w >> shift) & dmask;
+            const u32 d0 = digit_of(q.x), d1 = digit_of(q.y), d2 = digit_of(q.z), d3 = digit_of(q.w);
             if (d0 == d3 && d0 == d1 && d0 == d2) {
                 atomicAdd(&lh[wave][d0], 4u);
             } else {
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
     } else {
         for (u32 j = 0; j < SORT_ITEMS; j++) {
             const u32 i = base + j * SORT_THREADS + threadIdx.x;
-            if (i < count) atomicAdd(&lh[wave][(keys[i] >> shift) & dmask], 1u);
+            if (i < count) atomicAdd(&lh[wave][digit_of(keys[i])], 1u);
         }
     }
     __syncthreads();
@@ -109,12 +126,17 @@ __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ c
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                     u32* __restrict__ keys_out, u32* __restrict__ vals_out,
-                                                                    const u32* __restrict__ count_ptr, u32 shift, u32 dmask, u32 num_parts,
+                                                                    const u32* __restrict__ count_ptr, DigitOf digit_of, u32 num_parts,
                                                                     const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals,
                                                                     u32* __restrict__ ranges, u32 ranges_mode, u32 total_tiles) {
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
+    const u32 dmask = digit_of.dmask;
     const u32 count = *count_ptr;
-    const u32 part = blockIdx.x;
+    // neighbouring partitions write neighbouring slices of every digit run: the ACTIVE ones (the grid is sized for the capacity) are
+    // numbered so that neighbours share an XCD (common.h)
+    const u32 active_parts = max((count + SORT_TILE - 1u) / SORT_TILE, 1u);  // partition 0 runs even for an empty list
+    if (blockIdx.x >= active_parts) return;
+    const u32 part = xcd_contiguous(blockIdx.x, active_parts);
     const u32 base = part * SORT_TILE;
     // The per-tile range table of a tile-structured sort (sort_segmented) is built by the two scatter passes themselves: the first one
     // sets every entry to "empty" (and the terminator ranges[T] = E), the second one -- whose output is in tile order -- lowers
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     for (u32 j = 0; j < SORT_ITEMS; j++) {
         const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
         const bool valid = i < count;
-        const u32 digit = (k[j] >> shift) & dmask;
+        const u32 digit = valid ? digit_of(k[j]) : 0u;
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (u32 b = 0; b < 8; b++) {
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     for (u32 j = 0; j < SORT_ITEMS; j++) {
         const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
         if (i < count) {
-            const u32 digit = (k[j] >> shift) & dmask;
+            const u32 digit = digit_of(k[j]);
             const u32 lpos = whist[wave][digit] + rk[j];
             s_keys[lpos] = k[j];
             s_vals[lpos] = v[j];
@@ -226,7 +248,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
 #pragma unroll 4
     for (u32 e = threadIdx.x; e < n_here; e += SORT_THREADS) {
         const u32 key = s_keys[e];
-        const u32 pos = s_gdelta[(key >> shift) & dmask] + e;
+        const u32 pos = s_gdelta[digit_of(key)] + e;
         keys_out[pos] = key;
         vals_out[pos] = s_vals[e];
         // In the partition's sorted order the entries of one tile are neighbours (same digit, and the input of this pass is ordered by
@@ -557,6 +579,8 @@ int wdgs_sorter_destroy(wdgs_sorter* s) {
 void* wdgs_sorter_keys(wdgs_sorter* s, int i) { return s ? s->keys[i & 1] : nullptr; }
 void* wdgs_sorter_values(wdgs_sorter* s, int i) { return s ? s->vals[i & 1] : nullptr; }
 int wdgs_sorter_final_out_index(wdgs_sorter* s) { return s ? s->final_out_index : 0; }
+// (internal) the forward pass left unsorted entries in ping-pong 0 (encode(skipSort)): that is what the getters hand out
+void sorter_set_final_out_index(wdgs_sorter* s, int i) { if (s) s->final_out_index = i & 1; }
 uint32_t wdgs_sorter_capacity(wdgs_sorter* s) { return s ? s->capacity : 0; }
 
 }  // extern "C"
@@ -575,13 +599,13 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
         const u32 width = left / (passes - p);
         left -= width;
         const u32 dmask = (1u << width) - 1u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, dmask, s->num_parts,
-                    s->counts);
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts,
+                    s->counts, (u32*)nullptr, 0u);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(dmask + 1u), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
         // (two passes: the first initialises the range table, the second fills it; any other pass count keeps the search kernel)
         const u32 ranges_mode = (passes == 2u) ? p + 1u : 0u;
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, dmask, s->num_parts, s->counts, s->totals, ranges, ranges_mode, num_segments);
+                    s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts, s->counts, s->totals, ranges, ranges_mode, num_segments);
         src ^= 1;
         shift += width;
     }
@@ -595,6 +619,24 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
     return WDGS_OK;
 }
 
+// The forward pass's sort when emit has already written its entries in tile-COLUMN order (project.hip: emit_scatter = the first stable
+// pass, on tx): ONE stable pass on the tile ROW (ty = tile / num_tiles_x <= 255), which also builds the per-tile range table -- its
+// histogram kernel initialises the table, its scatter lowers ranges[tile] to the first position it writes for the tile -- then the per-tile
+// depth sort.  Input in ping-pong 0, result in ping-pong 1.  4E + 16E + 16E bytes.
+int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges) {
+    wdgs_device* dev = s->dev;
+    const u32 tiles = num_tiles_x * num_tiles_y;
+    const DigitOf rows{0u, num_tiles_y - 1u, 0xFFFFFFFFu / num_tiles_x + 1u};  // (num_tiles_x >= 2)
+    WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles);
+    WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(num_tiles_y), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+    WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->vals[0], s->keys[1], s->vals[1], s->count_ptr, rows,
+                s->num_parts, s->counts, s->totals, ranges, 2u, tiles);
+    WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(tiles), dim3(SEG_THREADS), 0, s->keys[1], s->vals[1], s->keys[0], s->vals[0], ranges, tiles);
+    WDGS_CHECK_HIP(hipGetLastError());
+    s->final_out_index = 1;
+    return WDGS_OK;
+}
+
 extern "C" {
 
 int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
@@ -605,11 +647,11 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
     int src = 0;
     for (u32 p = 0; p < passes; p++) {
         const u32 shift = p * 8u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, shift, RADIX - 1u, s->num_parts,
-                    s->counts);
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts,
+                    s->counts, (u32*)nullptr, 0u);
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, shift, RADIX - 1u, s->num_parts, s->counts, s->totals, (u32*)nullptr, 0u, 0u);
+                    s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts, s->counts, s->totals, (u32*)nullptr, 0u, 0u);
         src ^= 1;
     }
     WDGS_CHECK_HIP(hipGetLastError());
