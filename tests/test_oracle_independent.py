@@ -190,3 +190,165 @@ def test_k17_each_deviation_is_real(orc, flags, broken):
         else:
             assert err < 3e-3, (key, err)
     assert _rel(got["opacity_raw"], fd["opacity_raw"]) < 3e-3    # the opacity path has no deviation
+
+
+# ----------------------------------------------------------------------------------------------------------------- (c) K18 Adam
+def test_adam_is_the_closed_form_without_bias_correction(orc):
+    """Three steps of the oracle's Adam (adam.wgsl:67-175) against Kingma & Ba's update in float64 WITHOUT bias correction,
+    on all 14 trained scalars, with the quaternion renormalised after its update (adam.wgsl:113-130), Gaussians of a view that touched no
+    tile left alone (Q15), position w forced to 1 and scale w to 0 (adam.wgsl:108, 142).  The bias-corrected textbook form is far away,
+    so the test can tell the two apart."""
+    rng = np.random.default_rng(7)
+    n = 3000
+    st = orc.new_optimizer_state(n)
+    st["opt_pos"][:, 0:3] = rng.normal(0, 2, (n, 3)); st["opt_pos"][:, 3] = 1.0
+    q = rng.normal(0, 1, (n, 4)); st["opt_rot"][:, 0:4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    st["opt_scale"][:, 0:3] = rng.uniform(-6, -2, (n, 3))
+    st["opt_opacity"][:, 0] = rng.normal(0, 1, n)
+    st["param_sh"][:] = rng.uniform(-1, 1, (n, 48))
+    for k in ("opt_pos", "opt_rot", "opt_scale"):
+        st[k][:, 4:8] = rng.normal(0, 1e-3, (n, 4)); st[k][:, 8:12] = rng.uniform(0, 1e-5, (n, 4))
+    for k in ("opt_pos", "opt_scale"):     # the fourth lane of the two vec3 groups carries no moments (adam.wgsl:108, 142)
+        st[k][:, [7, 11]] = 0.0
+    st["opt_opacity"][:, 1] = rng.normal(0, 1e-3, n); st["opt_opacity"][:, 2] = rng.uniform(0, 1e-5, n)
+    st["state_sh"][:, 0:6] = np.stack([rng.normal(0, 1e-3, (n, 3)), rng.uniform(0, 1e-5, (n, 3))], 2).reshape(n, 6)
+    st = {k: v.astype(np.float32) for k, v in st.items()}
+    ref = {k: v.astype(np.float64) for k, v in st.items()}
+    corrected = {k: v.copy() for k, v in ref.items()}
+    cfg = orc.ADAM_DEFAULT.copy()
+    lr = dict(pos=float(cfg[0]), color=float(cfg[1]), opacity=float(cfg[2]), scale=float(cfg[3]), rot=float(cfg[4]))
+    b1, b2, eps = float(cfg[5]), float(cfg[6]), float(cfg[7])
+    frozen_sh = st["param_sh"][:, 3:].copy()
+    for step in range(1, 4):
+        g16 = rng.normal(0, 1, (n, 16)).astype(np.float16)
+        g16[:, [11, 15]] = 0
+        grads = np.ascontiguousarray(g16).view(np.uint32).reshape(n, 8)
+        counts = (rng.uniform(size=n) < 0.8).astype(np.uint32) * rng.integers(1, 9, n).astype(np.uint32)
+        orc.adam(cfg, counts, grads, st)
+        g = g16.astype(np.float64)
+        vis = counts != 0
+        for tgt, bias in ((ref, False), (corrected, True)):
+            def upd(p, gr, m, v, rate):
+                m2, v2 = b1 * m + (1 - b1) * gr, b2 * v + (1 - b2) * gr * gr
+                mh, vh = (m2 / (1 - b1 ** step), v2 / (1 - b2 ** step)) if bias else (m2, v2)
+                return p - rate * mh / (np.sqrt(vh) + eps), m2, v2
+            for key, gcols, rate, width in (("opt_pos", slice(0, 3), lr["pos"], 3), ("opt_rot", slice(4, 8), lr["rot"], 4), ("opt_scale", slice(8, 11), lr["scale"], 3)):
+                a = tgt[key]
+                p, m, v = upd(a[vis, 0:width], g[vis, gcols], a[vis, 4:4 + width], a[vis, 8:8 + width], rate)
+                if key == "opt_rot":
+                    p = p / np.linalg.norm(p, axis=1, keepdims=True)
+                a[vis, 0:width], a[vis, 4:4 + width], a[vis, 8:8 + width] = p, m, v
+            o = tgt["opt_opacity"]
+            o[vis, 0], o[vis, 1], o[vis, 2] = upd(o[vis, 0], g[vis, 3], o[vis, 1], o[vis, 2], lr["opacity"])
+            s_ = tgt["state_sh"]
+            for c in range(3):
+                tgt["param_sh"][vis, c], s_[vis, 2 * c], s_[vis, 2 * c + 1] = upd(tgt["param_sh"][vis, c], g[vis, 12 + c], s_[vis, 2 * c], s_[vis, 2 * c + 1], lr["color"])
+
+    def dist(a, b):
+        return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+    for k in st:
+        assert dist(st[k].astype(np.float64), ref[k]) < 2e-6, (k, dist(st[k].astype(np.float64), ref[k]))
+    assert dist(st["opt_pos"][:, 0:3].astype(np.float64), corrected["opt_pos"][:, 0:3]) > 1e-4   # bias correction would be a different optimizer
+    assert np.allclose(np.linalg.norm(st["opt_rot"][:, 0:4], axis=1), 1.0, atol=2e-6)
+    assert np.all(st["opt_pos"][:, 3] == 1.0) and np.all(st["opt_scale"][:, 3] == 0.0)
+    assert np.array_equal(st["param_sh"][:, 3:], frozen_sh)       # only the DC coefficients are trained (Q14)
+
+
+# ----------------------------------------------------------------------------------------------------------------- (d) K26-K30
+def _rand01(seed_u32):
+    """f32(hash) * 2^-32 (densify-prune-scatter-gaussians.wgsl:40-43): the u32 -> f32 conversion rounds to 24 bits."""
+    return ind.lowbias32(seed_u32).astype(np.float32).astype(np.float64) / 4294967296.0
+
+
+def _densify_children_fp64(pos, quat, log_sigma, src, dst, action, variant):
+    """Child position and log-scale of output slot `dst` copied from input `src` (float64, vectorised): clone slot 1 is jittered by
+    0.25 sigma (.) U(-1,1)^3, split children sit at +- 0.5 sigma (.) n with n a six-uniform CLT normal and shrink by ln 1.6; offsets are
+    rotated by the (normalised) quaternion (densify-prune-scatter-gaussians.wgsl:79-150)."""
+    src32, dst32 = src.astype(np.uint64), dst.astype(np.uint64)
+    sigma = np.exp(np.clip(log_sigma, -10, 10))
+    R = ind.rotation_from_quaternion(quat / np.sqrt(np.maximum(1e-12, (quat * quat).sum(1, keepdims=True))))
+    out_pos, out_ls = pos.copy(), log_sigma.copy()
+    clone = (action == 1) & (variant == 1)
+    seed = ((src32 * 1664525 + dst32 * 1013904223) & 0xFFFFFFFF).astype(np.uint64)
+    r = np.stack([_rand01(seed ^ c) for c in (0xA2C79, 0x5E2D9, 0x1B873)], 1) * 2.0 - 1.0
+    out_pos[clone] += np.einsum("nij,nj->ni", R, 0.25 * sigma * r)[clone]
+    split = action == 2
+    seed2 = ((src32 * 747796405 + 2891336453) & 0xFFFFFFFF).astype(np.uint64)
+
+    def randn(s):
+        return (sum(_rand01(s ^ c) for c in (0xA2C79, 0x5E2D9, 0x1B873, 0xC0FFE, 0xBADC0, 0xDEADB)) - 3.0) * 1.41421356237
+    d = np.stack([randn(seed2 ^ c) for c in (0x9E3779B9, 0x243F6A88, 0xB7E15162)], 1)
+    sgn = np.where(variant == 1, -1.0, 1.0)[:, None]
+    out_pos[split] += (sgn * np.einsum("nij,nj->ni", R, 0.5 * sigma * d))[split]
+    out_ls[split] = np.clip(log_sigma, -10, 10)[split] - 0.4700036292457356
+    return out_pos, out_ls
+
+
+def test_densify_decisions_capacity_and_children(orc):
+    """K26-K30 restated from the rules (densify-prune-decide / -cap / -scatter-*.wgsl), vectorised in float64, against the oracle:
+    actions, capped counts, offsets and total exactly; every child's position, log-scale and opacity within one fp16 ulp (working copy) or
+    1e-6 (fp32 masters); state carry-over / reset and the always-zeroed opacity moments (Q16) exactly."""
+    cfg = harness.small_config("c1", num_points=6000, s0=0.1)            # scales 0.1 .. 1: both clone and split occur
+    g, sh = synth.make_gaussians(cfg)
+    n = g.shape[0]
+    rng = np.random.default_rng(11)
+    metric = rng.integers(0, 12, n).astype(np.uint32)
+    gs = ind.unpack_gaussians(g)
+    clone_thr, prune_op, split_scale = 6, 0.15, 0.5
+    max_out = n + 700                                                     # binds: the tail of the cloud is cut off by the capacity rule
+    prep = orc.densify_prepare(g, metric, max_out, clone_threshold=clone_thr, prune_opacity=prune_op, split_scale=split_scale)
+
+    sig = ind.sigmoid(gs["opacity_raw"])
+    act = np.where(sig < prune_op, 3, np.where(metric >= clone_thr, np.where(np.exp(gs["log_scale"]).max(1) >= split_scale, 2, 1), 0))
+    cnt = np.where(act == 3, 0, np.where(act == 0, 1, 2))
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    act = np.where(off >= max_out, 3, np.where((cnt == 2) & (off == max_out - 1), 0, act))     # cap rule (densify-prune-cap.wgsl:32-49)
+    cnt = np.where(off >= max_out, 0, np.where((cnt == 2) & (off == max_out - 1), 1, cnt))
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    assert np.array_equal(prep["actions"], act) and np.array_equal(prep["counts"], cnt) and np.array_equal(prep["offsets"], off)
+    assert prep["total"] == int(cnt.sum()) <= max_out and (act == 1).sum() > 50 and (act == 2).sum() > 50 and (act == 3).sum() > 50
+    assert (off >= 0).all() and cnt[np.flatnonzero(np.cumsum(cnt) > max_out)].sum() == 0
+
+    st = orc.unpack(g, sh)
+    for k in ("opt_pos", "opt_rot", "opt_scale"):
+        st[k][:, 4:] = rng.uniform(0.1, 1.0, (n, 8)).astype(np.float32)
+    st["opt_opacity"][:, 1:] = rng.uniform(0.1, 1.0, (n, 2)).astype(np.float32)
+    st["state_sh"][:] = rng.uniform(0.1, 1.0, (n, 96)).astype(np.float32)
+    st["opt_pos"][:, 0:3] += rng.normal(0, 1e-3, (n, 3)).astype(np.float32)   # masters differ from the fp16 copy (Q17)
+    out_n = prep["total"]
+    og, osh, ost = orc.densify_scatter(g, sh, st, prep, out_n)
+
+    src = np.repeat(np.arange(n), cnt)
+    dst = np.arange(out_n)
+    variant = dst - off[src]
+    a = act[src]
+    # ---- working copy (fp16): perturbed from the fp16 values
+    want_pos, want_ls = _densify_children_fp64(gs["pos"][src], gs["quat"][src], gs["log_scale"][src], src, dst, a, variant)
+    clamp = sig[src] > 0.8
+    want_op = np.where(clamp, 1.38629436112, gs["opacity_raw"][src])
+    got = ind.unpack_gaussians(og)
+    moved = (a == 2) | ((a == 1) & (variant == 1))
+    # (a child coordinate that lands near zero is the difference of two O(1) float32 numbers: there one fp16 ulp is below float32's
+    # own rounding, and the absolute error is what counts)
+    assert ((ind.f16_ulp_distance(ind.f16_bits(got["pos"]), ind.f16_bits(want_pos)) <= 1) | (np.abs(got["pos"] - want_pos) < 2e-6)).all()
+    assert np.array_equal(got["pos"][~moved], gs["pos"][src][~moved])                               # verbatim where nothing moves
+    assert ind.f16_ulp_distance(ind.f16_bits(got["log_scale"]), ind.f16_bits(want_ls)).max() <= 1
+    assert np.array_equal(got["log_scale"][a != 2], gs["log_scale"][src][a != 2])
+    assert np.array_equal(ind.f16_bits(got["opacity_raw"]), ind.f16_bits(want_op))
+    assert np.array_equal(got["quat"], gs["quat"][src]) and np.array_equal(osh, sh[src])
+    d = np.linalg.norm(got["pos"] - gs["pos"][src], axis=1)
+    assert d[moved].min() > 0 and (d[(a == 2)] > 0).all()
+    # ---- fp32 masters: the same perturbation from the MASTER position / rotation / scale; moments carried or reset
+    m_pos, m_ls = _densify_children_fp64(st["opt_pos"][src, 0:3].astype(np.float64), st["opt_rot"][src, 0:4].astype(np.float64),
+                                         st["opt_scale"][src, 0:3].astype(np.float64), src, dst, a, variant)
+    assert np.abs(ost["opt_pos"][:, 0:3] - m_pos).max() < 2e-6 * max(1.0, np.abs(m_pos).max())
+    want_scale = st["opt_scale"][src, 0:3].astype(np.float64) - np.where(a == 2, 0.4700036292457356, 0.0)[:, None]
+    assert np.abs(ost["opt_scale"][:, 0:3] - want_scale).max() < 2e-6
+    assert np.array_equal(ost["opt_rot"][:, 0:4], st["opt_rot"][src, 0:4]) and np.array_equal(ost["param_sh"], st["param_sh"][src])
+    new = (variant == 1) | (a == 2)
+    for k in ("opt_pos", "opt_rot", "opt_scale"):
+        assert np.all(ost[k][new, 4:] == 0) and np.array_equal(ost[k][~new, 4:], st[k][src][~new, 4:]), k
+    assert np.all(ost["state_sh"][new] == 0) and np.array_equal(ost["state_sh"][~new], st["state_sh"][src][~new])
+    assert np.all(ost["opt_opacity"][:, 1:] == 0)                                                       # Q16: opacity moments always zeroed
+    m_sig = ind.sigmoid(st["opt_opacity"][src, 0].astype(np.float64))
+    assert np.array_equal(ost["opt_opacity"][:, 0], np.where(m_sig > 0.8, np.float32(1.38629436112), st["opt_opacity"][src, 0]))
