@@ -314,7 +314,8 @@ static void read_backward_resources(napi_env env, napi_value o, wdgs_tiled_backw
 }
 static napi_value tiledBackwardMetric(napi_env env, napi_callback_info info) {
     // (op, stage, a, b, c): 0 computeLossOnly(pred, target) | 1 computeMetricMap(pred, target, threshold) |
-    //                       2 computeMetricCounts(resources, numInstances, clear) | 3 normalizeMetricCounts(divisor) | 4 setViewport(w, h)
+    //                       2 computeMetricCounts(resources, numInstances, clear) | 3 normalizeMetricCounts(divisor) | 4 setViewport(w, h) |
+    //                       5 setTrainingConfig(config)
     ARGS(5);
     wdgs_tiled_backward* op = (wdgs_tiled_backward*)get_ptr(env, argv[0]);
     switch (get_u32(env, argv[1])) {
@@ -327,6 +328,16 @@ static napi_value tiledBackwardMetric(napi_env env, napi_callback_info info) {
             break;
         }
         case 3: WDGS_OK_OR_THROW(wdgs_tiled_backward_normalize_metric_counts(op, get_u32(env, argv[2]))); break;
+        case 5: {  // setTrainingConfig({lambda_l1, lambda_l2, lambda_dssim, c1, c2}): the complete config (tiled-backward-pass.ts:812-830)
+            wdgs_training_config t;
+            t.lambda_l1 = (float)prop_f64(env, argv[2], "lambda_l1", 0.8);
+            t.lambda_l2 = (float)prop_f64(env, argv[2], "lambda_l2", 0.0);
+            t.lambda_dssim = (float)prop_f64(env, argv[2], "lambda_dssim", 0.2);
+            t.c1 = (float)prop_f64(env, argv[2], "c1", 0.0001);
+            t.c2 = (float)prop_f64(env, argv[2], "c2", 0.0009);
+            WDGS_OK_OR_THROW(wdgs_tiled_backward_set_training_config(op, &t));
+            break;
+        }
         default: WDGS_OK_OR_THROW(wdgs_tiled_backward_set_viewport(op, get_u32(env, argv[2]), get_u32(env, argv[3]))); break;
     }
     return js_undefined(env);

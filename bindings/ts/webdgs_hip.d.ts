@@ -50,7 +50,7 @@ export class PrefixScanner {             // src/prefix/prefix.ts:26-43
 export function get_prefix_scanner(maxElements: number, device: HipDevice): PrefixScanner;
 export class DynamicSortStuff {          // src/sort/sort_dynamic.ts:9-24
   readonly capacity: number; final_out_index: number;
-  readonly ping_pong: Array<{ sort_depths_buffer: HipBuffer; sort_indices_buffer: HipBuffer }>;
+  readonly ping_pong: { sort_depths_buffer: HipBuffer; sort_indices_buffer: HipBuffer }[];
   sort(encoder: HipEncoder | null, keyBits?: number): void;
   destroy(): void;
 }
@@ -81,7 +81,8 @@ export class TiledRasterizer {
   constructor(config: { device: HipDevice; forwardPass: TiledForwardPass; format?: string });
   encode(encoder: HipEncoder | null, width: number, height: number): void;
   getOutputTextureView(): HipBuffer; getAlphaTextureView(): HipBuffer; getNContribTextureView(): HipBuffer; getTileOffsetsBuffer(): HipBuffer;
-  blitToTexture(encoder: HipEncoder | null, target: HipBuffer, width?: number, height?: number): void;
+  /** `target` may carry its own `width` / `height` (a canvas of another size); the clear colour is accepted for signature compatibility only. */
+  blitToTexture(encoder: HipEncoder | null, target: HipBuffer & { width?: number; height?: number }, clearColor?: { r: number; g: number; b: number; a: number }): void;
   destroy(): void;
 }
 export interface TrainingConfig { lambda_l1: number; lambda_l2: number; lambda_dssim: number; c1?: number; c2?: number; }  // tiled-backward-pass.ts:19-25
@@ -90,7 +91,9 @@ export interface TiledBackwardResources {  // tiled-backward-pass.ts:40-50
 }
 export class TiledBackwardPass {
   constructor(device: HipDevice, pointCloud: PointCloud, config: { viewportWidth: number; viewportHeight: number; trainingConfig: TrainingConfig; maxSplatRadiusPx?: number });
-  encode(encoder: HipEncoder | null, predictedTexture: HipBuffer, targetTexture: HipBuffer, resources: TiledBackwardResources): void;
+  encode(encoder: HipEncoder | null, predictedTexture: HipBuffer, targetTexture: HipBuffer, resources: TiledBackwardResources, options?: {}): void;
+  setTrainingConfig(next: Partial<TrainingConfig>): void;
+  getMetricMapTexture(): HipBuffer;
   computeLossOnly(encoder: HipEncoder | null, predicted: HipBuffer, target: HipBuffer): void;
   computeMetricMap(encoder: HipEncoder | null, predicted: HipBuffer, target: HipBuffer, options?: { threshold?: number }): void;
   computeMetricCounts(encoder: HipEncoder | null, resources: TiledBackwardResources, options?: { clear?: boolean; numInstances?: number }): void;
@@ -131,13 +134,16 @@ export class DensifyPrunePass {
   encodeDecision(encoder: HipEncoder | null, inputs: { pointCloud: PointCloud; metricCountsBuffer?: HipBuffer }): { actionBuffer: HipBuffer; outCountBuffer: HipBuffer };
   encodePrefixSum(encoder: HipEncoder | null): HipBuffer;
   encodeCapToMax(encoder: HipEncoder | null, outOffsetBuffer: HipBuffer, maxOutPoints: number): void;
-  encodeTotalOut(encoder: HipEncoder | null, outOffsetBuffer?: HipBuffer): HipBuffer;
+  encodeTotalOut(encoder: HipEncoder | null, outOffsetBuffer: HipBuffer | null): HipBuffer;
+  getActionBuffer(): HipBuffer | null;
+  getOutCountBuffer(): HipBuffer | null;
+  getOutTotalBuffer(): HipBuffer;
   encodePrepare(encoder: HipEncoder | null, inputs: { pointCloud: PointCloud; metricCountsBuffer?: HipBuffer }): DensifyPrunePrepared;
   readTotal(): number;
   encodeScatter(encoder: HipEncoder | null,
                 inputs: { pointCloud: PointCloud; optimizerState?: OptimizerStateBuffers; outOffsetBuffer: HipBuffer; outNumPoints: number; resetNewOptimizerState?: boolean },
                 outputs: { outPointCloud: PointCloud; outOptimizerState?: OptimizerStateBuffers }): void;
-  applyActions(): never;
+  applyActions(encoder: HipEncoder | null): never;
   destroy(): void;
 }
 export function downsampleRGBA8(device: HipDevice, src: HipBuffer, srcW: number, srcH: number, dst: HipBuffer, dstW: number, dstH: number): void;

@@ -167,8 +167,10 @@ class TiledRasterizer {                  // tiled-rasterizer.ts:34
   getAlphaTextureView() { return this.device.view(addon.tiledRasterizerGet(this.handle, 1), 4 * this.w * this.h); }
   getNContribTextureView() { return this.device.view(addon.tiledRasterizerGet(this.handle, 2), 4 * this.w * this.h); }
   getTileOffsetsBuffer() { return this.device.view(addon.tiledRasterizerGet(this.handle, 3), 4 * (Math.ceil(this.w / 16) * Math.ceil(this.h / 16) + 1)); }
-  /** blitToTexture(encoder, targetView): `target` is an rgba8 image buffer of width x height (default: the rasterizer's size). */
-  blitToTexture(_encoder, target, width, height) { addon.tiledRasterizerBlit(this.handle, target.ptr, dflt(width, this.w), dflt(height, this.h)); }
+  /** blitToTexture(encoder, targetView, clearColor?) (tiled-rasterizer.ts:333-357): `target` is an rgba8 image buffer; it may carry its own
+   *  `width` / `height` (a canvas of another size: the blit is a bilinear resample), otherwise it has the rasterizer's size.  The blit covers
+   *  the whole target, so the reference's clear colour never shows and is accepted only for signature compatibility. */
+  blitToTexture(_encoder, target, _clearColor) { addon.tiledRasterizerBlit(this.handle, target.ptr, dflt(target.width, this.w), dflt(target.height, this.h)); }
   destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledRasterizerDestroy(this.handle); }
 }
 
@@ -182,9 +184,15 @@ class TiledBackwardPass {                // tiled-backward-pass.ts:71
     this.handle = addon.tiledBackwardCreate(device.handle, { numPoints: pointCloud.num_points, shDeg: pointCloud.sh_deg || 0, viewportWidth: config.viewportWidth,
       viewportHeight: config.viewportHeight, lambda_l1: t.lambda_l1, lambda_l2: t.lambda_l2, lambda_dssim: t.lambda_dssim, c1: dflt(t.c1, 0.0001), c2: dflt(t.c2, 0.0009),
       maxSplatRadiusPx: dflt(config.maxSplatRadiusPx, 128.0) });
+    this.trainingConfig = { lambda_l1: t.lambda_l1, lambda_l2: t.lambda_l2, lambda_dssim: t.lambda_dssim, c1: dflt(t.c1, 0.0001), c2: dflt(t.c2, 0.0009) };
   }
-  encode(_encoder, predictedTexture, targetTexture, r) {
+  encode(_encoder, predictedTexture, targetTexture, r, _options) {   // (TiledBackwardPassOptions is an empty interface in the reference)
     addon.tiledBackwardEncode(this.handle, predictedTexture.ptr, targetTexture.ptr, resourcePtrs(r), this.pointCloud.gaussian_3d_buffer.ptr);
+  }
+  /** setTrainingConfig(next) (tiled-backward-pass.ts:812-830): loss weights of the next encode. */
+  setTrainingConfig(next) {
+    this.trainingConfig = Object.assign({ lambda_l1: 0.8, lambda_l2: 0.0, lambda_dssim: 0.2, c1: 0.0001, c2: 0.0009 }, this.trainingConfig || {}, next || {});
+    addon.tiledBackwardMetric(this.handle, 5, this.trainingConfig, 0, 0);
   }
   /** See TiledForwardPass.setPointCloud (wdgs_tiled_backward_resize). */
   setPointCloud(pointCloud) {
@@ -202,6 +210,7 @@ class TiledBackwardPass {                // tiled-backward-pass.ts:71
   getMetricCountsBuffer() { return this.device.view(addon.tiledBackwardGet(this.handle, 1), 4 * Math.max(1, this.pointCloud.num_points)); }
   getLossTextureView() { return this.device.view(addon.tiledBackwardGet(this.handle, 2), 16 * this.w * this.h); }
   getMetricMapTextureView() { return this.device.view(addon.tiledBackwardGet(this.handle, 3), 4 * this.w * this.h); }
+  getMetricMapTexture() { return this.getMetricMapTextureView(); }   // (texture and view are the same r32uint image buffer here)
   destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledBackwardDestroy(this.handle); }
 }
 
@@ -293,7 +302,10 @@ class DensifyPrunePass {                 // densify-prune.ts:75
       inputs.optimizerState ? statePtrs(inputs.optimizerState) : null, inputs.outNumPoints, inputs.resetNewOptimizerState === false ? 0 : 1,
       outputs.outPointCloud.gaussian_3d_buffer.ptr, outputs.outPointCloud.sh_buffer.ptr, outputs.outOptimizerState ? statePtrs(outputs.outOptimizerState) : null);
   }
-  applyActions() { throw new Error('DensifyPrunePass.applyActions is unimplemented in the reference (densify-prune.ts:680-686)'); }
+  getActionBuffer() { return this.numPoints ? this.stage(4, this.numPoints).actionBuffer : null; }        // densify-prune.ts getters: null before ensureSize
+  getOutCountBuffer() { return this.numPoints ? this.stage(4, this.numPoints).outCountBuffer : null; }
+  getOutTotalBuffer() { return this.stage(4, Math.max(1, this.numPoints)).outTotalBuffer; }
+  applyActions(_encoder) { throw new Error('DensifyPrunePass.applyActions is unimplemented in the reference (densify-prune.ts:680-686)'); }
   destroy() { if (this.handle !== null) { addon.densifyDestroy(this.handle); this.handle = null; } }
 }
 

@@ -354,21 +354,29 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 ntx = ti.num_tiles_x;
     u32 cnt = 0u, ox = 0u, oy = 0u, width = 1u, depth16 = 0u;
-    if (idx < n) {
-        const u32 num_tiles = tile_counts[idx];
-        if (num_tiles != 0u) {
-            const uint2 w01 = *reinterpret_cast<const uint2*>(splats + (size_t)idx * 6);
-            const vec2 ndc = V2(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x));
-            const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
-            const vec2 ext = V2(wd_min(wd_unpack_lo(w01.y), cap), wd_min(wd_unpack_hi(w01.y), cap));
-            const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
-            const TileBox tb = tile_box(ndc, ext, viewport, ti.num_tiles_x, ti.num_tiles_y, false);
-            if (tb.valid) {  // the same box project_count counted
-                width = tb.max_x - tb.min_x + 1u;
-                cnt = width * (tb.max_y - tb.min_y + 1u);
-                ox = tb.min_x; oy = tb.min_y;
-                depth16 = depths[idx] >> 16u;
-            }
+    // everything this workgroup reads from memory is requested up front, in ONE round trip: the tile count, the Splat's first 8 bytes and
+    // the depth of every Gaussian (also of the ~7 % that turn out to be invisible: the rows exist, their content is ignored), the
+    // workgroup's offset and this thread's column total / offset.  Fetching Splat and depth behind the tests on the count was three
+    // dependent HBM round trips of ~2 us each on a kernel whose waves live ~9 us (profiles/r03c_pmc.json).
+    const u32 col = threadIdx.x;
+    const bool in_range = idx < n;
+    const u32 num_tiles = in_range ? tile_counts[idx] : 0u;
+    const uint2 w01 = in_range ? *reinterpret_cast<const uint2*>(splats + (size_t)idx * 6) : make_uint2(0u, 0u);
+    const u32 depth_all = in_range ? depths[idx] : 0u;
+    const u32 tot_c = (col < ntx) ? column_totals[col] : 0u;
+    const u32 off_c = (col < ntx) ? column_offsets[(size_t)col * gridDim.x + wg] : 0u;
+    const u32 wg_offset = block_offsets[wg];
+    if (num_tiles != 0u) {
+        const vec2 ndc = V2(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x));
+        const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+        const vec2 ext = V2(wd_min(wd_unpack_lo(w01.y), cap), wd_min(wd_unpack_hi(w01.y), cap));
+        const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+        const TileBox tb = tile_box(ndc, ext, viewport, ti.num_tiles_x, ti.num_tiles_y, false);
+        if (tb.valid) {  // the same box project_count counted
+            width = tb.max_x - tb.min_x + 1u;
+            cnt = width * (tb.max_y - tb.min_y + 1u);
+            ox = tb.min_x; oy = tb.min_y;
+            depth16 = depth_all >> 16u;
         }
     }
     // exclusive prefix of the counts over the workgroup
@@ -381,9 +389,6 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
     if (lane == 63u) s_wsum[wave] = inc;
     // global start of column c for this workgroup: exclusive scan of the column totals (done by every workgroup: a dozen instructions,
     // instead of a one-workgroup kernel in between) + the workgroup's offset inside the column
-    const u32 col = threadIdx.x;
-    const u32 tot_c = (col < ntx) ? column_totals[col] : 0u;
-    const u32 off_c = (col < ntx) ? column_offsets[(size_t)col * gridDim.x + wg] : 0u;
     u32 tinc = tot_c;
 #pragma unroll
     for (u32 d = 1; d < 64; d <<= 1) {
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
         tbase += (w < wave) ? s_tsum[w] : 0u;
     }
     const u32 pre = woff + inc - cnt;
-    if (idx < n) tile_offsets[idx] = block_offsets[wg] + pre;
+    if (idx < n) tile_offsets[idx] = wg_offset + pre;
     if (total == 0u) return;  // (uniform)
     s_pre[threadIdx.x] = pre;
     s_box[threadIdx.x] = ox | (oy << 8u) | (width << 16u);

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     }
     if (base >= count) return;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (requested here, with the keys, although they are used after the ranking: behind the barriers below they would be a second
+    // dependent memory round trip in the middle of a workgroup whose whole life is ~15 us)
+    const u32 tot_d_early = (threadIdx.x <= dmask) ? digit_totals[threadIdx.x] : 0u;  // (rows above the digit range are neither counted nor scanned)
+    const u32 off_d_early = (threadIdx.x <= dmask) ? offsets[(size_t)threadIdx.x * num_parts + part] : 0u;
 #pragma unroll
     for (u32 w = 0; w < SORT_THREADS / 64; w++) whist[w][threadIdx.x] = 0;
     __syncthreads();
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         const u32 local_start = woff + inc - cnt_d;
         // global base of digit d = exclusive scan of the 256 digit totals, done here by every block (a dozen instructions)
         // rather than by a 1-block kernel between the row scan and the scatter (a 4.5 us bubble per pass)
-        const u32 tot_d = (d <= dmask) ? digit_totals[d] : 0u;  // (rows above the digit range are neither counted nor scanned)
+        const u32 tot_d = tot_d_early;
         u32 tinc = tot_d;
 #pragma unroll
         for (u32 s = 1; s < 64; s <<= 1) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         u32 tbase = tinc - tot_d;
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) if (w < wave) tbase += s_wsum[w];
-        s_gdelta[d] = tbase + ((d <= dmask) ? offsets[(size_t)d * num_parts + part] : 0u) - local_start;
+        s_gdelta[d] = tbase + off_d_early - local_start;
         u32 run = local_start;   // per-wave start of digit d inside the partition's sorted order
 #pragma unroll
         for (u32 w = 0; w < SORT_THREADS / 64; w++) {
@@ -457,20 +461,14 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
     __shared__ seg_hist_t whist[SEG_THREADS / 64][SEG_BINS];
     __shared__ u32 s_base[RADIX];
     __shared__ u32 s_wsum[SEG_THREADS / 64];
-    __shared__ u32 s_end;
     __shared__ u32 s_min[SEG_THREADS / 64], s_max[SEG_THREADS / 64];
     const u32 t = blockIdx.x;
     const u32 start = ranges[t];
+    u32 end = ranges[t + 1u];          // (requested together with `start`: one round trip)
     if (start == 0xFFFFFFFFu) return;  // empty tile (uniform per workgroup)
-    // end of the segment = start of the next non-empty tile (ranges[T] = E ends the walk)
-    if (threadIdx.x == 0u) {
-        u32 nx = t + 1u;
-        u32 e = ranges[nx];
-        while (e == 0xFFFFFFFFu && nx < total_tiles) { nx++; e = ranges[nx]; }
-        s_end = e;
-    }
-    __syncthreads();
-    const u32 end = s_end;
+    // end of the segment = start of the next non-empty tile (ranges[T] = E ends the walk): the successor itself unless it is empty, in
+    // which case every thread walks on (uniform addresses: the same few loads for the whole workgroup, no barrier)
+    for (u32 nx = t + 1u; end == 0xFFFFFFFFu && nx < total_tiles;) { nx++; end = ranges[nx]; }
     if (end <= start + 1u || end == 0xFFFFFFFFu) return;
     const u32 n = end - start;
     if (n <= SEG_CAP) {

@@ -541,6 +541,10 @@ class TiledBackwardPass:
     def getMetricMapTextureView(self) -> HipBuffer:
         return self.device.view(self.device.lib.wdgs_tiled_backward_metric_map(self.handle), 4 * self.viewportWidth * self.viewportHeight)
 
+    def getMetricMapTexture(self) -> HipBuffer:
+        """``getMetricMapTexture`` (tiled-backward-pass.ts): texture and view are the same r32uint image buffer here."""
+        return self.getMetricMapTextureView()
+
     def getAccumulatorsBuffer(self) -> HipBuffer:
         """INTERNAL (parity tests): i32[N*12] fixed-point accumulators of the last encode."""
         return self.device.view(self.device.lib.wdgs_tiled_backward_accumulators(self.handle), 48 * max(1, self.pointCloud.num_points))
@@ -768,6 +772,12 @@ class DensifyPrunePass:
 
     def getOutTotalBuffer(self) -> HipBuffer:
         return self._buffers()["outTotalBuffer"]
+
+    def getActionBuffer(self) -> HipBuffer:
+        return self._buffers()["actionBuffer"]
+
+    def getOutCountBuffer(self) -> HipBuffer:
+        return self._buffers()["outCountBuffer"]
 
     def readTotal(self) -> int:
         t = C.c_uint32(0)
