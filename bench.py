@@ -248,6 +248,7 @@ class TrainingSnapshot:
         self.t = trainer
         dev = trainer.device
         pc = trainer.pointCloud
+        trainer.flushPointCloud()                          # (deferred SH-DC halves -> the cloud's rows, which are what is copied)
         bufs = dict(trainer.optimizer.getStateBuffers())  # (flushes the compact SH-DC copy into paramSH / stateSH first)
         bufs.update(gaussians=pc.gaussian_3d_buffer, sh=pc.sh_buffer)
         self.views = {k: parallel._tensor_at(dev, b.ptr, b.size, __import__("torch").uint8) for k, b in bufs.items() if b.size > 0}
@@ -258,9 +259,12 @@ class TrainingSnapshot:
     def restore(self) -> None:
         t = self.t
         t.drain()
+        t.flushPointCloud()
         for k, v in self.views.items():
             v.copy_(self.copies[k])
         t.optimizer.stateChanged()  # the compact SH-DC copy is reloaded from paramSH / stateSH
+        if t.deferred_sh:
+            t.optimizer.setDeferredSH(t.pointCloud, True)  # ... and the compact SH-DC halves from the restored rows
         t.optimizer.advanceIteration((self.opt_iteration - t.optimizer.getIteration()) & 0xFFFFFFFF)
         t.iteration = self.iteration
         t._rng.setstate(self.rng)

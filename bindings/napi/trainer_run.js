@@ -38,6 +38,7 @@ async function main() {
   if (drawn !== draws.length) throw new Error(`drew ${drawn} views, schedule has ${draws.length}`);
   dev.synchronize();
   const n = t.getPointCount();
+  t.flushPointCloud();   // deferred SH writes: the rows are brought up to date before the host reads them
   fs.writeFileSync(path.join(dir, 'out_gaussians.bin'), Buffer.from(dev.readBuffer(t.pointCloud.gaussian_3d_buffer, n * 24)));
   fs.writeFileSync(path.join(dir, 'out_sh.bin'), Buffer.from(dev.readBuffer(t.pointCloud.sh_buffer, n * 96)));
   const st = t.optimizer.getStateBuffers();

@@ -72,6 +72,7 @@ static void set_prop(napi_env env, napi_value obj, const char* name, napi_value 
     if (argc < n) { napi_throw_type_error(env, nullptr, "too few arguments"); return nullptr; }
 
 static napi_value js_undefined(napi_env env) { napi_value v; napi_get_undefined(env, &v); return v; }
+static napi_value js_null(napi_env env) { napi_value v; napi_get_null(env, &v); return v; }
 
 // ---- device / queue ---------------------------------------------------------------------------------------------
 static napi_value abiVersion(napi_env env, napi_callback_info) { return make_u32(env, (uint32_t)wdgs_abi_version()); }
@@ -629,6 +630,24 @@ static napi_value optimizerSetGuard(napi_env env, napi_callback_info info) {  //
     WDGS_OK_OR_THROW(wdgs_optimizer_set_guard((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1])));
     return js_undefined(env);
 }
+// ---- deferred SH writes (include/webdgs.h: wdgs_optimizer_set_deferred_sh)
+static napi_value optimizerDeferredSH(napi_env env, napi_callback_info info) {  // (optimizer, shPtr, enabled) -> dcWordsPtr | null
+    ARGS(3);
+    wdgs_optimizer* op = (wdgs_optimizer*)get_ptr(env, argv[0]);
+    WDGS_OK_OR_THROW(wdgs_optimizer_set_deferred_sh(op, get_ptr(env, argv[1]), (int)get_u32(env, argv[2])));
+    void* w = wdgs_optimizer_dc_words(op);
+    return w ? make_ptr(env, w) : js_null(env);
+}
+static napi_value optimizerFlushSH(napi_env env, napi_callback_info info) {  // (optimizer, shPtr)
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_optimizer_flush_sh((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1])));
+    return js_undefined(env);
+}
+static napi_value tiledForwardSetDcSource(napi_env env, napi_callback_info info) {  // (forward, dcWordsPtr | null)
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_tiled_forward_set_dc_source((wdgs_tiled_forward*)get_ptr(env, argv[0]), get_ptr(env, argv[1])));
+    return js_undefined(env);
+}
 static napi_value optimizerStepF32Range(napi_env env, napi_callback_info info) {  // (optimizer, gaussiansPtr, shPtr, gradF32Ptr, visiblePtr, first, count, rowsPtr | null)
     ARGS(8);
     WDGS_OK_OR_THROW(wdgs_optimizer_step_f32_range((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), get_ptr(env, argv[3]),
@@ -700,6 +719,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(densifyDestroy);
     EXPORT_FN(commUniqueId); EXPORT_FN(commCreate); EXPORT_FN(commAllreduceGradients); EXPORT_FN(commAllreduceCounts); EXPORT_FN(commDestroy);
     EXPORT_FN(encoderAbort); EXPORT_FN(hostAlloc); EXPORT_FN(bufferReadAsync); EXPORT_FN(prefixScanner); EXPORT_FN(dynamicSorter);
+    EXPORT_FN(optimizerDeferredSH); EXPORT_FN(optimizerFlushSH); EXPORT_FN(tiledForwardSetDcSource);
     EXPORT_FN(optimizerSetGuard); EXPORT_FN(optimizerStepF32Range); EXPORT_FN(optimizerStateChanged); EXPORT_FN(storeGradients); EXPORT_FN(guardAccumulate);
     EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder); EXPORT_FN(queueMark); EXPORT_FN(queueWait); EXPORT_FN(tiledForwardResize); EXPORT_FN(tiledBackwardResize);
     EXPORT_FN(applyRepackedRows); EXPORT_FN(commExchangeGradients); EXPORT_FN(commAllgatherRows); EXPORT_FN(commBroadcast); EXPORT_FN(commInfo);

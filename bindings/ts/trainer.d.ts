@@ -11,7 +11,9 @@ export interface TrainingImage { texture: HipBuffer; width: number; height: numb
 export interface PointCloudSwapRequest { pointCloud: PointCloud; optimizerInitialState?: OptimizerInitialState; }
 
 export class Trainer {
-  constructor(device: HipDevice, trainingConfig?: TrainingConfig, options?: { random?: () => number; useCommandBuffers?: boolean; maxTileEntries?: number; reusePasses?: boolean });
+  constructor(device: HipDevice, trainingConfig?: TrainingConfig, options?: { random?: () => number; useCommandBuffers?: boolean; maxTileEntries?: number; reusePasses?: boolean; deferredSH?: boolean });
+  /** Deferred SH writes: brings pointCloud.sh_buffer up to date before a host read, an export, or a foreign forward pass (no reference counterpart). */
+  flushPointCloud(): void;
   random: () => number;
   setPointCloud(pointCloud: PointCloud): void;
   requestPointCloudSwap(pointCloud: PointCloud, optimizerInitialState?: OptimizerInitialState): void;

@@ -86,6 +86,10 @@ class Trainer {
     this.useCommandBuffers = !(options && options.useCommandBuffers === false);
     this.maxTileEntries = (options && options.maxTileEntries) || 0;
     this.reusePasses = !(options && options.reusePasses === false);   // applyPointCloudSwap resizes the passes instead of rebuilding them
+    // Adam writes the trained SH-DC halves to a compact array that K1 reads instead of 6 bytes into every 96-byte SH row (Optimizer.setDeferredSH);
+    // the rows are flushed at hand-over points (flushPointCloud).  Results are identical either way.
+    this.deferredSH = !(options && options.deferredSH === false);
+    this.dcWords = null;
     this.forwardPass = null; this.rasterizer = null; this.backwardPass = null; this.optimizer = null; this.pointCloud = null;
     this.metricsForwardPass = null; this.metricsRasterizer = null; this.metricsPass = null;
     this.metricsViewportWidth = 0; this.metricsViewportHeight = 0; this.metricsTarget = null;
@@ -131,9 +135,14 @@ class Trainer {
     }
     this.optimizer = new hip.Optimizer(this.device, this.pointCloud, oldParams || this.optimizerHyperparameters, request.optimizerInitialState);
     this.optimizerHyperparameters = this.optimizer.getHyperparameters();
+    this.dcWords = this.deferredSH ? this.optimizer.setDeferredSH(this.pointCloud, true) : null;
+    for (const fw of [this.forwardPass, this.metricsForwardPass]) if (fw) fw.setDcSource(this.dcWords);
     if (old && old !== this.pointCloud) { old.gaussian_3d_buffer.destroy(); old.sh_buffer.destroy(); }
     this.ensurePipelines(this.lastViewportWidth, this.lastViewportHeight);
   }
+  /** Brings pointCloud.sh_buffer up to date with what has been trained (deferred SH writes): call before reading the cloud's SH buffer on the
+   *  host, exporting it, or rendering it with a forward pass that is not this trainer's. */
+  flushPointCloud() { if (this.optimizer && this.pointCloud) this.optimizer.flushSH(this.pointCloud); }
   /** cameras[i] pairs with images[i] (trainer.ts:575-577): { camera: Float32Array(68), width, height } and { texture: HipBuffer, width, height }. */
   setDataset(cameras, images) {
     this.trainCameras = cameras.slice(); this.images = images.slice();
@@ -193,6 +202,7 @@ class Trainer {
     const cam = this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer;
     if (!this.forwardPass) {
       this.forwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+      this.forwardPass.setDcSource(this.dcWords);
     } else this.forwardPass.setViewport(w, h);
     if (!this.rasterizer) this.rasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.forwardPass, format: 'rgba8unorm' });
     if (!this.backwardPass || this.recreateBackward) {
@@ -212,6 +222,7 @@ class Trainer {
     if (this.metricsTarget) this.metricsTarget.destroy();
     this.metricsViewportWidth = w; this.metricsViewportHeight = h;
     this.metricsForwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, this.metricsCameraBuffer, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+    this.metricsForwardPass.setDcSource(this.dcWords);
     this.metricsRasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.metricsForwardPass, format: 'rgba8unorm' });
     this.metricsPass = new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig });
     this.metricsTarget = this.device.createBuffer({ size: 4 * w * h, label: 'metrics-gt-downsampled' });
@@ -314,6 +325,7 @@ class Trainer {
     const inN = this.pointCloud.num_points;
     const outN = Math.min(outTotal, prepared.maxOutPoints);
     if (outN === 0 || outN === inN) return;
+    this.flushPointCloud();   // the rebuild copies the cloud's SH rows: bring the deferred DC halves in first
     const outPointCloud = hip.allocatePointCloudLike(this.device, this.pointCloud, { numPoints: outN });
     const outOptimizerState = hip.allocateOptimizerStateBuffers(this.device, outN);
     const scatterEncoder = this.device.createCommandEncoder({ label: 'densify-prune scatter' });

@@ -71,6 +71,8 @@ export class TiledForwardPass {
   setCameraBuffer(buffer: HipBuffer): void;
   /** Resize instead of rebuild (include/webdgs.h wdgs_tiled_forward_resize); false if the SH degree differs. */
   setPointCloud(pointCloud: PointCloud): boolean;
+  /** K1 takes the SH-DC halves from the optimizer's compact array (Optimizer.setDeferredSH); null restores the rows. */
+  setDcSource(dcWords: HipBuffer | null): void;
   setRenderMode(mode: RenderMode): void; setPointSize(value: number): void; setGaussianScale(value: number): void; setViewport(width: number, height: number): void;
   getResources(): TiledForwardResources;
   getSortedIndicesBuffer(): HipBuffer; getSortedKeysBuffer(): HipBuffer; getTileOffsetsBuffer(): HipBuffer; getStatsBuffer(): HipBuffer;
@@ -116,6 +118,9 @@ export class Optimizer {
   getIteration(): number; getHyperparameters(): AdamHyperparameters; setHyperparameters(next: Partial<AdamHyperparameters>): void;
   getStateBuffers(): OptimizerStateBuffers;
   step(encoder: HipEncoder | null, coefficients: PointCloud, gradientsBuffer: HipBuffer, tileCountsBuffer: HipBuffer): void;
+  /** Deferred SH writes (include/webdgs.h wdgs_optimizer_set_deferred_sh); no reference counterpart. */
+  setDeferredSH(pointCloud: PointCloud, enabled?: boolean): HipBuffer | null;
+  flushSH(pointCloud: PointCloud): void;
   setGuard(flagBuffer: HipBuffer | null, offset?: number): void;
   advanceIteration(count?: number): void;
   destroy(): void;

@@ -129,6 +129,8 @@ class TiledForwardPass {                 // tiled-forward-pass.ts:62
     });
   }
   get nativeHandle() { return this.handle; }
+  /** K1 takes the SH-DC halves from the optimizer's compact array (Optimizer.setDeferredSH) instead of the cloud's rows; null restores the rows. */
+  setDcSource(dcWords) { this.dcSource = dcWords || null; addon.tiledForwardSetDcSource(this.handle, dcWords ? dcWords.ptr : null); }
   encode(_encoder, options) {
     addon.tiledForwardEncode(this.handle, this.pointCloud.gaussian_3d_buffer.ptr, this.pointCloud.sh_buffer.ptr, this.cameraBuffer.ptr, options && options.skipSort ? 1 : 0);
   }
@@ -252,6 +254,17 @@ class Optimizer {                        // optimizer.ts:40
   step(_encoder, coefficients, gradientsBuffer, tileCountsBuffer) {
     addon.optimizerStep(this.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradientsBuffer.ptr, tileCountsBuffer.ptr);
   }
+  /** Deferred SH writes (include/webdgs.h wdgs_optimizer_set_deferred_sh): on, step() writes the trained SH-DC halves to a compact array
+   *  (returned: give it to every forward pass that renders the cloud, TiledForwardPass.setDcSource) instead of 6 bytes into every 96-byte
+   *  row; flushSH(pointCloud) brings the rows up to date -- call it before anything reads pointCloud.sh_buffer (a host read, an export, a
+   *  viewer's own forward pass, DensifyPrunePass.encodeScatter).  Off: flushes and restores the reference's write pattern. */
+  setDeferredSH(pointCloud, enabled) {
+    const on = enabled !== false;
+    const p = addon.optimizerDeferredSH(this.handle, pointCloud.sh_buffer.ptr, on ? 1 : 0);
+    this.deferredCloud = on ? pointCloud : null;
+    return on && p !== null ? this.device.view(p, 8 * Math.max(1, this.pointCloud.num_points)) : null;
+  }
+  flushSH(pointCloud) { if (!this.destroyed) addon.optimizerFlushSH(this.handle, pointCloud.sh_buffer.ptr); }
   /** While the u32 at `flagBuffer + offset` is non-zero at execution time, step() leaves every buffer untouched (tile-entry overflow). */
   setGuard(flagBuffer, offset) { addon.optimizerSetGuard(this.handle, flagBuffer ? flagBuffer.ptr + BigInt(offset || 0) : null); }
   /** Host-side iteration counter: call when a recorded command buffer containing step() is re-submitted. */
@@ -259,6 +272,7 @@ class Optimizer {                        // optimizer.ts:40
   /** Also destroys adopted state buffers, as the reference's Optimizer.destroy() does (optimizer.ts:352-362). */
   destroy() {
     if (this.destroyed) return;
+    if (this.deferredCloud && !this.deferredCloud.sh_buffer.destroyed) this.setDeferredSH(this.deferredCloud, false);  // the cloud outlives its optimizer: leave its rows current
     this.destroyed = true;
     addon.optimizerDestroy(this.handle);
     if (this.buffers) for (const k of STATE_KEYS) this.buffers[k].destroy();

@@ -358,6 +358,21 @@ int wdgs_apply_repacked_rows(wdgs_device* dev, uint32_t num_points, const void* 
  * TiledForwardResources.stats_buffer + 8 (the overflow word): a step whose tile-entry list was truncated -- it will be reported
  * as WDGS_E_CAPACITY by the next wdgs_device_synchronize -- then does not corrupt the optimizer state first.  NULL removes it. */
 int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag_u32_dev);
+/* Deferred SH writes (no reference counterpart).  update-gaussians.wgsl:59-75 (K19) rewrites the first six bytes of every 96-byte SH row
+ * each step; on HBM a 6-byte store is a read-modify-write of a 64-byte memory word.  With deferral on, the step functions write those
+ * three fp16 halves to a compact array owned by the optimizer (u32[N][2]: r,g | b,0) and leave the rows alone; a forward pass given that
+ * array (wdgs_tiled_forward_set_dc_source) reads the halves from it, so rendering and training see the same values as before.  The rows
+ * are brought up to date by wdgs_optimizer_flush_sh, which the host calls at every hand-over: before the cloud's SH buffer is read by the
+ * host, exported, rendered by a forward pass that has no dc source (a viewer), or copied by DensifyPrunePass.encodeScatter.
+ * `sh_dev` = the point cloud's SH buffer: set_deferred_sh(enabled) takes the current halves from it, (disabled) flushes into it. */
+int wdgs_optimizer_set_deferred_sh(wdgs_optimizer* op, void* sh_dev, int enabled);
+void* wdgs_optimizer_dc_words(wdgs_optimizer* op);            /* the compact array, or NULL while deferral is off */
+int wdgs_optimizer_flush_sh(wdgs_optimizer* op, void* sh_dev); /* no-op unless deferral is on and a step ran since the last flush */
+/* wdgs_apply_repacked_rows for a replica whose optimizer defers its SH writes (the gathered halves go to the compact array) */
+int wdgs_optimizer_apply_repacked_rows(wdgs_optimizer* op, const void* rows_dev, uint32_t skip_first, uint32_t skip_count, const void* guard_u32_dev,
+                                       void* gaussians_dev, void* sh_dev);
+/* project_count (K1) takes the SH-DC halves from `dc_words_dev` (wdgs_optimizer_dc_words) instead of the rows; NULL restores the rows */
+int wdgs_tiled_forward_set_dc_source(wdgs_tiled_forward* op, const void* dc_words_dev);
 /* flag = (overwrite ? 0 : flag) | (*src != 0): folds the overflow words of the views of a batched step into one guard word. */
 int wdgs_guard_accumulate(wdgs_device* dev, void* flag_u32_dev, const void* src_u32_dev, int overwrite);
 /* The caller rewrote the state arrays (gathered slices from other ranks): refresh the optimizer's internal compact copies. */

@@ -50,6 +50,9 @@ def main():
     entries_total = 0
     hist = np.zeros(65, np.int64)
     rows_it = rows_cull_it = same_all = 0  # 4 independent 4x4 quadrants per wave: iterations = per chunk, the longest quadrant list
+    # lane-per-splat systolic form: the block's KEPT splats sit on lanes (up to 64 at a time, compacted across the
+    # block's chunks), the 64 pixel states rotate through them back to front; a group of k splats takes 64 + k - 1 steps to fill and drain
+    sys_steps = sys_steps_ideal = sys_groups = 0
     chunks = walked = in_box = reach = 0  # per 8x8 block: 64-entry chunks walked, entries walked, entries passing the box test, entries with alpha >= 1/255 somewhere
     for t in tiles:
         a, b = int(ranges[t]), int(ranges[t + 1])
@@ -86,6 +89,11 @@ def main():
                 box = (ent < wmax) & ~((X0 - cx > ex) | (cx - X1 > ex) | (Y0 - cy > ey) | (cy - Y1 > ey))
                 in_box += int(box.sum())
                 reach += int((box & (alpha[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8, :] >= 1.0 / 255.0).any(axis=(0, 1))).sum())
+                kept = int((box & (alpha[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8, :] >= 1.0 / 255.0).any(axis=(0, 1))).sum())
+                full, rest = divmod(kept, 64)
+                sys_groups += full + (1 if rest else 0)
+                sys_steps += full * (64 + 63) + ((64 + rest - 1) if rest else 0)   # every group fills and drains on its own
+                sys_steps_ideal += kept + (63 if kept else 0)                       # groups chained without a bubble (two groups resident): one drain per block
                 blk_act = act[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8, :]
                 blk_alpha = alpha[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8, :] >= 1.0 / 255.0
                 quad = blk_act.reshape(2, 4, 2, 4, -1).any(axis=(1, 3)).reshape(4, -1)          # [quadrant, entry]: a contributing pixel
@@ -107,6 +115,11 @@ def main():
           f"{it['8x8 (now)']} have a contributing pixel; per chunk: {in_box / max(1, chunks):.1f} in box, {reach / max(1, chunks):.1f} kept, {it['8x8 (now)'] / max(1, chunks):.1f} iterations")
     print(f"  four independent 4x4 quadrants per wave (per chunk: the longest quadrant list): {rows_it} iterations ({rows_it / max(1, it['8x8 (now)']):.2f} of now), "
           f"{rows_cull_it} when lists hold what a per-quadrant alpha cull keeps; entries contributing in all four quadrants: {same_all}")
+    now_instr = it["8x8 (now)"] * 125                      # ~125 VALU wave-instructions per (wave, splat) iteration today, 22 of them the butterfly
+    per_step = 125 - 22 + 10 + 9                            # no butterfly; + rotating ~10 registers of pixel state by DPP; + nine register accumulations
+    print(f"  lane-per-splat systolic form: {sys_groups} groups of <= 64 kept splats, {sys_steps} steps ({sys_steps_ideal} if groups of a block chain without a bubble) "
+          f"x ~{per_step} VALU = {sys_steps * per_step / 1e6:.2f} M ({sys_steps_ideal * per_step / 1e6:.2f} M) wave-instructions vs {now_instr / 1e6:.2f} M today: "
+          f"{sys_steps * per_step / max(1, now_instr):.2f}x ({sys_steps_ideal * per_step / max(1, now_instr):.2f}x)")
     c = np.cumsum(hist) / max(1, hist.sum())
     print("  8x8: share of iterations with <= k contributing pixels: " + ", ".join(f"k={k}: {c[k]:.2f}" for k in (1, 2, 4, 8, 16, 32, 48, 63)))
 

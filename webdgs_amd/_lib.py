@@ -138,6 +138,11 @@ SIGNATURES = {
     "wdgs_optimizer_step_f32_range": (_I, [_P, _P, _P, _P, _P, _U, _U, _P]),
     "wdgs_apply_repacked_rows": (_I, [_P, _U, _P, _U, _U, _P, _P, _P]),
     "wdgs_optimizer_set_guard": (_I, [_P, _P]),
+    "wdgs_optimizer_set_deferred_sh": (_I, [_P, _P, _I]),
+    "wdgs_optimizer_dc_words": (_P, [_P]),
+    "wdgs_optimizer_flush_sh": (_I, [_P, _P]),
+    "wdgs_optimizer_apply_repacked_rows": (_I, [_P, _P, _U, _U, _P, _P, _P]),
+    "wdgs_tiled_forward_set_dc_source": (_I, [_P, _P]),
     "wdgs_guard_accumulate": (_I, [_P, _P, _P, _I]),
     "wdgs_optimizer_state_changed": (_I, [_P]),
     "wdgs_copy_to_host": (_I, [_P, _P, _P, _Z]),

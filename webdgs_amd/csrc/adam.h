@@ -30,7 +30,8 @@ WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
 // the 32-byte form in which a data-parallel rank publishes the Gaussians it owns (wdgs_comm_allgather_rows).
 WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_pos,
                             float4* __restrict__ opt_rot, float4* __restrict__ opt_scale, float* __restrict__ opt_opacity,
-                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ rows_out = nullptr) {
+                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ rows_out = nullptr,
+                            u32* __restrict__ dc_words = nullptr) {
     float4 P = opt_pos[(size_t)idx * 3];
     float4 R = opt_rot[(size_t)idx * 3];
     float4 S = opt_scale[(size_t)idx * 3];
@@ -91,10 +92,18 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
     // pack2x16float(c2, unpack2x16float(old).y): the neighbouring coefficient survives that round trip bit for bit (only a NaN
     // payload could change, which WGSL leaves implementation-defined), so not touching it is the same result -- without fetching
     // the 96-byte row's cache line just to copy 2 bytes back (it was 19 % of this kernel's HBM traffic).
-    u32* shp = sh_buffer + (size_t)idx * 24;
     const u32 sh0 = wd_pack2(c0, c1), sh1lo = wd_f16bits(c2) & 0xFFFFu;
-    shp[0] = sh0;
-    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)sh1lo;
+    if (dc_words) {
+        // Deferred SH writes (wdgs_optimizer_set_deferred_sh): the three trained halves go to a compact u32[N][2] array that project_count
+        // reads in place of the row's first six bytes -- an 8-byte store, 512 contiguous bytes per wave -- and the 96-byte rows are
+        // brought up to date at hand-over points (wdgs_optimizer_flush_sh).  The 6-byte store below is a partial write of a 64-byte
+        // memory word: ~120 MB of read-modify-write per step at 1 M Gaussians (profiles/r02o_hbm_by_kernel.md), a fifth of this kernel's traffic.
+        *reinterpret_cast<uint2*>(dc_words + (size_t)idx * 2) = make_uint2(sh0, sh1lo);
+    } else {
+        u32* shp = sh_buffer + (size_t)idx * 24;
+        shp[0] = sh0;
+        reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)sh1lo;
+    }
     if (rows_out) {
         uint4* ro = reinterpret_cast<uint4*>(rows_out + (size_t)idx * 8);
         ro[0] = make_uint4(wd_pack2(P.x, P.y), wd_pack2(P.z, op), wd_pack2(R.x, R.y), wd_pack2(R.z, R.w));

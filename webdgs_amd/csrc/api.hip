@@ -1,5 +1,6 @@
 // C ABI of libwebdgs_hip.so (include/webdgs.h): handle types, ownership, launch sequencing.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -8,7 +9,8 @@
 #include "common.h"
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
-int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*, void*);
+int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*, void*,
+                         const void*);
 int launch_emit_scatter(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, const void*, const void*, void*, void*, u32);
 int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges);
 extern "C" void sorter_set_final_out_index(wdgs_sorter* s, int i);
@@ -23,14 +25,16 @@ int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, con
 int launch_acc_clear_if_dirty(wdgs_device*, void*, u32, void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*);
 int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
-                                  const wdgs_optimizer_state&, void*, void*, const void*);
+                                  const wdgs_optimizer_state&, void*, void*, const void*, void*);
 int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*, void*, void*, void*, const void*, void*,
                                         const void*, u32);
 int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
-                       const void*);
+                       const void*, void*);
 int launch_adam_repack_f32(wdgs_device*, u32, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*,
-                           void*, const void*, void*, void*);
-int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, void*, void*, void*);
+                           void*, const void*, void*, void*, void*);
+int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, void*, void*, void*, void*);
+int launch_dc_words_load(wdgs_device*, u32, const void*, void*);
+int launch_dc_words_flush(wdgs_device*, u32, const void*, void*);
 int launch_guard_accumulate(wdgs_device*, void*, const void*, u32);
 int launch_dc_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
 int launch_dc_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
@@ -107,6 +111,7 @@ struct wdgs_tiled_forward {
     // offset inside the column, and the column totals -- the digit counts of the sort's first pass, which emit_scatter performs (project.hip)
     u32* column_counts;
     u32* column_totals;
+    const void* dc_source;  // nullable: the optimizer's compact SH-DC words (wdgs_tiled_forward_set_dc_source), read by project_count in place of the rows' first 6 bytes
     u32 points_capacity;  // Gaussians the per-Gaussian buffers above and the scanner hold (>= cfg.num_points: wdgs_tiled_forward_resize)
     wdgs_prefix_scanner* scanner;  // input = tile counts, output = per-Gaussian offsets
     wdgs_sorter* sorter;
@@ -159,6 +164,11 @@ struct wdgs_optimizer {
     float* dc;        // compact SH-DC copy float[N][9] {param rgb, m rgb, v rgb} (optimizer.hip "HBM layout note"); always owned
     bool dc_dirty;    // dc is ahead of state.param_sh / state.state_sh
     const void* guard;  // device word: non-zero at execution time turns step / step_f32 into a no-op (wdgs_optimizer_set_guard)
+    // Deferred SH writes (wdgs_optimizer_set_deferred_sh): the steps write the trained DC halves to dc_words (u32[N][2]) instead of the
+    // 96-byte rows; sh_stale says the rows are behind until wdgs_optimizer_flush_sh.
+    u32* dc_words;
+    bool deferred_sh;
+    bool sh_stale;
 };
 
 // Brings the reference-layout SH arrays up to date with the compact DC copy (no-op when nothing was trained since).
@@ -588,6 +598,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->dev = d;
     op->cfg = *cfg;
     op->stats = op->splats = op->depths = op->block_counts = op->column_counts = op->column_totals = nullptr;
+    op->dc_source = nullptr;
     op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;
@@ -696,9 +707,11 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     // per-column offsets, and emit writes its entries straight into column order (project.hip: emit_scatter) -- the keys are never
     // written in emission order, histogrammed and scattered.  encode(skipSort) and compat_caps keep the reference's emission order.
     const TileInfo& ti = op->tile_info;
-    const bool columns = !skip_sort && !op->cfg.compat_caps && n > 0 && ti.num_tiles_x >= 2u && ti.num_tiles_x <= 256u && ti.num_tiles_y <= 256u;
+    // (WDGS_FORWARD_COLUMNS=0: the separate emit + two-pass tile sort of round 2, for same-box A/B timing; results are identical)
+    static const bool columns_enabled = !(std::getenv("WDGS_FORWARD_COLUMNS") && std::getenv("WDGS_FORWARD_COLUMNS")[0] == '0');
+    const bool columns = columns_enabled && !skip_sort && !op->cfg.compat_caps && n > 0 && ti.num_tiles_x >= 2u && ti.num_tiles_x <= 256u && ti.num_tiles_y <= 256u;
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
-                                  op->block_counts, columns ? op->column_counts : nullptr));
+                                  op->block_counts, columns ? op->column_counts : nullptr, op->dc_source));
     const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries};
     if (columns) {
         WDGS_TRY(forward_scan(d, op->block_counts, ceil_div(n, 256), op->column_counts, op->column_totals, ti.num_tiles_x, ep));
@@ -1092,6 +1105,7 @@ int wdgs_optimizer_destroy(wdgs_optimizer* op) {
     sync_if_alive(op->dev);
     if (op->owns_state) optimizer_free_state(op);
     free_dev(op->dc);
+    free_dev(op->dc_words);
     delete op;
     return WDGS_OK;
 }
@@ -1105,7 +1119,8 @@ int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const voi
     WDGS_REQUIRE(op && gaussians && sh && gradients && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step: null argument");
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
-    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh, op->guard);
+    if (op->deferred_sh) op->sh_stale = true;
+    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
 }
 // K17 + K18 + K19 in one pass over the Gaussians (the single-view step): `bwd` must have run wdgs_tiled_backward_encode_raster for this view.
 int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera, void* gaussians, void* sh, const void* tile_counts) {
@@ -1114,14 +1129,17 @@ int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* b
                  bwd->cfg.num_points, op->num_points);
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
+    if (op->deferred_sh) op->sh_stale = true;
     return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradients, op->params, tile_counts, op->state,
-                                         op->dc, sh, op->guard);
+                                         op->dc, sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");
     op->iteration++;
     op->dc_dirty = true;
-    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, nullptr);
+    if (op->deferred_sh) op->sh_stale = true;
+    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, nullptr,
+                                  op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible, uint32_t first, uint32_t count,
                                   void* rows_out) {
@@ -1130,7 +1148,9 @@ int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh,
                  op->num_points);
     op->iteration++;
     op->dc_dirty = true;
-    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, rows_out);
+    if (op->deferred_sh) op->sh_stale = true;
+    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, rows_out,
+                                  op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
@@ -1145,7 +1165,42 @@ int wdgs_optimizer_state_changed(wdgs_optimizer* op) {
 int wdgs_apply_repacked_rows(wdgs_device* d, uint32_t n, const void* rows, uint32_t skip_first, uint32_t skip_count, const void* guard, void* gaussians,
                              void* sh) {
     WDGS_REQUIRE(d && rows && gaussians && sh, WDGS_E_INVALID, "wdgs_apply_repacked_rows: null argument");
-    return launch_apply_rows(d, n, rows, skip_first, skip_count, guard, d->host_guard, gaussians, sh);
+    return launch_apply_rows(d, n, rows, skip_first, skip_count, guard, d->host_guard, gaussians, sh, nullptr);
+}
+// The same for a replica whose optimizer defers its SH writes: the gathered DC halves go to its compact words as well.
+int wdgs_optimizer_apply_repacked_rows(wdgs_optimizer* op, const void* rows, uint32_t skip_first, uint32_t skip_count, const void* guard, void* gaussians, void* sh) {
+    WDGS_REQUIRE(op && rows && gaussians && sh, WDGS_E_INVALID, "wdgs_optimizer_apply_repacked_rows: null argument");
+    if (op->deferred_sh) op->sh_stale = true;
+    return launch_apply_rows(op->dev, op->num_points, rows, skip_first, skip_count, guard, op->dev->host_guard, gaussians, sh, op->deferred_sh ? op->dc_words : nullptr);
+}
+// ---- deferred SH writes (no reference counterpart)
+int wdgs_optimizer_set_deferred_sh(wdgs_optimizer* op, void* sh, int enabled) {
+    WDGS_REQUIRE(op && sh, WDGS_E_INVALID, "wdgs_optimizer_set_deferred_sh: null argument");
+    WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_optimizer_set_deferred_sh while recording a command buffer");
+    if (!enabled) {
+        if (op->deferred_sh && op->sh_stale) WDGS_TRY(launch_dc_words_flush(op->dev, op->num_points, op->dc_words, sh));
+        op->deferred_sh = false;
+        op->sh_stale = false;
+        return WDGS_OK;
+    }
+    if (!op->dc_words) WDGS_TRY(wdgs_alloc((void**)&op->dc_words, sizeof(u32) * 2 * (size_t)std::max(op->num_points, 1u), true, op->dev->stream));
+    if (!op->deferred_sh || !op->sh_stale) WDGS_TRY(launch_dc_words_load(op->dev, op->num_points, sh, op->dc_words));  // the rows are current: take their DC halves
+    op->deferred_sh = true;
+    return WDGS_OK;
+}
+void* wdgs_optimizer_dc_words(wdgs_optimizer* op) { return (op && op->deferred_sh) ? op->dc_words : nullptr; }
+int wdgs_optimizer_flush_sh(wdgs_optimizer* op, void* sh) {
+    WDGS_REQUIRE(op && sh, WDGS_E_INVALID, "wdgs_optimizer_flush_sh: null argument");
+    if (!op->deferred_sh || !op->sh_stale) return WDGS_OK;
+    WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_optimizer_flush_sh while recording a command buffer");
+    WDGS_TRY(launch_dc_words_flush(op->dev, op->num_points, op->dc_words, sh));  // stream-ordered: later kernels and copies on this device see current rows
+    op->sh_stale = false;
+    return WDGS_OK;
+}
+int wdgs_tiled_forward_set_dc_source(wdgs_tiled_forward* op, const void* dc_words) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_set_dc_source: null op");
+    op->dc_source = dc_words;
+    return WDGS_OK;
 }
 int wdgs_guard_accumulate(wdgs_device* d, void* flag, const void* src, int overwrite) {
     WDGS_REQUIRE(d && flag && src, WDGS_E_INVALID, "wdgs_guard_accumulate: null argument");
@@ -1164,6 +1219,7 @@ int wdgs_optimizer_advance_iteration(wdgs_optimizer* op, uint32_t count) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
     op->iteration += count;
     if (count) op->dc_dirty = true;  // a recorded step() was re-submitted
+    if (count && op->deferred_sh) op->sh_stale = true;
     return WDGS_OK;
 }
 int wdgs_optimizer_get_hyperparameters(const wdgs_optimizer* op, wdgs_adam_hyperparameters* out) {

@@ -23,21 +23,23 @@ namespace {
 // WDGS_E_CAPACITY does not first corrupt the optimizer state.
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
                                                            const u32* __restrict__ gradients, float4* opt_pos, float4* opt_rot, float4* opt_scale,
-                                                           float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer, const u32* __restrict__ guard) {
+                                                           float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer, const u32* __restrict__ guard,
+                                                           u32* dc_words) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     if (guard && *guard != 0u) return;
     const bool update = tile_counts[idx] != 0u;
     Grad14 g = {};
     if (update) g = unpack_gradient(gradients, idx);
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer);
+    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer, nullptr, dc_words);
 }
 
 // Gaussians [first, first + count): the slice a data-parallel rank owns (first = 0, count = n on a single GPU).
 __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 count, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
                                                                const float* __restrict__ grad_f32, float4* opt_pos, float4* opt_rot,
                                                                float4* opt_scale, float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer,
-                                                               const u32* __restrict__ guard, u32* __restrict__ guard_seen_host, u32* __restrict__ rows_out) {
+                                                               const u32* __restrict__ guard, u32* __restrict__ guard_seen_host, u32* __restrict__ rows_out,
+                                                               u32* dc_words) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     if (guard && *guard != 0u) {
@@ -54,13 +56,13 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 cou
         g.scale[0] = gp[8]; g.scale[1] = gp[9]; g.scale[2] = gp[10];
         g.color[0] = gp[11]; g.color[1] = gp[12]; g.color[2] = gp[13];
     }
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer, rows_out);
+    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer, rows_out, dc_words);
 }
 
 // Rows published by the other ranks (wdgs_comm_allgather_rows) -> this replica's point cloud: every Gaussian outside
 // [skip_first, skip_first + skip_count), which this rank re-packed itself.
 __global__ __launch_bounds__(256) void apply_rows_kernel(u32 n, const u32* __restrict__ rows, u32 skip_first, u32 skip_count, const u32* __restrict__ guard, u32* __restrict__ guard_seen_host,
-                                                          u32* __restrict__ gaussians, u32* __restrict__ sh_buffer) {
+                                                          u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ dc_words) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0u && guard && guard_seen_host && *guard != 0u) *guard_seen_host = 1u;  // (a rank whose owned slice is empty runs no Adam kernel)
     if (idx >= n || (idx >= skip_first && idx - skip_first < skip_count)) return;
@@ -71,9 +73,30 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(u32 n, const u32* __res
     *reinterpret_cast<uint2*>(gp) = make_uint2(a.x, a.y);
     *reinterpret_cast<uint2*>(gp + 2) = make_uint2(a.z, a.w);
     *reinterpret_cast<uint2*>(gp + 4) = make_uint2(b.x, b.y);
+    if (dc_words) {  // deferred SH writes (adam.h)
+        *reinterpret_cast<uint2*>(dc_words + (size_t)idx * 2) = make_uint2(b.z, b.w & 0xFFFFu);
+    } else {
+        u32* shp = sh_buffer + (size_t)idx * 24;
+        shp[0] = b.z;
+        reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)(b.w & 0xFFFFu);
+    }
+}
+
+// SH rows -> compact DC words (when deferred writes are switched on) and back (hand-over points: a host read of the cloud, an export, the
+// viewer, a densify rebuild -- anything that reads the 96-byte rows instead of going through project_count's dc_words argument)
+__global__ __launch_bounds__(256) void dc_words_load_kernel(u32 n, const u32* __restrict__ sh_buffer, u32* __restrict__ dc_words) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const uint2 w = *reinterpret_cast<const uint2*>(sh_buffer + (size_t)idx * 24);
+    *reinterpret_cast<uint2*>(dc_words + (size_t)idx * 2) = make_uint2(w.x, w.y & 0xFFFFu);
+}
+__global__ __launch_bounds__(256) void dc_words_flush_kernel(u32 n, const u32* __restrict__ dc_words, u32* __restrict__ sh_buffer) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const uint2 w = *reinterpret_cast<const uint2*>(dc_words + (size_t)idx * 2);
     u32* shp = sh_buffer + (size_t)idx * 24;
-    shp[0] = b.z;
-    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)(b.w & 0xFFFFu);
+    shp[0] = w.x;
+    reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)(w.y & 0xFFFFu);
 }
 
 // flag = (overwrite ? 0 : flag) | (src != 0): folds per-view overflow words into the one guard word of a batched step
@@ -165,29 +188,45 @@ __global__ __launch_bounds__(256) void unpack_kernel(u32 n, const u32* __restric
 }  // namespace
 
 int launch_adam_repack(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* tile_counts, const void* gradients,
-                       const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard) {
+                       const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack", adam_repack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)tile_counts, (const u32*)gradients,
                 (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh,
-                (const u32*)guard);
+                (const u32*)guard, (u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
 int launch_adam_repack_f32(wdgs_device* dev, u32 first, u32 count, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
-                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out) {
+                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out,
+                           void* dc_words) {
     if (count == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, first, count, h, (const u32*)visible,
                 (const float*)grad_f32, (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians,
-                (u32*)sh, (const u32*)guard, (u32*)guard_seen_host, (u32*)rows_out);
+                (u32*)sh, (const u32*)guard, (u32*)guard_seen_host, (u32*)rows_out, (u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_apply_rows(wdgs_device* dev, u32 n, const void* rows, u32 skip_first, u32 skip_count, const void* guard, void* guard_seen_host, void* gaussians, void* sh) {
+int launch_apply_rows(wdgs_device* dev, u32 n, const void* rows, u32 skip_first, u32 skip_count, const void* guard, void* guard_seen_host, void* gaussians, void* sh,
+                      void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "apply_repacked_rows", apply_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)rows, skip_first, skip_count,
-                (const u32*)guard, (u32*)guard_seen_host, (u32*)gaussians, (u32*)sh);
+                (const u32*)guard, (u32*)guard_seen_host, (u32*)gaussians, (u32*)sh, (u32*)dc_words);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_dc_words_load(wdgs_device* dev, u32 n, const void* sh, void* dc_words) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "optimizer_dc_words_load", dc_words_load_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)sh, (u32*)dc_words);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_dc_words_flush(wdgs_device* dev, u32 n, const void* dc_words, void* sh) {
+    if (n == 0) return WDGS_OK;
+    WDGS_LAUNCH(dev, "optimizer_dc_words_flush", dc_words_flush_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)dc_words, (u32*)sh);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

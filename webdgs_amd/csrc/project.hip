@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
                                                              const float* __restrict__ camera_f, RenderSettings settings, TileInfo ti,
                                                              u32* __restrict__ splats, u32* __restrict__ depths,
                                                              u32* __restrict__ tile_counts, u32* __restrict__ visible_shards,
-                                                             u32* __restrict__ block_counts, u32* __restrict__ column_counts /*[num_tiles_x][gridDim.x]*/) {
+                                                             u32* __restrict__ block_counts, u32* __restrict__ column_counts /*[num_tiles_x][gridDim.x]*/,
+                                                             const u32* __restrict__ dc_words /*nullable: u32[N][2], the trained SH-DC halves (adam.h)*/) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool visible = false;
     u32 num_tiles_out = 0u;
@@ -126,7 +127,12 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
             const vec3 gaussian_scale = vexp(V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y)));
             const vec3 pos = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
             const float opacity_raw = wd_unpack_hi(w01.y);
-            const ShRow sh_row = load_sh_row(sh_buffer, idx, wd_to_u32(settings.sh_deg));
+            ShRow sh_row = load_sh_row(sh_buffer, idx, wd_to_u32(settings.sh_deg));
+            if (dc_words) {  // the optimizer defers its writes of the row's first six bytes: the current values are here
+                const uint2 dcw = *reinterpret_cast<const uint2*>(dc_words + (size_t)idx * 2);
+                sh_row.w[0] = dcw.x;
+                sh_row.w[1] = (sh_row.w[1] & 0xFFFF0000u) | (dcw.y & 0xFFFFu);
+            }
             const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
 
             const CameraUniforms& cam = *reinterpret_cast<const CameraUniforms*>(camera_f);
@@ -536,10 +542,12 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
 }  // namespace
 
 int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const void* sh, const void* camera, const RenderSettings& st,
-                         const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards, void* block_counts, void* column_counts) {
+                         const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards, void* block_counts, void* column_counts,
+                         const void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "project_count", project_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh,
-                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts, (u32*)column_counts);
+                (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts, (u32*)column_counts,
+                (const u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -30,10 +30,15 @@ class HipBuffer:
     def __init__(self, device: "HipDevice", ptr: int, size: int, owner: Optional[torch.Tensor] = None, label: str = ""):
         self.device, self.ptr, self.size, self._owner, self.label = device, int(ptr or 0), int(size), owner, label
         self.destroyed = False
+        # called before the buffer's CONTENT is handed to the host (read / tensor): a producer that keeps part of it elsewhere brings it up
+        # to date first (the optimizer's deferred SH writes: Optimizer.setDeferredSH)
+        self.before_read = None
 
     def read(self, dtype=np.uint32, count: Optional[int] = None, offset: int = 0) -> np.ndarray:
         """mapAsync + getMappedRange: synchronous copy to host."""
         dt = np.dtype(dtype)
+        if self.before_read is not None:
+            self.before_read()
         n = (self.size - offset) // dt.itemsize if count is None else int(count)
         out = np.empty(n, dt)
         if n:
@@ -54,6 +59,8 @@ class HipBuffer:
     def tensor(self) -> torch.Tensor:
         if self._owner is None:
             raise _lib.StateError(_lib.WDGS_E_STATE, "buffer is library-owned; no torch tensor behind it")
+        if self.before_read is not None:
+            self.before_read()
         return self._owner
 
     def destroy(self) -> None:
@@ -336,6 +343,12 @@ class TiledForwardPass:
     def setCameraBuffer(self, buffer: HipBuffer) -> None:
         self.cameraBuffer = buffer
 
+    def setDcSource(self, dcWords: Optional[HipBuffer]) -> None:
+        """K1 takes the SH-DC halves from the optimizer's compact array (``Optimizer.setDeferredSH``) instead of the cloud's rows; ``None``
+        restores the rows.  No reference counterpart (include/webdgs.h)."""
+        self._dc_source = dcWords  # (kept alive)
+        check(self.device.lib.wdgs_tiled_forward_set_dc_source(self.handle, dcWords.ptr if dcWords is not None else None))
+
     def setPointCloud(self, pointCloud: PointCloud) -> bool:
         """Adopts a point cloud of another size (``wdgs_tiled_forward_resize``: buffers reused, or re-allocated with headroom) instead of
         the destroy + construct of ``applyPointCloudSwap`` (trainer.ts:201-237).  False -- nothing changed -- if the SH degree differs."""
@@ -613,6 +626,7 @@ class Optimizer:
         h = C.c_void_p()
         check(device.lib.wdgs_optimizer_create(device.handle, self.numPoints, C.byref(hp), None, None, C.byref(st), 0, it, C.byref(h)))
         self.handle = h
+        self._deferred_cloud: Optional[PointCloud] = None
         if fresh:  # initBuffers (optimizer.ts:145-253): K20 unpack into the zero-filled state
             check(device.lib.wdgs_optimizer_init_from_point_cloud(h, pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr))
 
@@ -633,6 +647,29 @@ class Optimizer:
         st = _lib.OptimizerState()
         check(self.device.lib.wdgs_optimizer_get_state(self.handle, C.byref(st)))
         return self.buffers
+
+    # ---- deferred SH writes (include/webdgs.h: wdgs_optimizer_set_deferred_sh; no reference counterpart)
+    def setDeferredSH(self, pointCloud: PointCloud, enabled: bool = True) -> Optional[HipBuffer]:
+        """On: the steps write the trained SH-DC halves to a compact array instead of the cloud's 96-byte rows; returns that array (give it
+        to every forward pass that renders the cloud: ``TiledForwardPass.setDcSource``).  The cloud's SH buffer is brought up to date
+        by ``flushSH`` -- automatically before any host read of it (``HipBuffer.before_read``), explicitly before device-side readers
+        that have no dc source (a viewer's own forward pass, ``DensifyPrunePass.encodeScatter``).  Off: flushes and restores the
+        reference's write pattern."""
+        check(self.device.lib.wdgs_optimizer_set_deferred_sh(self.handle, pointCloud.sh_buffer.ptr, 1 if enabled else 0))
+        self._deferred_cloud = pointCloud if enabled else None
+        pointCloud.sh_buffer.before_read = (lambda: self.flushSH(pointCloud)) if enabled else None
+        ptr = self.device.lib.wdgs_optimizer_dc_words(self.handle)
+        return self.device.view(ptr, 8 * max(1, self.numPoints), "sh-dc words") if (enabled and ptr) else None
+
+    def flushSH(self, pointCloud: PointCloud) -> None:
+        """Writes the deferred SH-DC halves into the cloud's rows (a no-op when nothing was trained since the last flush)."""
+        if not self.destroyed and self.handle:
+            check(self.device.lib.wdgs_optimizer_flush_sh(self.handle, pointCloud.sh_buffer.ptr))
+
+    def applyRepackedRows(self, rows: HipBuffer, skipFirst: int, skipCount: int, guard: Optional[HipBuffer], pointCloud: PointCloud) -> None:
+        """``applyRepackedRows`` for this optimizer's replica: with deferred SH writes the gathered halves go to the compact array."""
+        check(self.device.lib.wdgs_optimizer_apply_repacked_rows(self.handle, rows.ptr, int(skipFirst), int(skipCount), guard.ptr if guard is not None else None,
+                                                                 pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr))
 
     def advanceIteration(self, count: int = 1) -> None:
         """Bumps the host-side step counter when a recorded command buffer containing ``step`` is re-submitted."""
@@ -669,6 +706,12 @@ class Optimizer:
     def destroy(self) -> None:
         if self.destroyed:
             return
+        pc = self._deferred_cloud
+        if pc is not None and self.device.handle and not pc.sh_buffer.destroyed:  # the cloud outlives its optimizer: leave its SH rows current
+            try:
+                self.setDeferredSH(pc, False)
+            except _lib.WdgsError:
+                pc.sh_buffer.before_read = None
         self.destroyed = True
         self.device.lib.wdgs_optimizer_destroy(self.handle)
         self.handle = None

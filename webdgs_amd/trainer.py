@@ -63,6 +63,10 @@ class Trainer:
         self.pipeline_depth = max(1, min(int(pipeline_depth), 4))
         self.reuse_passes = True  # applyPointCloudSwap resizes the passes instead of rebuilding them (False: the reference's teardown)
         self.fuse_geometry_adam = True  # the single-view step runs K17, Adam and the re-pack as one kernel (False: the reference's three)
+        # Adam writes the trained SH-DC halves to a compact array that K1 reads, instead of 6 bytes into every 96-byte SH row each step; the
+        # rows are flushed at hand-over points (Optimizer.setDeferredSH).  False: the reference's write pattern.  Results are identical.
+        self.deferred_sh = os.environ.get("WDGS_DEFERRED_SH", "1") != "0"
+        self._dc_words: Optional[ops.HipBuffer] = None
         self._tickets: list = []
         self._more_op_sets: list = []  # [forwardPass, rasterizer, backwardPass] of lanes 1.. (set 0 is the three above)
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
@@ -152,12 +156,25 @@ class Trainer:
             self._destroy_more_op_sets()
         self.optimizer = ops.Optimizer(self.device, self.pointCloud, oldParams or self.optimizerHyperparameters, request.get("optimizerInitialState"))
         self.optimizerHyperparameters = dict(self.optimizer.getHyperparameters())
+        self._dc_words = self.optimizer.setDeferredSH(self.pointCloud, True) if self.deferred_sh else None
+        for fw in self._forward_passes():
+            fw.setDcSource(self._dc_words)
         if old is not None and old is not self.pointCloud:
             old.gaussian_3d_buffer.destroy()
             old.sh_buffer.destroy()
         self._dp_grad = self._dp_visible = self._dp_rows = self._dp_flag = None
         self._state_sliced = False
         self.ensurePipelines(self.lastViewportWidth, self.lastViewportHeight)
+
+    def _forward_passes(self) -> list:
+        return [p for p in [self.forwardPass, self.metricsForwardPass] + [more[0] for more in self._more_op_sets] if p is not None]
+
+    def flushPointCloud(self) -> None:
+        """Brings the point cloud's SH rows up to date with what has been trained (``Optimizer.flushSH``): call before a device-side reader
+        that does not go through this trainer's forward passes -- a viewer rendering the same cloud, a custom kernel.  Host reads of
+        ``pointCloud.sh_buffer`` do it by themselves."""
+        if self.optimizer is not None and self.pointCloud is not None:
+            self.optimizer.flushSH(self.pointCloud)
 
     def _invalidate_command_buffers(self) -> None:
         """Recorded kernels bake pointers, viewport, hyper-parameters and loss weights: any change drops the recordings."""
@@ -274,6 +291,7 @@ class Trainer:
         if self.forwardPass is None:
             self.forwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
                                                     dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+            self.forwardPass.setDcSource(self._dc_words)
         else:
             self.forwardPass.setViewport(w, h)
         if self.rasterizer is None:
@@ -288,6 +306,7 @@ class Trainer:
         while len(self._more_op_sets) < self._op_sets - 1:
             fw = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
                                       dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+            fw.setDcSource(self._dc_words)
             self._more_op_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
                                        ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))])
         if self.optimizer is not None and self.world_size * self.views_per_rank == 1:
@@ -307,6 +326,7 @@ class Trainer:
         self.metricsViewportWidth, self.metricsViewportHeight = w, h
         self.metricsForwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.metricsCameraBuffer,
                                                        dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+        self.metricsForwardPass.setDcSource(self._dc_words)
         self.metricsRasterizer = ops.TiledRasterizer(dict(device=self.device, forwardPass=self.metricsForwardPass, format="rgba8unorm"))
         self.metricsPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
         self.metricsTarget = self.device.createBuffer(4 * w * h, "metrics-gt-downsampled")
@@ -502,7 +522,7 @@ class Trainer:
             self.optimizer.advanceIteration(1)
         if self._sliced:
             self._timed(lambda: self.exchange.allgather_rows(self._dp_rows.ptr, sl))
-            self._run(("apply",), lambda encoder: ops.applyRepackedRows(self.device, n, self._dp_rows, first, count, self._dp_flag, self.pointCloud))
+            self._run(("apply",), lambda encoder: self.optimizer.applyRepackedRows(self._dp_rows, first, count, self._dp_flag, self.pointCloud))
             self._state_sliced = w > 1
         if not self.use_command_buffers or eager_before < 1:
             self._eager_steps += 1
@@ -620,6 +640,7 @@ class Trainer:
         if outN == 0 or outN == inN:
             return
         self.syncOptimizerState()  # every rank rebuilds the whole cloud, so every rank needs the whole state
+        self.optimizer.flushSH(self.pointCloud)  # the rebuild copies the cloud's SH rows: bring the deferred DC halves in first
         outPointCloud = ops.allocatePointCloudLike(self.device, self.pointCloud, dict(numPoints=outN))
         outState = ops.allocateOptimizerStateBuffers(self.device, outN)
         self.densifyPrune.encodeScatter(encoder, dict(pointCloud=self.pointCloud, optimizerState=self.optimizer.getStateBuffers(),
