@@ -438,7 +438,7 @@ def main() -> None:
     cameras, images = make_dataset(dev, cfg, tg, tsh, cams)
 
     trainer = Trainer(dev, seed=1234, world_size=world, rank=rank, views_per_rank=vpr, overlap_views=args.lanes or None, pipeline_depth=args.pipeline_depth)
-    lanes = trainer._op_sets
+    lanes = trainer._lanes
     trainer.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     trainer.setDataset(cameras, images)
     trainer.setMaxIterations(10 ** 9)
@@ -513,7 +513,7 @@ def main() -> None:
         gl, gms = groups.get(gname, (0, 0.0))
         groups[gname] = (gl + launches, gms + ms)
     per_view_kernels = ("project_count", "scan", "emit", "sort", "tile_ranges", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward", "geometry_backward_adam",
-                        "store_gradients", "accumulate_gradients", "guard_accumulate")
+                        "store_gradients", "accumulate_gradients", "guard_accumulate", "acc_clear")
     per_step = {k: v[1] / max(1, args.steps) / (vpr if k in per_view_kernels else 1) for k, v in groups.items()}
     dom = max(per_step, key=per_step.get) if per_step else None
     roofline = None
@@ -550,7 +550,7 @@ def main() -> None:
                 solo.step()
             solo.warmupCommandBuffers()
             s_el, s_dev, s_blocks = timed_blocks(solo, dev, args.steps, args.min_seconds, 1, barrier=lambda: None)
-            same_step = dict(views_per_s=round(vpr * args.steps / s_el, 3), ms_per_step=round(s_el / args.steps * 1e3, 4), views_per_step=vpr, lanes=solo._op_sets,
+            same_step = dict(views_per_s=round(vpr * args.steps / s_el, 3), ms_per_step=round(s_el / args.steps * 1e3, 4), views_per_step=vpr, lanes=solo._lanes,
                              blocks=len(s_blocks), note="rank 0's GPU alone: same views per rank, lanes, command buffers and pipeline depth; Adam on all N Gaussians, no exchange")
             solo.destroy()
         parallel.barrier()

@@ -91,8 +91,13 @@ int wdgs_device_reset_kernel_times(wdgs_device* dev);
  * point cloud is shared read-only until the lanes are joined in front of the optimizer step.  Neither call is allowed while
  * recording. */
 #define WDGS_MAX_LANES 4
+#define WDGS_MAX_BATCH_VIEWS 16 /* views one view-batched K1 / K17 launch covers (wdgs_tiled_forward_project_views) */
 int wdgs_device_select_lane(wdgs_device* dev, int lane);
 int wdgs_device_lane_order(wdgs_device* dev, int waiter_lane, int signal_lane);
+/* A position on `lane`, remembered in one of WDGS_MAX_BATCH_VIEWS numbered marks, for other lanes to wait for later
+ * (wdgs_device_lane_order records and waits in one call). */
+int wdgs_device_lane_mark(wdgs_device* dev, int lane, int mark);
+int wdgs_device_lane_wait_mark(wdgs_device* dev, int lane, int mark);
 
 /* ---------------------------------------------------------------- recorded command buffers (hipGraph)
  * Replaces device.createCommandEncoder() ... encoder.finish() -> GPUCommandBuffer -> queue.submit([cmd]) (trainer.ts:603-645).
@@ -373,6 +378,23 @@ int wdgs_optimizer_apply_repacked_rows(wdgs_optimizer* op, const void* rows_dev,
                                        void* gaussians_dev, void* sh_dev);
 /* project_count (K1) takes the SH-DC halves from `dc_words_dev` (wdgs_optimizer_dc_words) instead of the rows; NULL restores the rows */
 int wdgs_tiled_forward_set_dc_source(wdgs_tiled_forward* op, const void* dc_words_dev);
+
+/* View-batched step (no reference counterpart: the reference is batch-1, trainer.ts:573).  A step over V views projects every Gaussian
+ * for all V cameras in ONE launch -- the 24-byte Gaussian and its 96-byte SH row are read once, not V times -- into the V forward passes'
+ * own buffers (`ops[v]`, all created for the same cloud and viewport); each pass then runs the rest of its encode (scan, emit, sort) with
+ * wdgs_tiled_forward_encode_projected, on any lane, recorded or not.  Results are those of wdgs_tiled_forward_encode per view, bit for bit. */
+int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void* const* cameras_dev, uint32_t count, const void* gaussians_dev, const void* sh_dev);
+int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op);
+/* ... and K17 of all V views in one launch: per view the accumulators of `ops[v]` (wdgs_tiled_backward_encode_raster ran for it) are turned
+ * into the view's fp16 gradient under `cameras_dev[v]` and summed, in view order, into the step's fp32 block `sums_f32_dev` [N][14] with the
+ * visibility counts `visible_dev` [N] and the guard word (OR of the views' overflow words `overflow_words_dev[v]`) -- what V calls of
+ * wdgs_tiled_backward_encode_geometry(into = {first: v == 0}) produce, bit for bit, with the Gaussians read once and the fp32 block written
+ * once.  `write_gradients` != 0 also stores each view's packed gradient in its pass's gradient buffer.  A step may hand its views over
+ * in several GROUPS (so that one group's K17 runs beside the next group's rasterization): `continues` = 0 for the group that holds the
+ * step's first view, 1 for every later group, in view order -- the block then goes on from what the earlier groups left. */
+int wdgs_tiled_backward_encode_geometry_views(wdgs_tiled_backward* const* ops, const void* const* cameras_dev, const void* const* tile_counts_dev,
+                                              const void* const* overflow_words_dev, uint32_t count, const void* gaussians_dev, void* sums_f32_dev,
+                                              void* visible_dev, void* guard_u32_dev, int write_gradients, int continues);
 /* flag = (overwrite ? 0 : flag) | (*src != 0): folds the overflow words of the views of a batched step into one guard word. */
 int wdgs_guard_accumulate(wdgs_device* dev, void* flag_u32_dev, const void* src_u32_dev, int overwrite);
 /* The caller rewrote the state arrays (gathered slices from other ranks): refresh the optimizer's internal compact copies. */

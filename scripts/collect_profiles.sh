@@ -1,0 +1,29 @@
+#!/bin/bash
+# Everything the round's profiles/ set is made of, on the GPU box:   bash scripts/collect_profiles.sh <tag>
+#   bench lines (c3 full with sustained + cpu_baseline legs, c2, c5, c3 with 8 views per step on 3 lanes and on 1),
+#   rocprofv3 --kernel-trace --stats of the c3 bench (kernel_stats.csv), the PMC passes (scripts/pmc.sh) and the per-kernel HBM / VALU table.
+set -e
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+export TMPDIR=/tmp
+O=$R/gpurun_out
+mkdir -p $O
+echo "== bench c3 (headline, full)"; timeout -k 10 600 python3 bench.py > $O/${TAG}_bench_c3.json 2> $O/${TAG}_bench_c3.err
+echo "== bench c2"; timeout -k 10 300 python3 bench.py --config c2 > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
+echo "== bench c5"; timeout -k 10 400 python3 bench.py --config c5 --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c5.json 2> $O/${TAG}_bench_c5.err
+echo "== bench c3, 8 views per step"; for L in 3 1; do timeout -k 10 500 python3 bench.py --views-per-rank 8 --lanes $L --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c3_vpr8_lanes${L}.json 2> $O/${TAG}_bench_vpr8.err; done
+echo "== kernel trace of the c3 bench"
+rm -rf $O/prof_${TAG}
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --sustained-steps 0 --no-cpu-baseline --min-seconds 0.3 > $O/${TAG}_bench_c3_under_rocprof.json 2> $O/${TAG}_rocprof.err
+cp $(find $O/prof_${TAG} -name "*kernel_stats.csv" | head -1) $O/${TAG}_c3_kernel_stats.csv
+echo "== PMC passes"
+timeout -k 10 900 bash scripts/pmc.sh ${TAG} c3 3 > $O/${TAG}_pmc.log 2>&1 || { tail -5 $O/${TAG}_pmc.log; exit 1; }
+python3 scripts/pmc_to_json.py $O/pmc_${TAG} $O/${TAG}_pmc.json c3
+python3 scripts/hbm_table.py $O/${TAG}_pmc.json $O/${TAG}_c3_kernel_stats.csv ${TAG} > $O/${TAG}_hbm_by_kernel.md
+cat $O/${TAG}_hbm_by_kernel.md
+python3 -c "
+import json
+for f in ('bench_c3','bench_c2','bench_c5','bench_c3_vpr8_lanes3','bench_c3_vpr8_lanes1'):
+    d=json.load(open('$O/${TAG}_'+f+'.json')); print(f, d['value'], d['ms_per_step'], d.get('c3_as_written_iters_per_s'), d['roofline']['kernel'], d['roofline'].get('frac'), d['roofline'].get('hbm_frac'))
+"

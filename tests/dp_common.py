@@ -9,7 +9,9 @@ import harness
 def dataset(dev):
     import os
     big = os.environ.get("WDGS_DP_TEST_BIG")  # manual stress: WDGS_DP_TEST_BIG=400000
-    cfg = harness.small_config("c2", num_points=int(big), width=640, height=480) if big else harness.small_config("c2", num_points=6000, width=128, height=96, s0=0.01)
+    few = os.environ.get("WDGS_DP_TEST_POINTS")  # a cloud smaller than one slice: the last rank owns nothing
+    cfg = harness.small_config("c2", num_points=int(big), width=640, height=480) if big else harness.small_config("c2", num_points=int(few) if few else 6000, width=128, height=96,
+                                                                                                                   s0=0.03 if few else 0.01)
     g, sh, _ = harness.scene(cfg)
     tg, tsh = synth.make_target_scene(g, sh)
     cams = synth.circle_cameras(cfg, 4)

@@ -155,3 +155,68 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert out["exchange"]["ms_per_step"] > 0 and 0 < out["exchange"]["frac_of_step"] < 1.0  # (not double-counted: ADVICE r2)
     assert out["timed_blocks"]["blocks"] >= 1 and out["steps"] == 3
     assert out["roofline"]["kernel"] and out["roofline"]["hbm_frac"] is not None
+
+
+def _visible_gpus() -> int:
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("transport", ["torch", "capi"])
+def test_two_ranks_over_rccl_equal_the_oracle_trainer(hip_device, orc, tmp_path, transport):
+    """the REAL sliced exchange on more than one RCCL rank -- in-place reduce_scatter_tensor / all_gather_into_tensor on
+    aliased views (torch transport) and ncclReduceScatter / ncclAllGather inside the library's own communicator (capi transport), the
+    rank * slice offsets of exchange_gradients / adam_repack_f32(first, count) / apply_rows -- one rank per GPU.  Needs two GPUs: skipped
+    on the one-GPU test box, runs as it is on a multi-GPU node.  Both replicas must equal the oracle trainer's batched step bit for bit."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs 2 GPUs (one RCCL rank per GPU)")
+    from oracle import oracle_trainer
+    steps, vpr = 5, 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WDGS_DIST_BACKEND", "WDGS_FORCE_DEVICE")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_COMM="capi" if transport == "capi" else "")
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), str(steps), "1", str(vpr)], env))
+    assert r.returncode == 0, _verdict(r)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    cfg, g, sh, cameras, images = dp_common.dataset(hip_device)
+    imgs = [im["texture"].read(np.uint8).reshape(cfg.height, cfg.width, 4) for im in images]
+    o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, [c["camera"] for c in cameras], imgs, densify=dict(schedule=dict(enabled=False)))
+    for ids in dp_common.view_schedule(steps, 2, vpr):
+        o.step(ids, world=2)
+    n = o.num_points
+    for i in range(2):
+        assert_bits_equal(ranks[i]["gaussians"].reshape(-1, 6)[:n], o.g, f"rank {i} gaussians vs oracle trainer over RCCL ({transport})")
+        assert_bits_equal(ranks[i]["sh"].reshape(-1, 24)[:n], o.sh, f"rank {i} sh vs oracle trainer over RCCL ({transport})")
+        assert_bits_equal(ranks[i]["state_optPosBuffer"].view(np.float32).reshape(-1, 12)[:n], o.state["opt_pos"], f"rank {i} gathered position state ({transport})")
+
+
+def test_a_rank_with_an_empty_slice_over_rccl(tmp_path):
+    """4 ranks over 2+ GPUs is not possible (one rank per GPU), so the empty-slice case -- slice_points rounds up to 64, a small cloud
+    leaves the last rank nothing to own -- runs with world = 2 and 40 Gaussians: rank 0 owns 64 >= 40, rank 1 owns none, and must still
+    take part in every collective and end with the same cloud."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs 2 GPUs (one RCCL rank per GPU)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WDGS_DIST_BACKEND", "WDGS_FORCE_DEVICE")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_DP_TEST_POINTS="40")
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), "4", "1", "2"], env))
+    assert r.returncode == 0, _verdict(r)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    assert int(ranks[1]["own"][1]) == 0 and int(ranks[0]["own"][1]) == 40
+    assert_bits_equal(ranks[0]["gaussians"], ranks[1]["gaussians"], "replicas with an empty slice on rank 1")
+    assert_bits_equal(ranks[0]["sh"], ranks[1]["sh"], "replica SH rows with an empty slice on rank 1")
+
+
+def test_a_rank_with_an_empty_slice(tmp_path):
+    """The same over gloo on the one GPU of the test box: 40 Gaussians, world = 2 -> rank 0 owns all of them (a slice is rounded up to
+    64), rank 1 owns none: its Adam launch is empty, it publishes no rows, takes part in every collective and ends with the same cloud."""
+    env = dict(os.environ, WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_DP_TEST_POINTS="40")
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), "4", "1", "2"], env))
+    assert r.returncode == 0, _verdict(r)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    assert int(ranks[1]["own"][1]) == 0 and int(ranks[0]["own"][1]) == 40
+    assert_bits_equal(ranks[0]["gaussians"], ranks[1]["gaussians"], "replicas with an empty slice on rank 1")
+    assert_bits_equal(ranks[0]["sh"], ranks[1]["sh"], "replica SH rows with an empty slice on rank 1")
+    for k in ("optPosBuffer", "stateSH"):
+        assert_bits_equal(ranks[0]["state_" + k], ranks[1]["state_" + k], f"gathered state {k} with an empty slice on rank 1")

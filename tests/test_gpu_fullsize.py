@@ -352,7 +352,8 @@ def test_c2_long_run_is_the_same_whichever_way_it_is_driven(hip_device):
 def test_c3_batched_step_on_lanes_equals_one_lane(hip_device):
     """BASELINE c3 / c4's per-rank step at full size -- 1 M Gaussians, 1920x1080, four views per step -- where the kernels of different
     lanes really do run side by side for hundreds of microseconds: three lanes with the pipelined submission must leave the bits of
-    one lane with every step awaited (cloud and optimizer state after 6 steps)."""
+    one lane with every step awaited (cloud and optimizer state after 6 steps), with the view-batched K1 / K17 kernels and with the
+    per-view ones."""
     from webdgs_amd.trainer import Trainer
     import bench
     dev = hip_device
@@ -361,8 +362,8 @@ def test_c3_batched_step_on_lanes_equals_one_lane(hip_device):
     tg, tsh = synth.make_target_scene(g, sh)
     cameras, images = bench.make_dataset(dev, cfg, tg, tsh, synth.circle_cameras(cfg, 4))
 
-    def run(lanes, depth):
-        t = Trainer(dev, seed=5, views_per_rank=4, overlap_views=lanes, pipeline_depth=depth)
+    def run(lanes, depth, batch_views=None):
+        t = Trainer(dev, seed=5, views_per_rank=4, overlap_views=lanes, pipeline_depth=depth, batch_views=batch_views)
         t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
         t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
         t.setDataset(cameras, images)
@@ -371,7 +372,8 @@ def test_c3_batched_step_on_lanes_equals_one_lane(hip_device):
         t.warmupCommandBuffers()
         on_lanes = 0
         for ids in ([3, 1, 0, 2], [2, 2, 1, 0], [0, 3, 3, 1], [1, 0, 2, 3], [3, 2, 1, 0], [0, 1, 2, 3]):
-            on_lanes += int(t._op_sets > 1 and all(("view", v, k % t._op_sets) in t._cmd_cache for k, v in enumerate(ids)))
+            key = (lambda k, v: ("viewp", v, k)) if t.batch_views else (lambda k, v: ("view", v, k % t._lanes))
+            on_lanes += int(t._lanes > 1 and all(key(k, v) in t._cmd_cache for k, v in enumerate(ids)))
             t.step(ids)
         t.drain()
         dev.synchronize()
@@ -380,7 +382,8 @@ def test_c3_batched_step_on_lanes_equals_one_lane(hip_device):
         t.destroy()
         return out, on_lanes
 
-    a, lanes_a = run(3, 2)
-    b, lanes_b = run(1, 1)
-    assert lanes_a == 6 and lanes_b == 0
-    assert a == b
+    a, lanes_a = run(3, 2)                       # view-batched K1 / K17 (round 3), one op set per view, three lanes
+    b, lanes_b = run(1, 1, batch_views=False)    # round 2's per-view kernels, one lane, every step awaited
+    c, lanes_c = run(3, 2, batch_views=False)    # ... and those on three lanes
+    assert lanes_a == 6 and lanes_b == 0 and lanes_c == 6
+    assert a == b and c == b

@@ -15,9 +15,9 @@ from harness import assert_bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _train(dev, overlap, steps, vpr, densify_at=None):
+def _train(dev, overlap, steps, vpr, densify_at=None, batch_views=None):
     cfg, g, sh, cameras, images = dp_common.dataset(dev)
-    t = Trainer(dev, seed=5, world_size=1, rank=0, views_per_rank=vpr, overlap_views=overlap)
+    t = Trainer(dev, seed=5, world_size=1, rank=0, views_per_rank=vpr, overlap_views=overlap, batch_views=batch_views)
     sched = dict(enabled=False) if densify_at is None else dict(enabled=True, warmupIterations=densify_at, interval=1000, stopIterations=10 ** 6)
     t.setDensifyPruneConfig(dict(schedule=sched, metricViews=3, cloneThresholdCount=5, splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
@@ -29,7 +29,8 @@ def _train(dev, overlap, steps, vpr, densify_at=None):
     for ids in dp_common.view_schedule(steps, 1, vpr):
         before = dict(t._cmd_cache)
         t.step(ids)
-        replays_on_lanes += int(t._op_sets > 1 and all(("view", v, k % t._op_sets) in before for k, v in enumerate(ids)))
+        key = (lambda k, v: ("viewp", v, k)) if t.batch_views else (lambda k, v: ("view", v, k % t._lanes))
+        replays_on_lanes += int(t._lanes > 1 and all(key(k, v) in before for k, v in enumerate(ids)))
     dev.synchronize()
     out = dict(g=t.pointCloud.gaussian_3d_buffer.read(np.uint32), sh=t.pointCloud.sh_buffer.read(np.uint32), n=t.getPointCount(),
                state={k: b.read(np.uint32) for k, b in t.optimizer.getStateBuffers().items()}, iteration=t.optimizer.getIteration(),
@@ -38,11 +39,14 @@ def _train(dev, overlap, steps, vpr, densify_at=None):
     return out
 
 
+@pytest.mark.parametrize("batch_views", [True, False], ids=["view-batched-K1-K17", "per-view-kernels"])
 @pytest.mark.parametrize("vpr,lanes", [(2, 2), (5, 2), (5, 3), (7, 4)])
-def test_overlapped_views_leave_the_same_bits(hip_device, vpr, lanes):
+def test_overlapped_views_leave_the_same_bits(hip_device, vpr, lanes, batch_views):
+    """`batch_views`: K1 and K17 of all the step's views in one launch each, one op set per view (round 3), or round 2's per-view kernels
+    with one op set per lane.  Either way, on lanes or not, the bits are those of the per-view, one-lane run."""
     steps = 6
-    a = _train(hip_device, lanes, steps, vpr)
-    b = _train(hip_device, False, steps, vpr)
+    a = _train(hip_device, lanes, steps, vpr, batch_views=batch_views)
+    b = _train(hip_device, False, steps, vpr, batch_views=False)
     assert a["on_lanes"] == steps and b["on_lanes"] == 0, "the overlapped run replayed on both lanes, the other one never did"
     assert a["iteration"] == b["iteration"] == a["taken"]
     assert_bits_equal(a["g"], b["g"], f"gaussians, {vpr} views per step: two lanes vs one")

@@ -106,6 +106,8 @@ SIGNATURES = {
     "wdgs_queue_wait": (_I, [_P, C.c_uint64]),
     "wdgs_device_select_lane": (_I, [_P, _I]),
     "wdgs_device_lane_order": (_I, [_P, _I, _I]),
+    "wdgs_device_lane_mark": (_I, [_P, _I, _I]),
+    "wdgs_device_lane_wait_mark": (_I, [_P, _I, _I]),
     "wdgs_encoder_begin": (_I, [_P]),
     "wdgs_encoder_finish": (_I, [_P, C.POINTER(_P)]),
     "wdgs_encoder_abort": (_I, [_P]),
@@ -143,6 +145,9 @@ SIGNATURES = {
     "wdgs_optimizer_flush_sh": (_I, [_P, _P]),
     "wdgs_optimizer_apply_repacked_rows": (_I, [_P, _P, _U, _U, _P, _P, _P]),
     "wdgs_tiled_forward_set_dc_source": (_I, [_P, _P]),
+    "wdgs_tiled_forward_project_views": (_I, [_P, _P, _U, _P, _P]),
+    "wdgs_tiled_forward_encode_projected": (_I, [_P]),
+    "wdgs_tiled_backward_encode_geometry_views": (_I, [_P, _P, _P, _P, _U, _P, _P, _P, _P, _I, _I]),
     "wdgs_guard_accumulate": (_I, [_P, _P, _P, _I]),
     "wdgs_optimizer_state_changed": (_I, [_P]),
     "wdgs_copy_to_host": (_I, [_P, _P, _P, _Z]),

@@ -23,6 +23,10 @@ int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdg
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*, void*);
 int launch_acc_clear_if_dirty(wdgs_device*, void*, u32, void*);
+int launch_geometry_backward_views(wdgs_device*, u32, u32, const void* const*, const RenderSettings&, const void*, void* const*, void* const*, const void* const*,
+                                   const void* const*, void* const*, void*, void*, void*, u32);
+int launch_project_count_views(wdgs_device*, u32, u32, const void*, const void*, const void* const*, const RenderSettings&, const TileInfo&, void* const*, void* const*,
+                               void* const*, void* const*, void* const*, void* const*, const void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*);
 int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
                                   const wdgs_optimizer_state&, void*, void*, const void*, void*);
@@ -122,6 +126,8 @@ struct wdgs_tiled_forward {
     u32 ranges_capacity;
     bool ranges_valid;
     bool encoded;
+    bool projected;          // K1 of the current frame ran through wdgs_tiled_forward_project_views
+    bool projected_columns;  // ... and counted per tile column
 };
 
 struct wdgs_tiled_rasterizer {
@@ -243,6 +249,28 @@ int wdgs_device_lane_order(wdgs_device* d, int waiter, int signal) {
     return WDGS_OK;
 }
 
+// A position on a lane, kept in one of WDGS_MAX_BATCH_VIEWS numbered marks, that other lanes can be made to wait for LATER (lane_order
+// records and waits in one call): a batched step projects its view groups one after the other on one lane and lets each view wait only
+// for its own group's projection.
+int wdgs_device_lane_mark(wdgs_device* d, int lane, int mark) {
+    WDGS_REQUIRE(d && lane >= 0 && lane < WDGS_MAX_LANES && mark >= 0 && mark < WDGS_MAX_BATCH_VIEWS, WDGS_E_INVALID, "wdgs_device_lane_mark: lane %d, mark %d", lane, mark);
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_lane_mark while recording a command buffer");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    if (!d->lanes[lane]) WDGS_CHECK_HIP(hipStreamCreateWithFlags(&d->lanes[lane], hipStreamNonBlocking));
+    if (!d->lane_marks[mark]) WDGS_CHECK_HIP(hipEventCreateWithFlags(&d->lane_marks[mark], hipEventDisableTiming));
+    WDGS_CHECK_HIP(hipEventRecord(d->lane_marks[mark], d->lanes[lane]));
+    return WDGS_OK;
+}
+int wdgs_device_lane_wait_mark(wdgs_device* d, int lane, int mark) {
+    WDGS_REQUIRE(d && lane >= 0 && lane < WDGS_MAX_LANES && mark >= 0 && mark < WDGS_MAX_BATCH_VIEWS, WDGS_E_INVALID, "wdgs_device_lane_wait_mark: lane %d, mark %d", lane, mark);
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_device_lane_wait_mark while recording a command buffer");
+    WDGS_REQUIRE(d->lane_marks[mark], WDGS_E_STATE, "wdgs_device_lane_wait_mark: mark %d was never set", mark);
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    if (!d->lanes[lane]) WDGS_CHECK_HIP(hipStreamCreateWithFlags(&d->lanes[lane], hipStreamNonBlocking));
+    WDGS_CHECK_HIP(hipStreamWaitEvent(d->lanes[lane], d->lane_marks[mark], 0));
+    return WDGS_OK;
+}
+
 // Folds the finished event pairs into the per-kernel totals.  Pairs whose kernels have not finished yet (a wait for an earlier ticket,
 // a query between steps) stay pending: events of one queue complete in order, so the scan stops at the first unfinished pair.
 static int collect_profile(wdgs_device* d) {
@@ -334,6 +362,7 @@ int wdgs_device_destroy(wdgs_device* d) {
     collect_profile(d);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lane_events) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->lane_marks) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->ticket_events) if (e) (void)hipEventDestroy(e);
     if (d->host_guard) (void)hipHostFree(d->host_guard);
     for (int l = 1; l < WDGS_MAX_LANES; l++)
@@ -606,6 +635,7 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->ranges_capacity = 0;
     op->ranges_valid = false;
     op->encoded = false;
+    op->projected = op->projected_columns = false;
     const u32 n = cfg->num_points;
     const uint64_t cap = forward_tile_entry_cap(*cfg, n);
     op->points_capacity = std::max(n, 1u);
@@ -684,6 +714,7 @@ int wdgs_tiled_forward_resize(wdgs_tiled_forward* op, uint32_t n) {
     std::memset(op->host_stats, 0, 16);
     op->encoded = false;
     op->ranges_valid = false;
+    op->projected = false;
     return WDGS_OK;
 }
 
@@ -693,25 +724,22 @@ static u32 bits_for(u32 v) {  // number of bits needed to represent v
     return b;
 }
 
-int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, const void* sh, const void* camera, int skip_sort) {
-    WDGS_REQUIRE(op && gaussians && sh && camera, WDGS_E_INVALID, "wdgs_tiled_forward_encode: null argument");
-    wdgs_device* d = op->dev;
-    const u32 n = op->cfg.num_points;
-    // clearBuffer(pipelineStatsBuffer) (tiled-forward-pass.ts:345) needs no launch here: update_stats overwrites words 0..2, word 3
-    // stays 0, and the visible count is accumulated in shard words that update_stats clears after folding them.
-    // The offsets scan (K2-K4) is spread over its neighbours: project_count leaves the entry count of each of its workgroups, one
-    // single-workgroup kernel scans those N/256 sums (and publishes the stats block: update_stats, K5, as its epilogue), and emit adds
-    // its own in-workgroup prefix -- writing the per-Gaussian offsets table on the way.  Three launches instead of five.
-    // The tile sort's first pass is folded into its neighbours when the grid allows it (2..256 tile columns, <= 256 tile rows: any
-    // viewport up to 4096 x 4096): project_count also counts its workgroups' entries per tile COLUMN, the scan kernel turns those into
-    // per-column offsets, and emit writes its entries straight into column order (project.hip: emit_scatter) -- the keys are never
-    // written in emission order, histogrammed and scattered.  encode(skipSort) and compat_caps keep the reference's emission order.
-    const TileInfo& ti = op->tile_info;
+// The tile sort's first pass is folded into its neighbours when the grid allows it (2..256 tile columns, <= 256 tile rows: any
+// viewport up to 4096 x 4096): project_count also counts its workgroups' entries per tile COLUMN, the scan kernel turns those into
+// per-column offsets, and emit writes its entries straight into column order (project.hip: emit_scatter) -- the keys are never
+// written in emission order, histogrammed and scattered.  encode(skipSort) and compat_caps keep the reference's emission order.
+static bool forward_uses_columns(const wdgs_tiled_forward* op, int skip_sort) {
     // (WDGS_FORWARD_COLUMNS=0: the separate emit + two-pass tile sort of round 2, for same-box A/B timing; results are identical)
     static const bool columns_enabled = !(std::getenv("WDGS_FORWARD_COLUMNS") && std::getenv("WDGS_FORWARD_COLUMNS")[0] == '0');
-    const bool columns = columns_enabled && !skip_sort && !op->cfg.compat_caps && n > 0 && ti.num_tiles_x >= 2u && ti.num_tiles_x <= 256u && ti.num_tiles_y <= 256u;
-    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
-                                  op->block_counts, columns ? op->column_counts : nullptr, op->dc_source));
+    const TileInfo& ti = op->tile_info;
+    return columns_enabled && !skip_sort && !op->cfg.compat_caps && op->cfg.num_points > 0 && ti.num_tiles_x >= 2u && ti.num_tiles_x <= 256u && ti.num_tiles_y <= 256u;
+}
+
+// Everything of TiledForwardPass.encode behind K1: scan (+ stats), emit, sort.
+static int forward_encode_rest(wdgs_tiled_forward* op, int skip_sort, bool columns) {
+    wdgs_device* d = op->dev;
+    const u32 n = op->cfg.num_points;
+    const TileInfo& ti = op->tile_info;
     const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries};
     if (columns) {
         WDGS_TRY(forward_scan(d, op->block_counts, ceil_div(n, 256), op->column_counts, op->column_totals, ti.num_tiles_x, ep));
@@ -755,6 +783,50 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     }
     op->encoded = true;
     return WDGS_OK;
+}
+
+int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, const void* sh, const void* camera, int skip_sort) {
+    WDGS_REQUIRE(op && gaussians && sh && camera, WDGS_E_INVALID, "wdgs_tiled_forward_encode: null argument");
+    wdgs_device* d = op->dev;
+    const u32 n = op->cfg.num_points;
+    // clearBuffer(pipelineStatsBuffer) (tiled-forward-pass.ts:345) needs no launch here: update_stats overwrites words 0..2, word 3
+    // stays 0, and the visible count is accumulated in shard words that update_stats clears after folding them.
+    // The offsets scan (K2-K4) is spread over its neighbours: project_count leaves the entry count of each of its workgroups, one
+    // single-workgroup kernel scans those N/256 sums (and publishes the stats block: update_stats, K5, as its epilogue), and emit adds
+    // its own in-workgroup prefix -- writing the per-Gaussian offsets table on the way.  Three launches instead of five.
+    const bool columns = forward_uses_columns(op, skip_sort);
+    WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
+                                  op->block_counts, columns ? op->column_counts : nullptr, op->dc_source));
+    return forward_encode_rest(op, skip_sort, columns);
+}
+
+// ---- view-batched K1 (include/webdgs.h)
+int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void* const* cameras, uint32_t count, const void* gaussians, const void* sh) {
+    WDGS_REQUIRE(ops && cameras && gaussians && sh && count > 0 && count <= WDGS_MAX_BATCH_VIEWS, WDGS_E_INVALID, "wdgs_tiled_forward_project_views: invalid argument");
+    wdgs_tiled_forward* f0 = ops[0];
+    WDGS_REQUIRE(f0, WDGS_E_INVALID, "wdgs_tiled_forward_project_views: null pass");
+    const bool columns = forward_uses_columns(f0, 0);
+    void *splats[WDGS_MAX_BATCH_VIEWS], *depths[WDGS_MAX_BATCH_VIEWS], *counts[WDGS_MAX_BATCH_VIEWS], *shards[WDGS_MAX_BATCH_VIEWS], *blocks[WDGS_MAX_BATCH_VIEWS],
+        *cols[WDGS_MAX_BATCH_VIEWS];
+    for (u32 v = 0; v < count; v++) {
+        wdgs_tiled_forward* f = ops[v];
+        WDGS_REQUIRE(f && cameras[v], WDGS_E_INVALID, "wdgs_tiled_forward_project_views: null pass or camera %u", v);
+        for (u32 u = 0; u < v; u++) WDGS_REQUIRE(ops[u] != f, WDGS_E_INVALID, "wdgs_tiled_forward_project_views: pass %u is given twice (every view needs buffers of its own)", v);
+        WDGS_REQUIRE(f->dev == f0->dev && f->cfg.num_points == f0->cfg.num_points && f->cfg.sh_deg == f0->cfg.sh_deg && f->cfg.compat_caps == f0->cfg.compat_caps &&
+                         std::memcmp(&f->settings, &f0->settings, sizeof(RenderSettings)) == 0 && f->tile_info.num_tiles_x == f0->tile_info.num_tiles_x &&
+                         f->tile_info.num_tiles_y == f0->tile_info.num_tiles_y && f->dc_source == f0->dc_source,
+                     WDGS_E_STATE, "wdgs_tiled_forward_project_views: pass %u differs from pass 0 (cloud size, SH degree, viewport, settings or dc source)", v);
+        splats[v] = f->splats; depths[v] = f->depths; counts[v] = f->scanner->input; shards[v] = f->stats + 4; blocks[v] = f->block_counts; cols[v] = f->column_counts;
+    }
+    WDGS_TRY(launch_project_count_views(f0->dev, f0->cfg.num_points, count, gaussians, sh, cameras, f0->settings, f0->tile_info, splats, depths, counts, shards, blocks,
+                                        columns ? cols : nullptr, f0->dc_source));
+    for (u32 v = 0; v < count; v++) { ops[v]->projected = true; ops[v]->projected_columns = columns; }
+    return WDGS_OK;
+}
+int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_encode_projected: null op");
+    WDGS_REQUIRE(op->projected, WDGS_E_STATE, "wdgs_tiled_forward_encode_projected: the pass has not been projected (wdgs_tiled_forward_project_views)");
+    return forward_encode_rest(op, 0, op->projected_columns);
 }
 
 int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t h) {
@@ -1000,6 +1072,25 @@ int wdgs_tiled_backward_encode_geometry(wdgs_tiled_backward* op, const void* cam
                  "wdgs_tiled_backward_encode_geometry: incomplete accumulate target");
     return launch_geometry_backward_accumulate(op->dev, op->cfg.num_points, camera, op->settings, gaussians, op->acc, op->acc_dirty, op->gradients, into->sums, into->visible,
                                                into->tile_counts, into->guard, into->overflow_word, into->first ? 1u : 2u);
+}
+// ---- view-batched K17 (include/webdgs.h)
+int wdgs_tiled_backward_encode_geometry_views(wdgs_tiled_backward* const* ops, const void* const* cameras, const void* const* tile_counts, const void* const* overflow_words,
+                                              uint32_t count, const void* gaussians, void* sums, void* visible, void* guard, int write_gradients, int continues) {
+    WDGS_REQUIRE(ops && cameras && tile_counts && overflow_words && gaussians && sums && visible && guard && count > 0 && count <= WDGS_MAX_BATCH_VIEWS, WDGS_E_INVALID,
+                 "wdgs_tiled_backward_encode_geometry_views: invalid argument");
+    wdgs_tiled_backward* b0 = ops[0];
+    WDGS_REQUIRE(b0, WDGS_E_INVALID, "wdgs_tiled_backward_encode_geometry_views: null pass");
+    void *accs[WDGS_MAX_BATCH_VIEWS], *dirty[WDGS_MAX_BATCH_VIEWS], *grads[WDGS_MAX_BATCH_VIEWS];
+    for (u32 v = 0; v < count; v++) {
+        wdgs_tiled_backward* b = ops[v];
+        WDGS_REQUIRE(b && cameras[v] && tile_counts[v] && overflow_words[v], WDGS_E_INVALID, "wdgs_tiled_backward_encode_geometry_views: null argument for view %u", v);
+        for (u32 u = 0; u < v; u++) WDGS_REQUIRE(ops[u] != b, WDGS_E_INVALID, "wdgs_tiled_backward_encode_geometry_views: pass %u is given twice (every view has accumulators of its own)", v);
+        WDGS_REQUIRE(b->dev == b0->dev && b->cfg.num_points == b0->cfg.num_points && std::memcmp(&b->settings, &b0->settings, sizeof(RenderSettings)) == 0, WDGS_E_STATE,
+                     "wdgs_tiled_backward_encode_geometry_views: pass %u differs from pass 0 (cloud size, viewport or settings)", v);
+        accs[v] = b->acc; dirty[v] = b->acc_dirty; grads[v] = b->gradients;
+    }
+    return launch_geometry_backward_views(b0->dev, b0->cfg.num_points, count, cameras, b0->settings, gaussians, accs, dirty, tile_counts, overflow_words,
+                                          write_gradients ? grads : nullptr, sums, visible, guard, continues ? 1u : 0u);
 }
 int wdgs_tiled_backward_compute_metric_map(wdgs_tiled_backward* op, const void* pred, const void* targ, float threshold) {
     WDGS_REQUIRE(op && pred && targ, WDGS_E_INVALID, "wdgs_tiled_backward_compute_metric_map: null argument");

@@ -42,31 +42,14 @@ struct ViewAdam {
 
 // MODE 1: the view's gradient also goes into the step's fp32 block -- the values that accumulate_gradients / store_gradients
 // (optimizer.hip) would read back from the packed fp16 gradient, taken from the registers that were just packed.  MODE 2: Adam.
-template <int MODE>
-__global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
-                                                                 const u32* gaussians, int* __restrict__ acc, u32* __restrict__ acc_dirty,
-                                                                 u32* __restrict__ gradients, ViewAccumulate va, ViewAdam ad) {
-    constexpr bool ACC = MODE == 1;
-    // The Trainer's forms (MODE 1, 2) CONSUME the accumulators: a row that held sums is put back to zero by the thread that read it and
-    // the state word says "clean", so the next view's clear has nothing to do (backward_raster.hip: acc_clear_if_dirty).  The plain
-    // form (MODE 0: TiledBackwardPass.encode) leaves the sums in place for readers.
-    constexpr bool CONSUME = MODE != 0;
-    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ACC && idx == 0u) *va.guard = (va.mode == 1u ? 0u : *va.guard) | (*va.overflow != 0u ? 1u : 0u);  // guard_accumulate (optimizer.hip)
-    if (CONSUME && idx == 0u) *acc_dirty = 0u;
-    if (idx >= n) return;
-    int4* ap = reinterpret_cast<int4*>(acc + (size_t)idx * ACC_STRIDE);
-    const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-    if (CONSUME && ((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w | a2.x | a2.y | a2.z | a2.w) != 0)) {
-        const int4 z = make_int4(0, 0, 0, 0);
-        ap[0] = z; ap[1] = z; ap[2] = z;
-    }
+// K17 for one Gaussian under one camera: the three accumulator quads and the Gaussian's six words in, the packed GaussianGradient out
+// (tiled-backward.wgsl:41-298).  Shared by the per-view kernel and the view-batched one, so both evaluate the same operations in the same order.
+WD_DEV void geometry_chain(const int4 a0, const int4 a1, const int4 a2, const uint2 w01, const uint2 w23, const uint2 w45, const float* __restrict__ camera_f,
+                           const RenderSettings& settings, uint4& o0, uint4& o1) {
     const vec2 dL_dmean2D_px = V2(from_fixed(a0.x), from_fixed(a0.y));
     const vec3 dL_dconic = V3(from_fixed(a0.z), from_fixed(a0.w), from_fixed(a1.x));
     const float dL_dopac = from_fixed(a1.y);
 
-    const u32* gp = gaussians + (size_t)idx * 6;
-    const uint2 w01 = *reinterpret_cast<const uint2*>(gp), w23 = *reinterpret_cast<const uint2*>(gp + 2), w45 = *reinterpret_cast<const uint2*>(gp + 4);
     const vec3 mean3D = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
     const float opacity_raw = wd_unpack_hi(w01.y);
     const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
@@ -182,7 +165,6 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
             }
         }
     }
-    uint4 o0, o1;
     o0.x = wd_pack2(final_dL_dmean3D.x, final_dL_dmean3D.y);
     o0.y = wd_pack2(final_dL_dmean3D.z, dL_dopacity_raw);
     o0.z = wd_pack2(dL_drot_x, dL_drot_y);
@@ -192,6 +174,31 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
     o1.z = wd_pack2(from_fixed(a1.z), from_fixed(a1.w));
     // blue arrives as four partial sums, one per 16-lane row of the waves that produced it (backward_raster.hip); i32 sums wrap, as atomicAdd does
     o1.w = wd_pack2(from_fixed((int)((unsigned)a2.x + (unsigned)a2.y + (unsigned)a2.z + (unsigned)a2.w)), 0.0f);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
+                                                                 const u32* gaussians, int* __restrict__ acc, u32* __restrict__ acc_dirty,
+                                                                 u32* __restrict__ gradients, ViewAccumulate va, ViewAdam ad) {
+    constexpr bool ACC = MODE == 1;
+    // The Trainer's forms (MODE 1, 2) CONSUME the accumulators: a row that held sums is put back to zero by the thread that read it and
+    // the state word says "clean", so the next view's clear has nothing to do (backward_raster.hip: acc_clear_if_dirty).  The plain
+    // form (MODE 0: TiledBackwardPass.encode) leaves the sums in place for readers.
+    constexpr bool CONSUME = MODE != 0;
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ACC && idx == 0u) *va.guard = (va.mode == 1u ? 0u : *va.guard) | (*va.overflow != 0u ? 1u : 0u);  // guard_accumulate (optimizer.hip)
+    if (CONSUME && idx == 0u) *acc_dirty = 0u;
+    if (idx >= n) return;
+    int4* ap = reinterpret_cast<int4*>(acc + (size_t)idx * ACC_STRIDE);
+    const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    if (CONSUME && ((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w | a2.x | a2.y | a2.z | a2.w) != 0)) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        ap[0] = z; ap[1] = z; ap[2] = z;
+    }
+    const u32* gp = gaussians + (size_t)idx * 6;
+    const uint2 w01 = *reinterpret_cast<const uint2*>(gp), w23 = *reinterpret_cast<const uint2*>(gp + 2), w45 = *reinterpret_cast<const uint2*>(gp + 4);
+    uint4 o0, o1;
+    geometry_chain(a0, a1, a2, w01, w23, w45, camera_f, settings, o0, o1);
     uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
     op[0] = o0;
     op[1] = o1;
@@ -230,6 +237,81 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
     }
 }
 
+
+// K17 for ALL the views of a batched step in one pass over the Gaussians (the Trainer's view-batched step; no reference counterpart: the
+// reference is batch-1).  Per view the thread reads that view's accumulator row (and puts it back to zero), evaluates the same chain rule
+// under that view's camera, rounds the gradient to fp16 as K17 does, and adds it -- in VIEW ORDER, fp32, the first visible view's value
+// stored, later ones added: exactly the sequence of the per-view accumulate kernels -- into a register copy of the step's fp32 block,
+// which is written once.  The Gaussian is read once instead of once per view, the 60-byte fp32 row is written once instead of being
+// read-modify-written per view, and the per-view kernels' cross-lane ordering (view k's sums behind view k-1's) disappears.
+struct GeometryViews {
+    u32 count;
+    const float* camera[WDGS_MAX_BATCH_VIEWS];
+    int* acc[WDGS_MAX_BATCH_VIEWS];
+    u32* acc_dirty[WDGS_MAX_BATCH_VIEWS];
+    const u32* tile_counts[WDGS_MAX_BATCH_VIEWS];
+    const u32* overflow[WDGS_MAX_BATCH_VIEWS];
+    u32* gradients[WDGS_MAX_BATCH_VIEWS];   // nullable per view: the packed per-view GaussianGradient, for readers of getGradientsBuffer()
+};
+__global__ __launch_bounds__(256, 4) void geometry_backward_views_kernel(u32 n, RenderSettings settings, const u32* __restrict__ gaussians, GeometryViews gv,
+                                                                        float* __restrict__ sums, u32* __restrict__ visible, u32* __restrict__ guard,
+                                                                        u32 continues /*0: these are the step's first views; 1: the block already holds earlier views*/) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0u) {
+        u32 g = continues ? *guard : 0u;
+        for (u32 v = 0; v < gv.count; v++) { g |= (*gv.overflow[v] != 0u) ? 1u : 0u; *gv.acc_dirty[v] = 0u; }
+        *guard = g;
+    }
+    if (idx >= n) return;
+    const u32* gp = gaussians + (size_t)idx * 6;
+    const uint2 w01 = *reinterpret_cast<const uint2*>(gp), w23 = *reinterpret_cast<const uint2*>(gp + 2), w45 = *reinterpret_cast<const uint2*>(gp + 4);
+    float s[14];
+    u32 nvis = 0u;
+    float2* a2p = reinterpret_cast<float2*>(sums + (size_t)idx * 14);  // 56-byte rows: 8-byte aligned
+    if (continues) {   // a later group of the step's views: go on from what the earlier groups left
+#pragma unroll
+        for (u32 k = 0; k < 7u; k++) { const float2 t = a2p[k]; s[2 * k] = t.x; s[2 * k + 1] = t.y; }
+        nvis = visible[idx];
+    } else {
+#pragma unroll
+        for (u32 k = 0; k < 14u; k++) s[k] = 0.0f;
+    }
+    for (u32 v = 0; v < gv.count; v++) {
+        int4* ap = reinterpret_cast<int4*>(gv.acc[v] + (size_t)idx * ACC_STRIDE);
+        const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+        const bool vis = gv.tile_counts[v][idx] != 0u;
+        if ((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w | a2.x | a2.y | a2.z | a2.w) != 0) {
+            const int4 z = make_int4(0, 0, 0, 0);
+            ap[0] = z; ap[1] = z; ap[2] = z;
+        }
+        u32* gout = gv.gradients[v];
+        if (!vis && !gout) continue;   // (a Gaussian outside the view contributes nothing; its packed gradient is only of interest to a reader)
+        uint4 o0, o1;
+        geometry_chain(a0, a1, a2, w01, w23, w45, gv.camera[v], settings, o0, o1);
+        if (gout) {
+            uint4* op = reinterpret_cast<uint4*>(gout + (size_t)idx * 8);
+            op[0] = o0;
+            op[1] = o1;
+        }
+        if (vis) {
+            // the fp16-rounded values, in the block's order: pos.xyz, opacity, rot.wxyz, scale.xyz, colour.rgb
+            const float g[14] = {wd_unpack_lo(o0.x), wd_unpack_hi(o0.x), wd_unpack_lo(o0.y), wd_unpack_hi(o0.y), wd_unpack_lo(o0.z), wd_unpack_hi(o0.z), wd_unpack_lo(o0.w),
+                                 wd_unpack_hi(o0.w), wd_unpack_lo(o1.x), wd_unpack_hi(o1.x), wd_unpack_lo(o1.y), wd_unpack_lo(o1.z), wd_unpack_hi(o1.z), wd_unpack_lo(o1.w)};
+            if (v == 0u && !continues) {   // the per-view path STORES the step's first view's value (a -0.0 stays -0.0) and adds the later ones
+#pragma unroll
+                for (u32 k = 0; k < 14u; k++) s[k] = g[k];
+            } else {
+#pragma unroll
+                for (u32 k = 0; k < 14u; k++) s[k] = s[k] + g[k];
+            }
+            nvis++;
+        }
+    }
+#pragma unroll
+    for (u32 k = 0; k < 7u; k++) a2p[k] = make_float2(s[2 * k], s[2 * k + 1]);
+    visible[idx] = nvis;
+}
+
 }  // namespace
 
 int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, void* acc, void* acc_dirty, void* gradients,
@@ -258,6 +340,22 @@ int launch_geometry_backward_accumulate(wdgs_device* dev, u32 n, const void* cam
     WDGS_LAUNCH(dev, "geometry_backward", geometry_backward_kernel<1>, dim3(std::max(ceil_div(n, 256), 1u)), dim3(256), 0, n, (const float*)camera, st,
                 (const u32*)gaussians, (int*)acc, (u32*)acc_dirty, (u32*)gradients,
                 (ViewAccumulate{(float*)sums, (u32*)visible, (const u32*)tile_counts, (u32*)guard, (const u32*)overflow, mode}), ViewAdam{});
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_geometry_backward_views(wdgs_device* dev, u32 n, u32 count, const void* const* cameras, const RenderSettings& st, const void* gaussians, void* const* accs,
+                                   void* const* acc_dirtys, const void* const* tile_counts, const void* const* overflows, void* const* gradients, void* sums, void* visible,
+                                   void* guard, u32 continues) {
+    GeometryViews gv{};
+    gv.count = count;
+    for (u32 v = 0; v < count; v++) {
+        gv.camera[v] = (const float*)cameras[v]; gv.acc[v] = (int*)accs[v]; gv.acc_dirty[v] = (u32*)acc_dirtys[v]; gv.tile_counts[v] = (const u32*)tile_counts[v];
+        gv.overflow[v] = (const u32*)overflows[v]; gv.gradients[v] = gradients ? (u32*)gradients[v] : nullptr;
+    }
+    // (n == 0 still runs one workgroup: the guard word must be written)
+    WDGS_LAUNCH(dev, "geometry_backward_views", geometry_backward_views_kernel, dim3(std::max(ceil_div(n, 256), 1u)), dim3(256), 0, n, st, (const u32*)gaussians, gv,
+                (float*)sums, (u32*)visible, (u32*)guard, continues);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

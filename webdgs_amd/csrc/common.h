@@ -47,6 +47,7 @@ struct wdgs_device {
     // rasterization kernels of another (api.hip: wdgs_device_select_lane / wdgs_device_lane_order).
     hipStream_t lanes[WDGS_MAX_LANES] = {};
     hipEvent_t lane_events[WDGS_MAX_LANES] = {};
+    hipEvent_t lane_marks[WDGS_MAX_BATCH_VIEWS] = {};  // wdgs_device_lane_mark / wdgs_device_lane_wait_mark
     int lane = 0;
     // Tickets (wdgs_queue_mark / wdgs_queue_wait): a ring of events, so a host can wait for step k-1 while step k runs.
     hipEvent_t ticket_events[WDGS_TICKET_RING] = {};

@@ -100,6 +100,89 @@ WD_DEV TileBox tile_box(vec2 ndc_f16, vec2 extents_f16, vec2 viewport, u32 ntx, 
     return b;
 }
 
+// K1 for one Gaussian under one camera (tiled-forward.wgsl:161-294): false = culled (nothing is written); true = visible: Splat and depth
+// are written, the tile count and the box come back.  Shared by the per-view kernel and the view-batched one, so both evaluate the same
+// operations in the same order.
+WD_DEV bool project_one(u32 idx, const uint2 w01, const uint2 w23, const uint2 w45, const ShRow& sh_row, const float* __restrict__ camera_f,
+                        const RenderSettings& settings, const TileInfo& ti, u32* __restrict__ splats, u32* __restrict__ depths, u32& num_tiles_out, u32& box_x0,
+                        u32& box_x1, u32& box_rows) {
+    const vec4 quaternion = V4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w23.y));
+    const vec3 gaussian_scale = vexp(V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y)));
+    const vec3 pos = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
+    const float opacity_raw = wd_unpack_hi(w01.y);
+    const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
+
+    const CameraUniforms& cam = *reinterpret_cast<const CameraUniforms*>(camera_f);
+    const mat4 view = cam.view;
+    const vec4 world_to_view = view * V4(pos, 1.0f);
+    const vec4 clip = cam.proj * world_to_view;
+    if (clip.w == 0.0f) return false;
+    const vec3 ndc = xyz(clip) / clip.w;
+    if (ndc.x < -1.2f || ndc.x > 1.2f || ndc.y < -1.2f || ndc.y > 1.2f || ndc.z < 0.0f || ndc.z > 1.0f) return false;
+
+    const Cov3D c3 = covariance3D(quaternion, gaussian_scale);
+    const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
+    const vec3 c2 = covariance2D(c3, world_to_view, cam.focal, viewport, view);
+    const float det = (c2.x * c2.z) - (c2.y * c2.y);
+    if (det <= 0.0f) return false;
+    const float det_inv = wd_div(1.0f, det);
+    const vec3 conic = V3(c2.z * det_inv, -c2.y * det_inv, c2.x * det_inv);
+    const float disc = conic.y * conic.y - conic.x * conic.z;
+    if (conic.x <= 0.0f || conic.z <= 0.0f || disc >= 0.0f) return false;
+
+    const float t = 2.0f * wd_log(opacity_sigmoid * 128.0f);
+    if (t <= 0.0f) return false;
+    const float x_extent = wd_sqrt(wd_div(t * conic.z, -disc));
+    const float y_extent = wd_sqrt(wd_div(t * conic.x, -disc));
+    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
+    const float xec = wd_min(x_extent, cap), yec = wd_min(y_extent, cap);
+    // Round-trip through fp16 so emit/raster/backward (which only see the Splat) agree on the bbox.
+    const u32 ndc_packed = wd_pack2(wd_clamp(ndc.x, -60000.0f, 60000.0f), wd_clamp(ndc.y, -60000.0f, 60000.0f));
+    const u32 ext_packed = wd_pack2(xec, yec);
+    const vec2 ndc_store = V2(wd_unpack_lo(ndc_packed), wd_unpack_hi(ndc_packed));
+    const vec2 ext_f16 = V2(wd_unpack_lo(ext_packed), wd_unpack_hi(ext_packed));
+    const TileBox tb = tile_box(ndc_store, ext_f16, viewport, ti.num_tiles_x, ti.num_tiles_y, true);
+    if (!tb.valid) return false;
+
+    const vec3 cam_pos = xyz(cam.view_inv.c[3]);
+    const vec3 dir = normalize(pos - cam_pos);
+    const vec3 color = color_from_sh(sh_row, dir, wd_to_u32(settings.sh_deg));
+
+    const u32 num_tiles = (tb.max_x - tb.min_x + 1u) * (tb.max_y - tb.min_y + 1u);
+    if (num_tiles > 2048u) return false;
+
+    u32* s = splats + (size_t)idx * 6;
+    uint2 o01, o23, o45;
+    o01.x = ndc_packed;
+    o01.y = ext_packed;
+    o23.x = wd_pack2(conic.x, conic.y);
+    o23.y = wd_pack2(conic.z, 0.0f);
+    o45.x = wd_pack2(wd_clamp(color.x, 0.0f, 1.0f), wd_clamp(color.y, 0.0f, 1.0f));
+    o45.y = wd_pack2(wd_clamp(color.z, 0.0f, 1.0f), wd_clamp(opacity_sigmoid, 0.0f, 1.0f));
+    *reinterpret_cast<uint2*>(s) = o01;
+    *reinterpret_cast<uint2*>(s + 2) = o23;
+    *reinterpret_cast<uint2*>(s + 4) = o45;
+    depths[idx] = ordered_uint(world_to_view.z);
+    num_tiles_out = num_tiles;
+    box_x0 = tb.min_x; box_x1 = tb.max_x; box_rows = tb.max_y - tb.min_y + 1u;
+    return true;
+}
+
+// The Gaussian's six words and its SH row (with the optimizer's deferred DC halves, adam.h), fetched together at the top
+WD_DEV void load_gaussian_and_sh(u32 idx, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer, const u32* __restrict__ dc_words, u32 sh_deg,
+                                 uint2& w01, uint2& w23, uint2& w45, ShRow& sh_row) {
+    const u32* g = gaussians + (size_t)idx * 6;
+    w01 = *reinterpret_cast<const uint2*>(g);
+    w23 = *reinterpret_cast<const uint2*>(g + 2);
+    w45 = *reinterpret_cast<const uint2*>(g + 4);
+    sh_row = load_sh_row(sh_buffer, idx, sh_deg);
+    if (dc_words) {  // the optimizer defers its writes of the row's first six bytes: the current values are here
+        const uint2 dcw = *reinterpret_cast<const uint2*>(dc_words + (size_t)idx * 2);
+        sh_row.w[0] = dcw.x;
+        sh_row.w[1] = (sh_row.w[1] & 0xFFFF0000u) | (dcw.y & 0xFFFFu);
+    }
+}
+
 __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer,
                                                              const float* __restrict__ camera_f, RenderSettings settings, TileInfo ti,
                                                              u32* __restrict__ splats, u32* __restrict__ depths,
@@ -118,78 +201,10 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
         __syncthreads();
     }
     if (idx < n) {
-        do {
-            const u32* g = gaussians + (size_t)idx * 6;
-            const uint2 w01 = *reinterpret_cast<const uint2*>(g);
-            const uint2 w23 = *reinterpret_cast<const uint2*>(g + 2);
-            const uint2 w45 = *reinterpret_cast<const uint2*>(g + 4);
-            const vec4 quaternion = V4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w23.y));
-            const vec3 gaussian_scale = vexp(V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y)));
-            const vec3 pos = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
-            const float opacity_raw = wd_unpack_hi(w01.y);
-            ShRow sh_row = load_sh_row(sh_buffer, idx, wd_to_u32(settings.sh_deg));
-            if (dc_words) {  // the optimizer defers its writes of the row's first six bytes: the current values are here
-                const uint2 dcw = *reinterpret_cast<const uint2*>(dc_words + (size_t)idx * 2);
-                sh_row.w[0] = dcw.x;
-                sh_row.w[1] = (sh_row.w[1] & 0xFFFF0000u) | (dcw.y & 0xFFFFu);
-            }
-            const float opacity_sigmoid = wd_div(1.0f, 1.0f + wd_exp(-opacity_raw));
-
-            const CameraUniforms& cam = *reinterpret_cast<const CameraUniforms*>(camera_f);
-            const mat4 view = cam.view;
-            const vec4 world_to_view = view * V4(pos, 1.0f);
-            const vec4 clip = cam.proj * world_to_view;
-            if (clip.w == 0.0f) break;
-            const vec3 ndc = xyz(clip) / clip.w;
-            if (ndc.x < -1.2f || ndc.x > 1.2f || ndc.y < -1.2f || ndc.y > 1.2f || ndc.z < 0.0f || ndc.z > 1.0f) break;
-
-            const Cov3D c3 = covariance3D(quaternion, gaussian_scale);
-            const vec2 viewport = V2(settings.viewport_x, settings.viewport_y);
-            const vec3 c2 = covariance2D(c3, world_to_view, cam.focal, viewport, view);
-            const float det = (c2.x * c2.z) - (c2.y * c2.y);
-            if (det <= 0.0f) break;
-            const float det_inv = wd_div(1.0f, det);
-            const vec3 conic = V3(c2.z * det_inv, -c2.y * det_inv, c2.x * det_inv);
-            const float disc = conic.y * conic.y - conic.x * conic.z;
-            if (conic.x <= 0.0f || conic.z <= 0.0f || disc >= 0.0f) break;
-
-            const float t = 2.0f * wd_log(opacity_sigmoid * 128.0f);
-            if (t <= 0.0f) break;
-            const float x_extent = wd_sqrt(wd_div(t * conic.z, -disc));
-            const float y_extent = wd_sqrt(wd_div(t * conic.x, -disc));
-            const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
-            const float xec = wd_min(x_extent, cap), yec = wd_min(y_extent, cap);
-            // Round-trip through fp16 so emit/raster/backward (which only see the Splat) agree on the bbox.
-            const u32 ndc_packed = wd_pack2(wd_clamp(ndc.x, -60000.0f, 60000.0f), wd_clamp(ndc.y, -60000.0f, 60000.0f));
-            const u32 ext_packed = wd_pack2(xec, yec);
-            const vec2 ndc_store = V2(wd_unpack_lo(ndc_packed), wd_unpack_hi(ndc_packed));
-            const vec2 ext_f16 = V2(wd_unpack_lo(ext_packed), wd_unpack_hi(ext_packed));
-            const TileBox tb = tile_box(ndc_store, ext_f16, viewport, ti.num_tiles_x, ti.num_tiles_y, true);
-            if (!tb.valid) break;
-
-            const vec3 cam_pos = xyz(cam.view_inv.c[3]);
-            const vec3 dir = normalize(pos - cam_pos);
-            const vec3 color = color_from_sh(sh_row, dir, wd_to_u32(settings.sh_deg));
-
-            const u32 num_tiles = (tb.max_x - tb.min_x + 1u) * (tb.max_y - tb.min_y + 1u);
-            if (num_tiles > 2048u) break;
-
-            u32* s = splats + (size_t)idx * 6;
-            uint2 o01, o23, o45;
-            o01.x = ndc_packed;
-            o01.y = ext_packed;
-            o23.x = wd_pack2(conic.x, conic.y);
-            o23.y = wd_pack2(conic.z, 0.0f);
-            o45.x = wd_pack2(wd_clamp(color.x, 0.0f, 1.0f), wd_clamp(color.y, 0.0f, 1.0f));
-            o45.y = wd_pack2(wd_clamp(color.z, 0.0f, 1.0f), wd_clamp(opacity_sigmoid, 0.0f, 1.0f));
-            *reinterpret_cast<uint2*>(s) = o01;
-            *reinterpret_cast<uint2*>(s + 2) = o23;
-            *reinterpret_cast<uint2*>(s + 4) = o45;
-            depths[idx] = ordered_uint(world_to_view.z);
-            num_tiles_out = num_tiles;
-            visible = true;
-            box_x0 = tb.min_x; box_x1 = tb.max_x; box_rows = tb.max_y - tb.min_y + 1u;
-        } while (false);
+        uint2 w01, w23, w45;
+        ShRow sh_row;
+        load_gaussian_and_sh(idx, gaussians, sh_buffer, dc_words, wd_to_u32(settings.sh_deg), w01, w23, w45, sh_row);
+        visible = project_one(idx, w01, w23, w45, sh_row, camera_f, settings, ti, splats, depths, num_tiles_out, box_x0, box_x1, box_rows);
         tile_counts[idx] = num_tiles_out;
     }
     // visible_gaussians: the reference does one atomicAdd per visible splat on ONE word (tiled-forward.wgsl:292).  Even one
@@ -212,6 +227,54 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
         if (block_counts) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
     if (column_counts && threadIdx.x < ti.num_tiles_x) column_counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_col[threadIdx.x];
+}
+
+// K1 for ALL the views of a batched step (wdgs_tiled_forward_project_views): the thread fetches its Gaussian and SH row once and projects
+// it under each camera in turn into that view's own buffers.  Per view the epilogue of project_count: tile count, visible-count shard,
+// the workgroup's entry count and its per-column counts.
+struct ProjectViews {
+    u32 count;
+    const float* camera[WDGS_MAX_BATCH_VIEWS];
+    u32* splats[WDGS_MAX_BATCH_VIEWS];
+    u32* depths[WDGS_MAX_BATCH_VIEWS];
+    u32* tile_counts[WDGS_MAX_BATCH_VIEWS];
+    u32* visible_shards[WDGS_MAX_BATCH_VIEWS];
+    u32* block_counts[WDGS_MAX_BATCH_VIEWS];
+    u32* column_counts[WDGS_MAX_BATCH_VIEWS];   // all null or none null
+};
+__global__ __launch_bounds__(256) void project_count_views_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer, RenderSettings settings,
+                                                                   TileInfo ti, ProjectViews pv, const u32* __restrict__ dc_words) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ u32 s_col[256];
+    __shared__ u32 s_vis[4], s_cnt[4];
+    const bool columns = pv.column_counts[0] != nullptr;
+    uint2 w01 = make_uint2(0u, 0u), w23 = w01, w45 = w01;
+    ShRow sh_row;
+    if (idx < n) load_gaussian_and_sh(idx, gaussians, sh_buffer, dc_words, wd_to_u32(settings.sh_deg), w01, w23, w45, sh_row);
+    for (u32 v = 0; v < pv.count; v++) {
+        if (columns) s_col[threadIdx.x] = 0u;
+        __syncthreads();   // (also: the previous view's s_vis / s_cnt / s_col have been read)
+        bool visible = false;
+        u32 num_tiles_out = 0u, box_x0 = 1u, box_x1 = 0u, box_rows = 0u;
+        if (idx < n) {
+            visible = project_one(idx, w01, w23, w45, sh_row, pv.camera[v], settings, ti, pv.splats[v], pv.depths[v], num_tiles_out, box_x0, box_x1, box_rows);
+            pv.tile_counts[v][idx] = num_tiles_out;
+        }
+        if (columns)
+            for (u32 x = box_x0; x <= box_x1; x++) atomicAdd(&s_col[x], box_rows);
+        const unsigned long long mask = __ballot(visible);
+        u32 wsum = num_tiles_out;
+#pragma unroll
+        for (u32 d = 32; d >= 1; d >>= 1) wsum += (u32)__shfl_xor((int)wsum, (int)d, 64);
+        if ((threadIdx.x & 63u) == 0u) { s_vis[threadIdx.x >> 6] = (u32)__popcll(mask); s_cnt[threadIdx.x >> 6] = wsum; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const u32 c = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+            if (c) atomicAdd(&pv.visible_shards[v][blockIdx.x & 63u], c);
+            pv.block_counts[v][blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        }
+        if (columns && threadIdx.x < ti.num_tiles_x) pv.column_counts[v][(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_col[threadIdx.x];
+    }
 }
 
 // stats[0] = total tile entries (update_stats, src/shaders/update-stats.wgsl:19-35); stats[2] = overflow flag.
@@ -547,6 +610,22 @@ int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const v
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "project_count", project_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh,
                 (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts, (u32*)column_counts,
+                (const u32*)dc_words);
+    WDGS_CHECK_HIP(hipGetLastError());
+    return WDGS_OK;
+}
+
+int launch_project_count_views(wdgs_device* dev, u32 n, u32 count, const void* gaussians, const void* sh, const void* const* cameras, const RenderSettings& st,
+                               const TileInfo& ti, void* const* splats, void* const* depths, void* const* counts, void* const* visible_shards, void* const* block_counts,
+                               void* const* column_counts, const void* dc_words) {
+    if (n == 0 || count == 0) return WDGS_OK;
+    ProjectViews pv{};
+    pv.count = count;
+    for (u32 v = 0; v < count; v++) {
+        pv.camera[v] = (const float*)cameras[v]; pv.splats[v] = (u32*)splats[v]; pv.depths[v] = (u32*)depths[v]; pv.tile_counts[v] = (u32*)counts[v];
+        pv.visible_shards[v] = (u32*)visible_shards[v]; pv.block_counts[v] = (u32*)block_counts[v]; pv.column_counts[v] = column_counts ? (u32*)column_counts[v] : nullptr;
+    }
+    WDGS_LAUNCH(dev, "project_count_views", project_count_views_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh, st, ti, pv,
                 (const u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;

@@ -22,6 +22,7 @@ from ._lib import CapacityError, StateError, WdgsError, check  # noqa: F401  (re
 
 # ----------------------------------------------------------------------------- device / buffers
 MAX_LANES = 4  # WDGS_MAX_LANES (include/webdgs.h)
+MAX_BATCH_VIEWS = 16  # WDGS_MAX_BATCH_VIEWS
 
 
 class HipBuffer:
@@ -208,6 +209,13 @@ class HipDevice:
         """Directs every later encode / submit to lane 0 (this device's stream) or an internal one, 1..MAX_LANES-1 (``include/webdgs.h``: lanes)."""
         check(self.lib.wdgs_device_select_lane(self.handle, int(lane)))
 
+    def laneMark(self, lane: int, mark: int) -> None:
+        """Remembers the current end of ``lane`` in mark ``mark`` (``wdgs_device_lane_mark``) for ``laneWaitMark`` calls made later."""
+        check(self.lib.wdgs_device_lane_mark(self.handle, int(lane), int(mark)))
+
+    def laneWaitMark(self, lane: int, mark: int) -> None:
+        check(self.lib.wdgs_device_lane_wait_mark(self.handle, int(lane), int(mark)))
+
     def laneOrder(self, waiter: int, signal: int) -> None:
         """What lane ``waiter`` gets from now on runs after what lane ``signal`` has been given so far (device-side, no host wait)."""
         check(self.lib.wdgs_device_lane_order(self.handle, int(waiter), int(signal)))
@@ -339,6 +347,11 @@ class TiledForwardPass:
         skip = 1 if (options or {}).get("skipSort") else 0
         check(self.device.lib.wdgs_tiled_forward_encode(self.handle, self.pointCloud.gaussian_3d_buffer.ptr, self.pointCloud.sh_buffer.ptr,
                                                         self.cameraBuffer.ptr, skip))
+
+    def encodeProjected(self, encoder: Optional["HipEncoder"] = None) -> None:
+        """The rest of ``encode`` (scan, emit, sort) for a pass whose K1 ran through ``projectViews`` (view-batched step; no reference
+        counterpart)."""
+        check(self.device.lib.wdgs_tiled_forward_encode_projected(self.handle))
 
     def setCameraBuffer(self, buffer: HipBuffer) -> None:
         self.cameraBuffer = buffer
@@ -729,6 +742,33 @@ def storeGradients(device: HipDevice, numPoints: int, gradientsBuffer: HipBuffer
 def guardAccumulate(device: HipDevice, flag: HipBuffer, src: HipBuffer, srcOffset: int = 0, overwrite: bool = False) -> None:
     """``flag = (overwrite ? 0 : flag) | (src != 0)``: folds per-view overflow words into the guard word of a batched step."""
     check(device.lib.wdgs_guard_accumulate(device.handle, flag.ptr, src.ptr + srcOffset, 1 if overwrite else 0))
+
+
+def _ptr_array(values) -> "C.Array":
+    vals = [v.value if isinstance(v, C.c_void_p) else int(v) for v in values]
+    return (C.c_void_p * len(vals))(*vals)
+
+
+def projectViews(forwardPasses: list, cameraBuffers: list, pointCloud: PointCloud) -> None:
+    """K1 of ALL the views of a batched step in one launch (``wdgs_tiled_forward_project_views``): Gaussian and SH row are read once and
+    projected under every camera into that view's own forward pass.  Follow with ``forwardPasses[v].encodeProjected(encoder)``."""
+    dev = forwardPasses[0].device
+    check(dev.lib.wdgs_tiled_forward_project_views(_ptr_array([f.handle for f in forwardPasses]), _ptr_array([c.ptr for c in cameraBuffers]), len(forwardPasses),
+                                                   pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr))
+
+
+def geometryViews(backwardPasses: list, cameraBuffers: list, forwardPasses: list, sums: HipBuffer, visible: HipBuffer, guard: HipBuffer, pointCloud: PointCloud,
+                  writeGradients: bool = False, continues: bool = False) -> None:
+    """K17 of ALL the views of a batched step in one launch (``wdgs_tiled_backward_encode_geometry_views``): what ``encodeGeometry(camera,
+    accumulate=dict(first=(v == 0), ...))`` per view produces -- the step's fp32 gradient block, visibility counts and guard word -- bit for
+    bit, with the Gaussians read once and the block written once.  ``continues``: these views follow earlier ones of the same step that
+    were handed over in a previous call (groups, in view order)."""
+    dev = backwardPasses[0].device
+    counts = [f.getResources()["tileCountsBuffer"].ptr for f in forwardPasses]
+    stats = [f.getStatsBuffer().ptr + 8 for f in forwardPasses]   # the overflow word of each view's stats block
+    check(dev.lib.wdgs_tiled_backward_encode_geometry_views(_ptr_array([b.handle for b in backwardPasses]), _ptr_array([c.ptr for c in cameraBuffers]), _ptr_array(counts),
+                                                            _ptr_array(stats), len(backwardPasses), pointCloud.gaussian_3d_buffer.ptr, sums.ptr, visible.ptr, guard.ptr,
+                                                            1 if writeGradients else 0, 1 if continues else 0))
 
 
 def applyRepackedRows(device: HipDevice, numPoints: int, rows: HipBuffer, skipFirst: int, skipCount: int, guard: Optional[HipBuffer],

@@ -25,7 +25,7 @@ from . import loaders, ops, parallel
 class Trainer:
     def __init__(self, device: ops.HipDevice, trainingConfig: Optional[dict] = None, seed: int = 0, world_size: int = 1, rank: int = 0,
                  views_per_rank: int = 1, maxTileEntries: int = 0, use_command_buffers: bool = True, exchange: Optional[parallel.Exchange] = None,
-                 overlap_views: Optional[bool] = None, pipeline_depth: int = 1):
+                 overlap_views: Optional[bool] = None, pipeline_depth: int = 1, batch_views: Optional[bool] = None):
         self.device = device
         self.trainingConfig = dict(trainingConfig or dict(lambda_l1=0.8, lambda_l2=0.0, lambda_dssim=0.2))  # trainer.ts:100-104
         self.optimizerHyperparameters = dict(ops.DEFAULT_ADAM_HYPERPARAMETERS)
@@ -50,7 +50,18 @@ class Trainer:
             overlap_views = int(os.environ.get("WDGS_LANES", self.DEFAULT_LANES))
         elif isinstance(overlap_views, bool):
             overlap_views = self.DEFAULT_LANES if overlap_views else 1
-        self._op_sets = max(1, min(int(overlap_views), self.views_per_rank, ops.MAX_LANES))
+        self._lanes = max(1, min(int(overlap_views), self.views_per_rank, ops.MAX_LANES))
+        # View-batched kernels (round 3): a batched step projects every Gaussian for ALL its views in one launch (K1) and turns all the
+        # views' accumulators into the step's fp32 gradient block in one launch (K17) -- Gaussian and SH row read once per step instead
+        # of once per view, the fp32 block written once, and no cross-lane ordering of per-view K17s.  Every view then needs buffers of
+        # its own: one op set per view of the batch (the lanes -- in-order streams -- stay at `_lanes`).  False (WDGS_BATCH_VIEWS=0): the
+        # per-view kernels of round 2, one op set per lane.  The results are identical.
+        self.batch_views = self.views_per_rank > 1 and (os.environ.get("WDGS_BATCH_VIEWS", "1") != "0" if batch_views is None else bool(batch_views))
+        self._op_sets = min(self.views_per_rank, ops.MAX_BATCH_VIEWS) if self.batch_views else self._lanes
+        # views per batched launch: 0 = all the step's views in one K1 and one K17 (measured best at c3, 8 views: 1875 views/s; groups of
+        # 3 on their own lane, overlapping the other groups' rasterization, 1798: the batched kernels then re-read the cloud per group and
+        # take issue slots from the VALU-bound rasterization kernels they run beside -- profiles/r03i_*)
+        self.view_group = int(os.environ.get("WDGS_VIEW_GROUP", "0"))
         self._camera_buffers: list = []
         # every rank draws the same view sequence (same seed), then takes its shard
         self._rng = random.Random(seed)
@@ -358,12 +369,15 @@ class Trainer:
     def _ops_of(self, op_set: int) -> tuple:
         return tuple(self._more_op_sets[op_set - 1]) if op_set > 0 else (self.forwardPass, self.rasterizer, self.backwardPass)
 
-    def _encode_view(self, encoder, index: int, op_set: int = 0, geometry: bool = True) -> None:
+    def _encode_view(self, encoder, index: int, op_set: int = 0, geometry: bool = True, projected: bool = False) -> None:
         forwardPass, rasterizer, backwardPass = self._ops_of(op_set)
         image = self.images[index]
         cam = self._camera_buffers[index]  # camera.set_preset + update_buffer (trainer.ts:583-586): the view's resident block
         forwardPass.setCameraBuffer(cam)
-        forwardPass.encode(encoder)
+        if projected:   # K1 ran for all the views of the step at once (ops.projectViews): scan, emit, sort remain
+            forwardPass.encodeProjected(encoder)
+        else:
+            forwardPass.encode(encoder)
         rasterizer.encode(encoder, image["width"], image["height"])
         res = dict(splatBuffer=forwardPass.getResources()["splatBuffer"], tileOffsetsBuffer=rasterizer.getTileOffsetsBuffer(),
                    tileIndicesBuffer=forwardPass.getSortedIndicesBuffer(), cameraBuffer=cam,
@@ -492,8 +506,67 @@ class Trainer:
         first, count = parallel.owned_range(n, w, self.rank)
         eager_before = self._eager_steps
         dev = self.device
+        if self.batch_views and len(mine) <= self._op_sets:
+            self._views_batched(mine)
+        else:
+            self._views_one_by_one(mine)
+        self._timed(lambda: self.exchange.exchange_gradients(self._dp_grad.ptr, self._dp_visible.ptr, self._dp_flag.ptr, sl))
+        if self._run(("adam",), lambda encoder: self.optimizer.stepF32Range(encoder, self.pointCloud, self._dp_grad, self._dp_visible, first, count, self._dp_rows)):
+            self.optimizer.advanceIteration(1)
+        if self._sliced:
+            self._timed(lambda: self.exchange.allgather_rows(self._dp_rows.ptr, sl))
+            self._run(("apply",), lambda encoder: self.optimizer.applyRepackedRows(self._dp_rows, first, count, self._dp_flag, self.pointCloud))
+            self._state_sliced = w > 1
+        if not self.use_command_buffers or eager_before < 1:
+            self._eager_steps += 1
+
+    def _views_batched(self, mine: list) -> None:
+        """The step's views in groups (`view_group`; default: one group = all of them): [K1 of the group, one launch] -> per view, dealt to the lanes: scan, emit, sort,
+        composite, loss, backward raster (one recorded command buffer per (view, place in the batch)) -> [K17 of the group, one launch,
+        into the step's fp32 block, groups in view order].  The batched launches run on a lane of their own, so a group's projection and
+        the previous group's K17 -- bandwidth- and latency-bound -- execute beside the other groups' rasterization kernels; each view
+        waits only for its group's K1, each K17 only for its group's views."""
+        dev, L = self.device, self._lanes
+        sets = [self._ops_of(k) for k in range(len(mine))]
+        cams = [self._camera_buffers[v] for v in mine]
+        lanes = L > 1 and self.use_command_buffers and all(("viewp", v, k) in self._cmd_cache for k, v in enumerate(mine))
+        U = L if L < ops.MAX_LANES else 0          # the lane of the batched launches
+        G = self.view_group or len(mine)
+        groups = [list(range(g, min(g + G, len(mine)))) for g in range(0, len(mine), G)]
+        try:
+            if lanes:
+                for s in range(1, ops.MAX_LANES if U else L):
+                    dev.laneOrder(s, 0)  # every lane starts behind whatever lane 0 holds (the previous step's Adam, a densify rebuild)
+            for gi, grp in enumerate(groups):   # every group's projection first, back to back on the batched launches' lane
+                if lanes:
+                    dev.selectLane(U)
+                ops.projectViews([sets[k][0] for k in grp], [cams[k] for k in grp], self.pointCloud)
+                if lanes:
+                    dev.laneMark(U, gi)
+            for gi, grp in enumerate(groups):
+                for k in grp:
+                    if lanes:
+                        dev.laneWaitMark(k % L, gi)  # view k starts behind its OWN group's projection
+                        dev.selectLane(k % L)
+                    self._run(("viewp", mine[k], k), lambda encoder, v=mine[k], k=k: self._encode_view(encoder, v, k, geometry=False, projected=True))
+                    if lanes:
+                        dev.laneOrder(U, k % L)      # the group's K17 follows its views (and the earlier groups' K17: lane order)
+                if lanes:
+                    dev.selectLane(U)
+                ops.geometryViews([sets[k][2] for k in grp], [cams[k] for k in grp], [sets[k][0] for k in grp], self._dp_grad, self._dp_visible, self._dp_flag,
+                                  self.pointCloud, continues=gi > 0)
+        finally:
+            if lanes:
+                dev.lib.wdgs_encoder_abort(dev.handle)  # (a no-op unless an encode above failed mid-recording)
+                dev.selectLane(0)
+                for s in range(1, ops.MAX_LANES if U else L):
+                    dev.laneOrder(0, s)  # join: the exchange and the optimizer step follow every lane
+
+    def _views_one_by_one(self, mine: list) -> None:
+        """Round 2's form: per view K1..K16 recorded, K17 eager per view, ordered across the lanes (one op set per lane)."""
+        dev = self.device
         # lanes carry replays only: a step that still encodes eagerly (first-use allocations) or records keeps to lane 0
-        L = self._op_sets
+        L = min(self._lanes, self._op_sets)
         lanes = L > 1 and self.use_command_buffers and all(("view", v, k % L) in self._cmd_cache for k, v in enumerate(mine))
         try:
             for s in range(1, L if lanes else 0):
@@ -517,15 +590,6 @@ class Trainer:
                 dev.selectLane(0)
                 for s in range(1, L):
                     dev.laneOrder(0, s)  # join: the exchange and the optimizer step follow every lane
-        self._timed(lambda: self.exchange.exchange_gradients(self._dp_grad.ptr, self._dp_visible.ptr, self._dp_flag.ptr, sl))
-        if self._run(("adam",), lambda encoder: self.optimizer.stepF32Range(encoder, self.pointCloud, self._dp_grad, self._dp_visible, first, count, self._dp_rows)):
-            self.optimizer.advanceIteration(1)
-        if self._sliced:
-            self._timed(lambda: self.exchange.allgather_rows(self._dp_rows.ptr, sl))
-            self._run(("apply",), lambda encoder: self.optimizer.applyRepackedRows(self._dp_rows, first, count, self._dp_flag, self.pointCloud))
-            self._state_sliced = w > 1
-        if not self.use_command_buffers or eager_before < 1:
-            self._eager_steps += 1
 
     def _timed(self, collective) -> None:
         if not self.exchange_timing:
