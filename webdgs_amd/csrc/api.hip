@@ -19,7 +19,7 @@ int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, void*,
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
 int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
                      void*, void*);
-int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdgs_training_config&, void*);
+int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdgs_training_config&, void*, void*, u32, const void*);
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*, void*);
 int launch_acc_clear_if_dirty(wdgs_device*, void*, u32, void*);
@@ -1039,13 +1039,14 @@ int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op) {
 }
 int wdgs_tiled_backward_compute_loss_only(wdgs_tiled_backward* op, const void* pred, const void* targ) {
     WDGS_REQUIRE(op && pred && targ, WDGS_E_INVALID, "wdgs_tiled_backward_compute_loss_only: null argument");
-    return launch_loss_grad(op->dev, op->cfg.viewport_width, op->cfg.viewport_height, pred, targ, op->cfg.training, op->loss_image);
+    return launch_loss_grad(op->dev, op->cfg.viewport_width, op->cfg.viewport_height, pred, targ, op->cfg.training, op->loss_image, nullptr, 0u, nullptr);
 }
 static int backward_encode_raster(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res) {
     wdgs_device* d = op->dev;
     const u32 w = op->cfg.viewport_width, h = op->cfg.viewport_height, n = op->cfg.num_points;
-    WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image));
-    WDGS_TRY(launch_acc_clear_if_dirty(d, op->acc, n, op->acc_dirty));  // clearBuffer x4, tiled-backward-pass.ts:624-627 (a no-op behind a consuming K17)
+    // K15 + clearBuffer x4 (tiled-backward-pass.ts:624-627): the clear rides on the loss kernel and is a no-op behind a consuming K17
+    if (w > 0 && h > 0) WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image, op->acc, std::max(n, 1u), op->acc_dirty));
+    else WDGS_TRY(launch_acc_clear_if_dirty(d, op->acc, n, op->acc_dirty));
     return launch_backward_rasterize(d, op->settings, ceil_div(w, 16), ceil_div(h, 16), res->tile_offsets_buffer, res->tile_indices_buffer, res->splat_buffer,
                                      res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc, op->acc_dirty);
 }

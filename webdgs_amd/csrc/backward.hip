@@ -253,7 +253,7 @@ struct GeometryViews {
     const u32* overflow[WDGS_MAX_BATCH_VIEWS];
     u32* gradients[WDGS_MAX_BATCH_VIEWS];   // nullable per view: the packed per-view GaussianGradient, for readers of getGradientsBuffer()
 };
-__global__ __launch_bounds__(256, 4) void geometry_backward_views_kernel(u32 n, RenderSettings settings, const u32* __restrict__ gaussians, GeometryViews gv,
+__global__ __launch_bounds__(256, 3) void geometry_backward_views_kernel(u32 n, RenderSettings settings, const u32* __restrict__ gaussians, GeometryViews gv,
                                                                         float* __restrict__ sums, u32* __restrict__ visible, u32* __restrict__ guard,
                                                                         u32 continues /*0: these are the step's first views; 1: the block already holds earlier views*/) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,7 +21,16 @@ constexpr u32 LH = LT + 4;   // halo edge in texels
 constexpr u32 PPT = 4;       // vertically adjacent pixels per thread
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32* __restrict__ pred, const u32* __restrict__ targ,
-                                                         wdgs_training_config cfg, float4* __restrict__ out) {
+                                                         wdgs_training_config cfg, float4* __restrict__ out, int4* __restrict__ acc, u32 acc_quads,
+                                                         const u32* __restrict__ acc_dirty) {
+    // clearBuffer x4 of the gradient accumulators (tiled-backward-pass.ts:624-627) rides on this kernel, which precedes the backward
+    // rasterization anyway: the accumulators' state word (backward_raster.hip) says whether anything has to be cleared at all -- after a
+    // consuming K17 nothing has -- so the clear is one scalar load here instead of a launch of its own.
+    if (acc && *acc_dirty != 0u) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        const u32 nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+        for (u32 i = blk * 256u + threadIdx.x; i < acc_quads; i += nblk * 256u) acc[i] = z;
+    }
     __shared__ float s_lut[256];
     // A thread row is 32 lanes on 32 consecutive texels, so each 16-lane group of a ds_read_b128 covers 256 contiguous
     // bytes = every bank once, whatever the row stride.
@@ -154,10 +163,11 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
 
 }  // namespace
 
-int launch_loss_grad(wdgs_device* dev, u32 W, u32 H, const void* pred, const void* targ, const wdgs_training_config& cfg, void* out) {
+int launch_loss_grad(wdgs_device* dev, u32 W, u32 H, const void* pred, const void* targ, const wdgs_training_config& cfg, void* out, void* acc, u32 acc_rows,
+                     const void* acc_dirty) {
     if (W == 0 || H == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "loss_grad", loss_grad_kernel, dim3(ceil_div(W, LT), ceil_div(H, LT)), dim3(256), 0, W, H, (const u32*)pred, (const u32*)targ, cfg,
-                (float4*)out);
+                (float4*)out, (int4*)acc, acc_rows * 3u /*12 i32 per row*/, (const u32*)acc_dirty);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
