@@ -355,16 +355,16 @@ def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, 
     prof = pk = None
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime, reverse=True):
+        refused = []
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename, reverse=True):   # (names sort by round and pass: r03k > r02o > ...)
             cand = json.load(open(f))
             if cand.get("workload", "c3") != config or dom not in cand.get("kernels", {}) and dom not in ("sort", "scan"):
                 continue
             want, have = source_sha(dom), (cand.get("source_sha") or {}).get(dom)
-            if have is None:
-                pmc_note = f"{os.path.basename(f)} records no source hash for {dom}: refused"
-                continue
             if have != want:
-                pmc_note = f"{os.path.basename(f)} was taken at another version of {dom}'s source ({have} != {want}): refused"
+                refused.append(os.path.basename(f))
+                pmc_note = (f"no PMC profile of this version of {dom}'s source ({want}): refused " + ", ".join(refused[:3]) + (" ..." if len(refused) > 3 else "") +
+                            " (recorded hash differs or is absent)")
                 continue
             prof, pk, pmc_note = cand, cand["kernels"], f"offline PMC profile {os.path.basename(f)}" + (f" @ {cand['head']}" if cand.get("head") else "")
             break

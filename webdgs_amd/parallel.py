@@ -169,12 +169,14 @@ class TorchExchange(Exchange):
     _in_place = True
 
     def _out_of_place(self, error: Exception) -> None:
-        """Only a c10d build that REFUSES aliased input / output arguments (an argument check, raised before anything is enqueued)
-        switches the exchange to staging.  Any other error -- a transport failure, a timeout, an RCCL error -- is re-raised: retrying
-        a collective on one rank after such an error would leave the ranks issuing different collectives."""
+        """A c10d build that REFUSES aliased input / output arguments says so in an argument check, before anything is enqueued: only
+        then does the exchange switch to staging.  An error that names the transport -- an RCCL / NCCL failure, a timeout, a lost
+        connection -- is re-raised: retrying a collective on one rank after such an error would leave the ranks issuing different
+        collectives."""
         import sys
         text = str(error).lower()
-        if not any(w in text for w in ("alias", "overlap", "in-place", "inplace", "same tensor", "input and output", "share storage", "partially")):
+        if any(w in text for w in ("nccl error", "rccl", "ncclsystemerror", "ncclinternalerror", "ncclunhandled", "unhandled system error", "unhandled cuda error", "timeout",
+                                   "timed out", "connection", "socket", "remote process", "watchdog", "hip error", "cuda error")):
             raise error
         print(f"[webdgs_amd.parallel] in-place collective refused ({error}); staging through a scratch tensor from now on", file=sys.stderr, flush=True)
         self._in_place = False
