@@ -19,6 +19,7 @@
 // Bound: fp32 VALU issue -- about 129 wave-instructions per (wave, splat) with a contributing pixel: the pinned exp (14), one division (8),
 // the per-pixel gradient arithmetic (about 55), the reduction (22) and the bookkeeping around them; DESIGN.md section 4 has the counters.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "dmath.h"
@@ -72,26 +73,40 @@ WD_DEV int cvt_fixed(float scaled) {
     return r;
 }
 
-__global__ __launch_bounds__(256, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges,
+// WPW = waves per workgroup: 1 (default: workgroup = one 8x8 block; the four blocks of a tile are numbered so that they are dispatched back
+// to back on one XCD and share its L2 lines of the entry list) or 4 (workgroup = tile, round 2's form).
+template <u32 WPW>
+__global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty) {
     // the accumulators hold sums from here on (acc_clear_if_dirty below, and the consuming forms of geometry_backward, backward.hip)
     if (blockIdx.x == 0u && threadIdx.x == 0u) *acc_dirty = 1u;
-    __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, extent.x, extent.y
-    __shared__ float4 s_con_all[4][64];  // conic.x, conic.y, conic.z, opacity
-    __shared__ float4 s_col_all[4][64];  // r, g, b, gaussian index (bits)
-    __shared__ float4 s_aux_all[4][64];  // position of the entry in the tile's list (bits), 2*conic.xyz
+    __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y
+    __shared__ float4 s_con_all[WPW][64];  // conic.x, conic.y, conic.z, opacity
+    __shared__ float4 s_col_all[WPW][64];  // r, g, b, gaussian index (bits)
+    __shared__ float4 s_aux_all[WPW][64];  // position of the entry in the tile's list (bits), 2*conic.xyz
 
     // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
     // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
-    const u32 tile_id = blockIdx.x, sub = threadIdx.x >> 6;
+    u32 tile_id, sub;
+    if (WPW == 4u) {
+        tile_id = blockIdx.x; sub = threadIdx.x >> 6;
+    } else {
+        // launch slots b, b + 8, ... share an XCD: slot j of XCD k is block (j & 3) of the XCD's tile number j >> 2; XCD k owns the tiles
+        // k, k + 8, k + 16, ... (any tile count: the grid is rounded up and surplus slots leave)
+        const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        tile_id = k + 8u * (j >> 2);
+        sub = j & 3u;
+        if (tile_id >= num_tiles) return;
+    }
     const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
     const u32 lane = threadIdx.x & 63u;
-    float4* const s_geo = s_geo_all[sub];  // wave-private record sets
-    float4* const s_con = s_con_all[sub];
-    float4* const s_col = s_col_all[sub];
-    float4* const s_aux = s_aux_all[sub];
+    const u32 slot = (WPW == 4u) ? sub : 0u;
+    float4* const s_geo = s_geo_all[slot];  // wave-private record sets
+    float4* const s_con = s_con_all[slot];
+    float4* const s_col = s_col_all[slot];
+    float4* const s_aux = s_aux_all[slot];
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -285,8 +300,17 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
                               const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc, void* acc_dirty) {
     const u32 tiles = num_tiles_x * num_tiles_y;
     if (tiles == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel, dim3(tiles), dim3(256), 0, st, num_tiles_x, (const u32*)ranges, (const u32*)instances,
-                (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty);
+    // one 8x8 block (one wave) per workgroup: nothing is shared inside a tile's workgroup but cache lines, and single-wave workgroups are
+    // placed as soon as ONE wave slot is free -- a shorter tail: 303 -> 295.5 us at c3, same box (r03l).  WDGS_BWR_WPW=4: workgroup = tile.
+    static const bool one_wave = !(std::getenv("WDGS_BWR_WPW") && std::getenv("WDGS_BWR_WPW")[0] == '4');
+    if (one_wave) {
+        const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
+        WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel<1u>, dim3(slots), dim3(64), 0, st, num_tiles_x, tiles, (const u32*)ranges, (const u32*)instances,
+                    (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty);
+    } else {
+        WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel<4u>, dim3(tiles), dim3(256), 0, st, num_tiles_x, tiles, (const u32*)ranges, (const u32*)instances,
+                    (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty);
+    }
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

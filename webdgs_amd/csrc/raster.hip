@@ -17,27 +17,40 @@
 // Bound: fp32 VALU issue (about 40 lane-ops per accepted pixel-splat pair incl. the deterministic exp), not HBM.
 // Arithmetic is the pinned contraction of DESIGN.md "raster math", bit-identical to the parity oracle.
 #include "common.h"
+#include <cstdlib>
+
 #include "dmath.h"
 
 namespace {
 
-template <bool GAUSSIAN_MODE>
-__global__ __launch_bounds__(256) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
+// WPW = waves per workgroup: 1 (one 8x8 block per workgroup, a tile's four blocks dispatched back to back on one XCD) or 4 (workgroup = tile);
+// see backward_raster.hip.
+template <bool GAUSSIAN_MODE, u32 WPW>
+__global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
                                                         const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                                                         const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
                                                         u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib) {
-    __shared__ float4 s_geo_all[4][64];  // centre.x, centre.y, extent.x, extent.y   (pixels)
-    __shared__ float4 s_con_all[4][64];  // conic.x, 2*conic.y, conic.z, opacity
-    __shared__ float4 s_col_all[4][64];  // r, g, b, position in the tile list + 1 (bits)
+    __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y   (pixels)
+    __shared__ float4 s_con_all[WPW][64];  // conic.x, 2*conic.y, conic.z, opacity
+    __shared__ float4 s_col_all[WPW][64];  // r, g, b, position in the tile list + 1 (bits)
 
-    // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
-    // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
-    const u32 tile_id = blockIdx.x, sub = threadIdx.x >> 6;
+    // independent waves (no barrier is ever taken): one per 8x8 block
+    u32 tile_id, sub;
+    if (WPW == 4u) {
+        tile_id = blockIdx.x; sub = threadIdx.x >> 6;
+    } else {
+        // launch slots b, b + 8, ... share an XCD: slot j of XCD k is block (j & 3) of the XCD's tile number j >> 2; XCD k owns tiles k, k + 8, ...
+        const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        tile_id = k + 8u * (j >> 2);
+        sub = j & 3u;
+        if (tile_id >= ti.total_tiles) return;
+    }
     const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
     const u32 lane = threadIdx.x & 63u;
-    float4* const s_geo = s_geo_all[sub];  // wave-private record sets
-    float4* const s_con = s_con_all[sub];
-    float4* const s_col = s_col_all[sub];
+    const u32 slot = (WPW == 4u) ? sub : 0u;
+    float4* const s_geo = s_geo_all[slot];  // wave-private record sets
+    float4* const s_con = s_con_all[slot];
+    float4* const s_col = s_col_all[slot];
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;  // block origin
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -171,14 +184,19 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
                      void* out_ncontrib) {
     if (ti.total_tiles == 0) return WDGS_OK;
     const u32 max_entries = max_batches * 256u;  // compat cap: 32 batches x 256 splats per tile; 0 = unlimited
+    // (one-wave workgroups help backward_rasterize -- 303 -> 295.5 us -- but not this kernel: 119.2 vs 119.8 us, r03m; workgroup = tile stays)
+    static const bool one_wave = std::getenv("WDGS_RASTER_WPW") && std::getenv("WDGS_RASTER_WPW")[0] == '1';
+    const u32 slots = ceil_div(ti.total_tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
+#define RASTER_ARGS st, ti, (const u32*)splats, num_splats, (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, \
+                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib
     if (st.gaussian_mode >= 0.5f) {
-        WDGS_LAUNCH(dev, "rasterize", rasterize_kernel<true>, dim3(ti.total_tiles), dim3(256), 0, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
-                    (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib);
+        if (one_wave) WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);
+        else WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 4u>), dim3(ti.total_tiles), dim3(256), 0, RASTER_ARGS);
     } else {
-        WDGS_LAUNCH(dev, "rasterize_points", rasterize_kernel<false>, dim3(ti.total_tiles), dim3(256), 0, st, ti, (const u32*)splats, num_splats,
-                    (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8,
-                    (float*)out_alpha, (u32*)out_ncontrib);
+        if (one_wave) WDGS_LAUNCH(dev, "rasterize_points", (rasterize_kernel<false, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);
+        else WDGS_LAUNCH(dev, "rasterize_points", (rasterize_kernel<false, 4u>), dim3(ti.total_tiles), dim3(256), 0, RASTER_ARGS);
     }
+#undef RASTER_ARGS
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
