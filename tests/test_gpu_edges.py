@@ -209,3 +209,55 @@ def test_needle_splats_and_marginal_opacities(hip_device, orc):
     assert (ref["tile_counts"] > 0).sum() > 5000 and ref["total_entries"] > 100_000
     _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target, steps=2)
     _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target, steps=1, max_radius=-1.0)  # radius cap lifted: footprints of hundreds of pixels
+
+
+def _forward_equals_oracle(orc, dev, cfg, g, sh, cam, what):
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    ref = orc.forward(g, sh, cam, st, ti)
+    e = ref["total_entries"]
+    pipe = harness.HipPipeline(dev, cfg, g, sh, cam)
+    try:
+        pipe.forward()
+        got = pipe.collect_forward()
+        assert got["total_entries"] == e, what
+        assert_bits_equal(got["tile_offsets"], ref["tile_offsets"], f"{what}: per-Gaussian offsets")
+        assert_bits_equal(got["sorted_keys"], ref["sorted_keys"][:e], f"{what}: sorted keys")
+        assert_bits_equal(got["sorted_values"], ref["sorted_values"][:e], f"{what}: stable order")
+        assert_bits_equal(got["tile_ranges"], ref["tile_ranges"], f"{what}: tile ranges")
+        assert_bits_equal(got["rgba8"], ref["rgba8"], f"{what}: image")
+        # encode(skipSort) right after a sorted encode: the reference's emission order, in the buffers the getters hand out
+        pipe.fwd.encode(None, dict(skipSort=True))
+        dev.synchronize()
+        assert_bits_equal(pipe.fwd.getSortedKeysBuffer().read(np.uint32, count=e), ref["keys"][:e], f"{what}: emission-order keys after skipSort")
+        assert_bits_equal(pipe.fwd.getSortedIndicesBuffer().read(np.uint32, count=e), ref["values"][:e], f"{what}: emission-order values after skipSort")
+        pipe.forward()   # ... and sorted again
+        assert_bits_equal(pipe.collect_forward()["sorted_values"], ref["sorted_values"][:e], f"{what}: stable order, second sorted encode")
+    finally:
+        pipe.destroy()
+    return ref
+
+
+@pytest.mark.parametrize("w,h", [(16, 400), (32, 400), (4096, 48), (4112, 48), (48, 4096), (48, 4112), (250, 130)],
+                         ids=["1-column", "2-columns", "256-columns", "257-columns", "256-rows", "257-rows", "odd"])
+def test_tile_grid_shapes_around_the_column_path(hip_device, orc, w, h):
+    """The forward pass folds the sort's first pass into emit when the grid has 2..256 tile columns and <= 256 rows (emit_scatter: digit =
+    tile column, then one pass on the tile row); outside that it keeps emit + two tile-bit passes.  Both sides of every limit, against the
+    oracle: offsets, sorted keys, stable order, ranges, image; encode(skipSort) in between still yields the reference's emission order."""
+    cfg = harness.small_config("c1", num_points=3000, width=w, height=h, fy=0.9 * max(w, h), s0=0.01)
+    g, sh, cam = harness.scene(cfg)
+    ref = _forward_equals_oracle(orc, hip_device, cfg, g, sh, cam, f"{w}x{h}")
+    assert ref["total_entries"] > 1000
+
+
+def test_workgroups_with_many_chunks_of_entries(hip_device, orc):
+    """emit_scatter expands a workgroup's 256 Gaussians in chunks of 2048 entries: large splats (hundreds of tiles each, radius cap lifted)
+    give workgroups tens of chunks, with Gaussians spanning chunk boundaries and columns receiving entries from every chunk."""
+    cfg = harness.small_config("c2", num_points=900, width=640, height=480, fy=500.0, s0=0.12, sh_deg=0)
+    g, sh, cam = harness.scene(cfg)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    ref = _forward_equals_oracle(orc, hip_device, cfg, g, sh, cam, "many chunks")
+    per_wg = np.add.reduceat(ref["tile_counts"].astype(np.int64), np.arange(0, cfg.num_points, 256))
+    assert per_wg.max() > 6 * 2048, per_wg
+    tg, tsh = synth.make_target_scene(g, sh)
+    target = orc.forward(tg, tsh, cam, st, ti)["rgba8"]
+    _full_step_matches_oracle(orc, hip_device, cfg, g, sh, cam, target, steps=1)

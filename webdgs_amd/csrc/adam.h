@@ -25,29 +25,32 @@ WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
     return g;
 }
 
+// Compact training copy "cs": float[N][CS_STRIDE], one 112-byte row per Gaussian holding what the reference spreads over three arrays with
+// padding or long strides -- position {param, m, v} (OptVec4: a fourth, unused lane each), log-scale {param, m, v} (same), SH-DC {param, m,
+// v} (192- / 384-byte strides in paramSH / stateSH):
+//   [0-2] pos p  [3-5] pos m  [6-8] pos v  [9-11] scale p  [12-14] scale m  [15-17] scale v  [18-20] dc p  [21-23] dc m  [24-26] dc v  [27] pad
+// The reference-layout arrays are brought up to date at every hand-over (cs_flush: get_state / release_state / destroy) and loaded when
+// state is adopted, unpacked or rewritten from outside (cs_load).  Rotation (no padding) and opacity stay where they are.
+constexpr u32 CS_STRIDE = 28;
+
 // Adam on one Gaussian's 14 trained scalars (SH: DC only) followed by the fp16 re-pack of that Gaussian.
 // rows_out (nullable): the re-packed row -- 6 Gaussian words, SH word 0, low half of SH word 1 -- also goes to rows_out[idx*8 ..],
 // the 32-byte form in which a data-parallel rank publishes the Gaussians it owns (wdgs_comm_allgather_rows).
-WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_pos,
-                            float4* __restrict__ opt_rot, float4* __restrict__ opt_scale, float* __restrict__ opt_opacity,
-                            float* __restrict__ dc, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ rows_out = nullptr,
-                            u32* __restrict__ dc_words = nullptr) {
-    float4 P = opt_pos[(size_t)idx * 3];
+WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_rot,
+                            float* __restrict__ opt_opacity, float* __restrict__ cs, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer,
+                            u32* __restrict__ rows_out = nullptr, u32* __restrict__ dc_words = nullptr) {
+    float4* row = reinterpret_cast<float4*>(cs + (size_t)idx * CS_STRIDE);
+    const float4 q0 = row[0], q2 = row[2], q4 = row[4], q5 = row[5];
     float4 R = opt_rot[(size_t)idx * 3];
-    float4 S = opt_scale[(size_t)idx * 3];
     float op = opt_opacity[(size_t)idx * 3];
-    float* d = dc + (size_t)idx * 9;
-    float c0 = d[0], c1 = d[1], c2 = d[2];
+    float Px = q0.x, Py = q0.y, Pz = q0.z;          // position
+    float Sx = q2.y, Sy = q2.z, Sz = q2.w;          // log-scale
+    float c0 = q4.z, c1 = q4.w, c2 = q5.x;          // SH DC
     if (update) {
-        {
-            const float4 m = opt_pos[(size_t)idx * 3 + 1], v = opt_pos[(size_t)idx * 3 + 2];
-            const Adam3 rx = adam_step(h, P.x, g.pos[0], m.x, v.x, h.lr_pos), ry = adam_step(h, P.y, g.pos[1], m.y, v.y, h.lr_pos),
-                        rz = adam_step(h, P.z, g.pos[2], m.z, v.z, h.lr_pos);
-            P = make_float4(rx.p, ry.p, rz.p, 1.0f);
-            opt_pos[(size_t)idx * 3] = P;
-            opt_pos[(size_t)idx * 3 + 1] = make_float4(rx.m, ry.m, rz.m, 0.0f);
-            opt_pos[(size_t)idx * 3 + 2] = make_float4(rx.v, ry.v, rz.v, 0.0f);
-        }
+        const float4 q1 = row[1], q3 = row[3], q6 = row[6];
+        const Adam3 px = adam_step(h, Px, g.pos[0], q0.w, q1.z, h.lr_pos), py = adam_step(h, Py, g.pos[1], q1.x, q1.w, h.lr_pos),
+                    pz = adam_step(h, Pz, g.pos[2], q1.y, q2.x, h.lr_pos);
+        Px = px.p; Py = py.p; Pz = pz.p;
         {
             const float4 m = opt_rot[(size_t)idx * 3 + 1], v = opt_rot[(size_t)idx * 3 + 2];
             const Adam3 rx = adam_step(h, R.x, g.rot[0], m.x, v.x, h.lr_rot), ry = adam_step(h, R.y, g.rot[1], m.y, v.y, h.lr_rot),
@@ -58,15 +61,9 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
             opt_rot[(size_t)idx * 3 + 1] = make_float4(rx.m, ry.m, rz.m, rw.m);
             opt_rot[(size_t)idx * 3 + 2] = make_float4(rx.v, ry.v, rz.v, rw.v);
         }
-        {
-            const float4 m = opt_scale[(size_t)idx * 3 + 1], v = opt_scale[(size_t)idx * 3 + 2];
-            const Adam3 rx = adam_step(h, S.x, g.scale[0], m.x, v.x, h.lr_scale), ry = adam_step(h, S.y, g.scale[1], m.y, v.y, h.lr_scale),
-                        rz = adam_step(h, S.z, g.scale[2], m.z, v.z, h.lr_scale);
-            S = make_float4(rx.p, ry.p, rz.p, 0.0f);
-            opt_scale[(size_t)idx * 3] = S;
-            opt_scale[(size_t)idx * 3 + 1] = make_float4(rx.m, ry.m, rz.m, 0.0f);
-            opt_scale[(size_t)idx * 3 + 2] = make_float4(rx.v, ry.v, rz.v, 0.0f);
-        }
+        const Adam3 sx = adam_step(h, Sx, g.scale[0], q3.x, q3.w, h.lr_scale), sy = adam_step(h, Sy, g.scale[1], q3.y, q4.x, h.lr_scale),
+                    sz = adam_step(h, Sz, g.scale[2], q3.z, q4.y, h.lr_scale);
+        Sx = sx.p; Sy = sy.p; Sz = sz.p;
         {
             const Adam3 r = adam_step(h, op, g.opac, opt_opacity[(size_t)idx * 3 + 1], opt_opacity[(size_t)idx * 3 + 2], h.lr_opacity);
             op = r.p;
@@ -74,15 +71,18 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
             opt_opacity[(size_t)idx * 3 + 1] = r.m;
             opt_opacity[(size_t)idx * 3 + 2] = r.v;
         }
-        {
-            const Adam3 r0 = adam_step(h, c0, g.color[0], d[3], d[6], h.lr_color), r1 = adam_step(h, c1, g.color[1], d[4], d[7], h.lr_color),
-                        r2 = adam_step(h, c2, g.color[2], d[5], d[8], h.lr_color);
-            c0 = r0.p; c1 = r1.p; c2 = r2.p;
-            d[0] = r0.p; d[1] = r1.p; d[2] = r2.p;
-            d[3] = r0.m; d[4] = r1.m; d[5] = r2.m;
-            d[6] = r0.v; d[7] = r1.v; d[8] = r2.v;
-        }
+        const Adam3 r0 = adam_step(h, c0, g.color[0], q5.y, q6.x, h.lr_color), r1 = adam_step(h, c1, g.color[1], q5.z, q6.y, h.lr_color),
+                    r2 = adam_step(h, c2, g.color[2], q5.w, q6.z, h.lr_color);
+        c0 = r0.p; c1 = r1.p; c2 = r2.p;
+        row[0] = make_float4(px.p, py.p, pz.p, px.m);
+        row[1] = make_float4(py.m, pz.m, px.v, py.v);
+        row[2] = make_float4(pz.v, sx.p, sy.p, sz.p);
+        row[3] = make_float4(sx.m, sy.m, sz.m, sx.v);
+        row[4] = make_float4(sy.v, sz.v, r0.p, r1.p);
+        row[5] = make_float4(r2.p, r0.m, r1.m, r2.m);
+        row[6] = make_float4(r0.v, r1.v, r2.v, 0.0f);
     }
+    struct { float x, y, z; } P = {Px, Py, Pz}, S = {Sx, Sy, Sz};
     // re-pack (update-gaussians.wgsl:41-75): whole Gaussian, SH word 0, low half of SH word 1
     u32* gp = gaussians + (size_t)idx * 6;
     *reinterpret_cast<uint2*>(gp) = make_uint2(wd_pack2(P.x, P.y), wd_pack2(P.z, op));

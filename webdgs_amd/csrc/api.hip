@@ -40,8 +40,8 @@ int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, voi
 int launch_dc_words_load(wdgs_device*, u32, const void*, void*);
 int launch_dc_words_flush(wdgs_device*, u32, const void*, void*);
 int launch_guard_accumulate(wdgs_device*, void*, const void*, u32);
-int launch_dc_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
-int launch_dc_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
+int launch_cs_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
+int launch_cs_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
 int launch_accumulate_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
 int launch_store_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
 int launch_unpack(wdgs_device*, u32, const void*, const void*, const wdgs_optimizer_state&);
@@ -167,8 +167,8 @@ struct wdgs_optimizer {
     wdgs_optimizer_state state;
     bool owns_state;
     u32 iteration;
-    float* dc;        // compact SH-DC copy float[N][9] {param rgb, m rgb, v rgb} (optimizer.hip "HBM layout note"); always owned
-    bool dc_dirty;    // dc is ahead of state.param_sh / state.state_sh
+    float* dc;        // compact training copy float[N][28]: position, log-scale and SH-DC {param, m, v} (adam.h CS_STRIDE; optimizer.hip "HBM layout note"); always owned
+    bool dc_dirty;    // it is ahead of state.opt_pos / opt_scale / param_sh / state_sh
     const void* guard;  // device word: non-zero at execution time turns step / step_f32 into a no-op (wdgs_optimizer_set_guard)
     // Deferred SH writes (wdgs_optimizer_set_deferred_sh): the steps write the trained DC halves to dc_words (u32[N][2]) instead of the
     // 96-byte rows; sh_stale says the rows are behind until wdgs_optimizer_flush_sh.
@@ -177,10 +177,10 @@ struct wdgs_optimizer {
     bool sh_stale;
 };
 
-// Brings the reference-layout SH arrays up to date with the compact DC copy (no-op when nothing was trained since).
+// Brings the reference-layout arrays (position, log-scale, SH) up to date with the compact training copy (no-op when nothing was trained since).
 static int optimizer_flush_dc(wdgs_optimizer* op) {
     if (!op->dc_dirty) return WDGS_OK;
-    WDGS_TRY(launch_dc_flush(op->dev, op->num_points, op->dc, op->state));
+    WDGS_TRY(launch_cs_flush(op->dev, op->num_points, op->dc, op->state));
     op->dc_dirty = false;
     return WDGS_OK;
 }
@@ -1183,8 +1183,8 @@ int wdgs_optimizer_create(wdgs_device* d, uint32_t n, const wdgs_adam_hyperparam
         if (r != WDGS_OK) { optimizer_free_state(op); delete op; return r; }
         op->iteration = 0;
     }
-    int r = wdgs_alloc((void**)&op->dc, sizeof(float) * 9 * (size_t)std::max(n, 1u), true, d->stream);
-    if (r == WDGS_OK) r = launch_dc_load(d, n, op->state, op->dc);
+    int r = wdgs_alloc((void**)&op->dc, sizeof(float) * 28 * (size_t)std::max(n, 1u), true, d->stream);
+    if (r == WDGS_OK) r = launch_cs_load(d, n, op->state, op->dc);
     if (r != WDGS_OK) { free_dev(op->dc); if (op->owns_state) optimizer_free_state(op); delete op; return r; }
     op->dc_dirty = false;
     *out = op;
@@ -1205,7 +1205,7 @@ int wdgs_optimizer_init_from_point_cloud(wdgs_optimizer* op, const void* gaussia
     WDGS_REQUIRE(op && gaussians && sh, WDGS_E_INVALID, "wdgs_optimizer_init_from_point_cloud: null argument");
     WDGS_TRY(launch_unpack(op->dev, op->num_points, gaussians, sh, op->state));
     op->dc_dirty = false;
-    return launch_dc_load(op->dev, op->num_points, op->state, op->dc);
+    return launch_cs_load(op->dev, op->num_points, op->state, op->dc);
 }
 int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const void* gradients, const void* tile_counts) {
     WDGS_REQUIRE(op && gaussians && sh && gradients && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step: null argument");
@@ -1252,7 +1252,7 @@ int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag) {
 int wdgs_optimizer_state_changed(wdgs_optimizer* op) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
     op->dc_dirty = false;
-    return launch_dc_load(op->dev, op->num_points, op->state, op->dc);
+    return launch_cs_load(op->dev, op->num_points, op->state, op->dc);
 }
 int wdgs_apply_repacked_rows(wdgs_device* d, uint32_t n, const void* rows, uint32_t skip_first, uint32_t skip_count, const void* guard, void* gaussians,
                              void* sh) {

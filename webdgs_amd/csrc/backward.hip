@@ -31,9 +31,9 @@ struct ViewAccumulate {
 struct ViewAdam {
     wdgs_adam_hyperparameters h;
     const u32* tile_counts;
-    float4 *opt_pos, *opt_rot, *opt_scale;
+    float4* opt_rot;
     float* opt_opacity;
-    float* dc;
+    float* cs;       // compact training copy (adam.h)
     u32* gaussians;  // the same buffer K17 reads: this thread's own 24-byte row, read above, re-packed below
     u32* sh;
     const u32* guard;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
             g.scale[0] = wd_unpack_lo(o1.x); g.scale[1] = wd_unpack_hi(o1.x); g.scale[2] = wd_unpack_lo(o1.y);
             g.color[0] = wd_unpack_lo(o1.z); g.color[1] = wd_unpack_hi(o1.z); g.color[2] = wd_unpack_lo(o1.w);
         }
-        adam_and_repack(idx, update, g, ad.h, ad.opt_pos, ad.opt_rot, ad.opt_scale, ad.opt_opacity, ad.dc, ad.gaussians, ad.sh, nullptr, ad.dc_words);
+        adam_and_repack(idx, update, g, ad.h, ad.opt_rot, ad.opt_opacity, ad.cs, ad.gaussians, ad.sh, nullptr, ad.dc_words);
     }
 }
 
@@ -315,13 +315,13 @@ __global__ __launch_bounds__(256, 3) void geometry_backward_views_kernel(u32 n, 
 }  // namespace
 
 int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, void* acc, void* acc_dirty, void* gradients,
-                                  const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, void* dc, void* sh,
+                                  const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, void* cs, void* sh,
                                   const void* guard, void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "geometry_backward_adam", geometry_backward_kernel<2>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st,
                 (const u32*)gaussians, (int*)acc, (u32*)acc_dirty, (u32*)gradients, ViewAccumulate{},
-                (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_pos, (float4*)state.opt_rot, (float4*)state.opt_scale, (float*)state.opt_opacity,
-                          (float*)dc, (u32*)gaussians, (u32*)sh, (const u32*)guard, (u32*)dc_words}));
+                (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_rot, (float*)state.opt_opacity, (float*)cs, (u32*)gaussians, (u32*)sh, (const u32*)guard,
+                          (u32*)dc_words}));
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -7,9 +7,10 @@
 //
 // HBM layout note.  The reference keeps the SH-DC parameter in param_sh[idx*48 + c] (192-byte stride) and its moments in
 // state_sh[idx*48 + c] (384-byte stride): 36 useful bytes cost three extra cache lines per Gaussian per step (measured:
-// 1.06 GB moved for 0.49 GB algorithmic at N = 1 M, profiles/r01b_pmc.json).  The optimizer therefore trains a compact
-// copy "dc" = float[N][9] {param rgb, m rgb, v rgb} and the reference-layout arrays are brought up to date by dc_flush at
-// every hand-over point (get_state / release_state / destroy), loaded by dc_load when state is adopted or unpacked.
+// 1.06 GB moved for 0.49 GB algorithmic at N = 1 M, profiles/r01b_pmc.json), and the position / log-scale structs (OptVec4 x 3) carry a
+// padding lane each.  The optimizer therefore trains a compact copy "cs" = float[N][28] (adam.h: position, log-scale and SH-DC {param, m, v},
+// 112 bytes per Gaussian) and the reference-layout arrays are brought up to date by cs_flush at every hand-over point (get_state /
+// release_state / destroy), loaded by cs_load when state is adopted, unpacked or rewritten from outside.
 // Arithmetic and visible results are unchanged.  Per visible Gaussian: 32 B gradient + 4 B visibility + 2 x (3 x 48 + 12
 // + 36) B state; per Gaussian 24 B + 8 B re-pack writes.
 #include "common.h"
@@ -22,22 +23,21 @@ namespace {
 // overflow word (its tile-entry list was truncated: gradients are incomplete), so a step that is going to be reported as
 // WDGS_E_CAPACITY does not first corrupt the optimizer state.
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
-                                                           const u32* __restrict__ gradients, float4* opt_pos, float4* opt_rot, float4* opt_scale,
-                                                           float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer, const u32* __restrict__ guard,
-                                                           u32* dc_words) {
+                                                           const u32* __restrict__ gradients, float4* opt_rot, float* opt_opacity, float* cs, u32* gaussians,
+                                                           u32* sh_buffer, const u32* __restrict__ guard, u32* dc_words) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     if (guard && *guard != 0u) return;
     const bool update = tile_counts[idx] != 0u;
     Grad14 g = {};
     if (update) g = unpack_gradient(gradients, idx);
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer, nullptr, dc_words);
+    adam_and_repack(idx, update, g, h, opt_rot, opt_opacity, cs, gaussians, sh_buffer, nullptr, dc_words);
 }
 
 // Gaussians [first, first + count): the slice a data-parallel rank owns (first = 0, count = n on a single GPU).
 __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 count, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
-                                                               const float* __restrict__ grad_f32, float4* opt_pos, float4* opt_rot,
-                                                               float4* opt_scale, float* opt_opacity, float* dc, u32* gaussians, u32* sh_buffer,
+                                                               const float* __restrict__ grad_f32, float4* opt_rot, float* opt_opacity, float* cs,
+                                                               u32* gaussians, u32* sh_buffer,
                                                                const u32* __restrict__ guard, u32* __restrict__ guard_seen_host, u32* __restrict__ rows_out,
                                                                u32* dc_words) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 cou
         g.scale[0] = gp[8]; g.scale[1] = gp[9]; g.scale[2] = gp[10];
         g.color[0] = gp[11]; g.color[1] = gp[12]; g.color[2] = gp[13];
     }
-    adam_and_repack(idx, update, g, h, opt_pos, opt_rot, opt_scale, opt_opacity, dc, gaussians, sh_buffer, rows_out, dc_words);
+    adam_and_repack(idx, update, g, h, opt_rot, opt_opacity, cs, gaussians, sh_buffer, rows_out, dc_words);
 }
 
 // Rows published by the other ranks (wdgs_comm_allgather_rows) -> this replica's point cloud: every Gaussian outside
@@ -105,29 +105,50 @@ __global__ void guard_accumulate_kernel(u32* __restrict__ flag, const u32* __res
     *flag = prev | (*src != 0u ? 1u : 0u);
 }
 
-// reference layout -> compact DC copy
-__global__ __launch_bounds__(256) void dc_load_kernel(u32 n, const float* __restrict__ param_sh, const float2* __restrict__ state_sh, float* __restrict__ dc) {
+// reference layout -> compact training copy (adam.h: CS_STRIDE)
+__global__ __launch_bounds__(256) void cs_load_kernel(u32 n, const float4* __restrict__ opt_pos, const float4* __restrict__ opt_scale, const float* __restrict__ param_sh,
+                                                       const float2* __restrict__ state_sh, float* __restrict__ cs) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    float* d = dc + (size_t)idx * 9;
+    const float4 pp = opt_pos[(size_t)idx * 3], pm = opt_pos[(size_t)idx * 3 + 1], pv = opt_pos[(size_t)idx * 3 + 2];
+    const float4 sp = opt_scale[(size_t)idx * 3], sm = opt_scale[(size_t)idx * 3 + 1], sv = opt_scale[(size_t)idx * 3 + 2];
+    float cp[3], cm[3], cv[3];
 #pragma unroll
     for (u32 c = 0; c < 3u; c++) {
         const float2 mv = state_sh[(size_t)idx * 48 + c];
-        d[c] = param_sh[(size_t)idx * 48 + c];
-        d[3 + c] = mv.x;
-        d[6 + c] = mv.y;
+        cp[c] = param_sh[(size_t)idx * 48 + c];
+        cm[c] = mv.x;
+        cv[c] = mv.y;
     }
+    float4* row = reinterpret_cast<float4*>(cs + (size_t)idx * CS_STRIDE);
+    row[0] = make_float4(pp.x, pp.y, pp.z, pm.x);
+    row[1] = make_float4(pm.y, pm.z, pv.x, pv.y);
+    row[2] = make_float4(pv.z, sp.x, sp.y, sp.z);
+    row[3] = make_float4(sm.x, sm.y, sm.z, sv.x);
+    row[4] = make_float4(sv.y, sv.z, cp[0], cp[1]);
+    row[5] = make_float4(cp[2], cm[0], cm[1], cm[2]);
+    row[6] = make_float4(cv[0], cv[1], cv[2], 0.0f);
 }
 
-// compact DC copy -> reference layout
-__global__ __launch_bounds__(256) void dc_flush_kernel(u32 n, const float* __restrict__ dc, float* __restrict__ param_sh, float2* __restrict__ state_sh) {
+// compact training copy -> reference layout.  The fourth lanes get the constants the reference's Adam writes (adam.wgsl:108, 142: position
+// w = 1, scale w = 0, their moments 0) -- which is also what unpack and the densify scatter leave in Gaussians that were never updated.
+__global__ __launch_bounds__(256) void cs_flush_kernel(u32 n, const float* __restrict__ cs, float4* __restrict__ opt_pos, float4* __restrict__ opt_scale,
+                                                        float* __restrict__ param_sh, float2* __restrict__ state_sh) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const float* d = dc + (size_t)idx * 9;
+    const float4* row = reinterpret_cast<const float4*>(cs + (size_t)idx * CS_STRIDE);
+    const float4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6];
+    opt_pos[(size_t)idx * 3] = make_float4(q0.x, q0.y, q0.z, 1.0f);
+    opt_pos[(size_t)idx * 3 + 1] = make_float4(q0.w, q1.x, q1.y, 0.0f);
+    opt_pos[(size_t)idx * 3 + 2] = make_float4(q1.z, q1.w, q2.x, 0.0f);
+    opt_scale[(size_t)idx * 3] = make_float4(q2.y, q2.z, q2.w, 0.0f);
+    opt_scale[(size_t)idx * 3 + 1] = make_float4(q3.x, q3.y, q3.z, 0.0f);
+    opt_scale[(size_t)idx * 3 + 2] = make_float4(q3.w, q4.x, q4.y, 0.0f);
+    const float cp[3] = {q4.z, q4.w, q5.x}, cm[3] = {q5.y, q5.z, q5.w}, cv[3] = {q6.x, q6.y, q6.z};
 #pragma unroll
     for (u32 c = 0; c < 3u; c++) {
-        param_sh[(size_t)idx * 48 + c] = d[c];
-        state_sh[(size_t)idx * 48 + c] = make_float2(d[3 + c], d[6 + c]);
+        param_sh[(size_t)idx * 48 + c] = cp[c];
+        state_sh[(size_t)idx * 48 + c] = make_float2(cm[c], cv[c]);
     }
 }
 
@@ -188,21 +209,20 @@ __global__ __launch_bounds__(256) void unpack_kernel(u32 n, const u32* __restric
 }  // namespace
 
 int launch_adam_repack(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* tile_counts, const void* gradients,
-                       const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* dc_words) {
+                       const wdgs_optimizer_state& st, void* cs, void* gaussians, void* sh, const void* guard, void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack", adam_repack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)tile_counts, (const u32*)gradients,
-                (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians, (u32*)sh,
-                (const u32*)guard, (u32*)dc_words);
+                (float4*)st.opt_rot, (float*)st.opt_opacity, (float*)cs, (u32*)gaussians, (u32*)sh, (const u32*)guard, (u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
 int launch_adam_repack_f32(wdgs_device* dev, u32 first, u32 count, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
-                           const wdgs_optimizer_state& st, void* dc, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out,
+                           const wdgs_optimizer_state& st, void* cs, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out,
                            void* dc_words) {
     if (count == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, first, count, h, (const u32*)visible,
-                (const float*)grad_f32, (float4*)st.opt_pos, (float4*)st.opt_rot, (float4*)st.opt_scale, (float*)st.opt_opacity, (float*)dc, (u32*)gaussians,
+                (const float*)grad_f32, (float4*)st.opt_rot, (float*)st.opt_opacity, (float*)cs, (u32*)gaussians,
                 (u32*)sh, (const u32*)guard, (u32*)guard_seen_host, (u32*)rows_out, (u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
@@ -237,16 +257,18 @@ int launch_guard_accumulate(wdgs_device* dev, void* flag, const void* src, u32 o
     return WDGS_OK;
 }
 
-int launch_dc_load(wdgs_device* dev, u32 n, const wdgs_optimizer_state& st, void* dc) {
+int launch_cs_load(wdgs_device* dev, u32 n, const wdgs_optimizer_state& st, void* cs) {
     if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "optimizer_dc_load", dc_load_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)st.param_sh, (const float2*)st.state_sh, (float*)dc);
+    WDGS_LAUNCH(dev, "optimizer_cs_load", cs_load_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float4*)st.opt_pos, (const float4*)st.opt_scale,
+                (const float*)st.param_sh, (const float2*)st.state_sh, (float*)cs);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_dc_flush(wdgs_device* dev, u32 n, const void* dc, const wdgs_optimizer_state& st) {
+int launch_cs_flush(wdgs_device* dev, u32 n, const void* cs, const wdgs_optimizer_state& st) {
     if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "optimizer_dc_flush", dc_flush_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)dc, (float*)st.param_sh, (float2*)st.state_sh);
+    WDGS_LAUNCH(dev, "optimizer_cs_flush", cs_flush_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)cs, (float4*)st.opt_pos, (float4*)st.opt_scale,
+                (float*)st.param_sh, (float2*)st.state_sh);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
