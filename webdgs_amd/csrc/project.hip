@@ -412,12 +412,16 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
     __shared__ u32 s_pre[256];                     // exclusive prefix of the entry counts over the workgroup's Gaussians
     __shared__ u32 s_box[256];                     // min_x | min_y << 8 | width << 16  (all < 256 on this path)
     __shared__ u32 s_inv[256], s_dep[256];
-    __shared__ __align__(16) unsigned short s_own[ES_CHUNK];  // owner (Gaussian of the workgroup, + 1) of every entry of the chunk
     __shared__ u32 whist[4][256];                  // per-wave column counters, then per-wave column starts inside the chunk
     __shared__ u32 s_gbase[256];                   // where this workgroup's next entry of column c goes (global)
     __shared__ u32 s_delta[256];                   // global position = s_delta[column] + position in the chunk's column order
-    __shared__ u32 s_keys[ES_CHUNK], s_vals[ES_CHUNK];
+    __shared__ __align__(16) u32 s_keys[ES_CHUNK];
+    __shared__ __align__(16) u32 s_vals[ES_CHUNK];
     __shared__ u32 s_wsum[4], s_tsum[4];
+    // owner (Gaussian of the workgroup, + 1) of every entry of the chunk: lives in the first 4 KB of s_vals, which is written only after
+    // the ranking has read the owners (26 KB per workgroup: six fit a CU, five at 30 KB -- 3907 workgroups are 2.5 rounds of 1536 instead of
+    // 3.05 rounds of 1280)
+    unsigned short* const s_own = reinterpret_cast<unsigned short*>(s_vals);
     const u32 wg = xcd_contiguous(blockIdx.x, gridDim.x);
     const u32 idx = wg * 256u + threadIdx.x;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
