@@ -10,6 +10,8 @@ this file compares:
           the reference's K17 deviates from the true gradient in exactly the places named in the test                -- test_k17_*
   (c) K18 Adam without bias correction, quaternion renormalisation, visibility skip                                 -- test_adam_*
   (d) K26-K30 densify decisions, capacity rule, offsets, clone / split children                                     -- test_densify_*
+  (e) K15 loss gradient (L1 / L2 / DSSIM with 5x5 box statistics)                                                   -- test_k15_*
+  (f) K21-K23 metric map, K24 metric counts, K31 ground-truth downsample                                            -- test_k21_*, test_k24_*, test_k31_*
 
 K14 / K16 have their float64 checks in tests/test_oracle_golden.py (re-composite, finite differences of the composite)."""
 import numpy as np
@@ -352,3 +354,132 @@ def test_densify_decisions_capacity_and_children(orc):
     assert np.all(ost["opt_opacity"][:, 1:] == 0)                                                       # Q16: opacity moments always zeroed
     m_sig = ind.sigmoid(st["opt_opacity"][src, 0].astype(np.float64))
     assert np.array_equal(ost["opt_opacity"][:, 0], np.where(m_sig > 0.8, np.float32(1.38629436112), st["opt_opacity"][src, 0]))
+
+
+# ----------------------------------------------------------------------------------------------------------------- (e) K15
+def _loss_gradient_fp64(pred_u8, targ_u8, l1, l2, ld, c1, c2):
+    """loss.wgsl:25-115 from its formulas: L1 / L2 terms per channel plus the (non-differentiated-statistics) DSSIM term
+    0.5 (1 - SSIM) (x - y) with 5x5 box statistics sampled clamp-to-edge; alpha lane 1."""
+    from scipy.ndimage import uniform_filter
+    x, y = pred_u8[..., :3].astype(np.float64) / 255.0, targ_u8[..., :3].astype(np.float64) / 255.0
+    box = lambda a: uniform_filter(a, size=(5, 5, 1), mode="nearest")
+    mx, my = box(x), box(y)
+    sxx, syy, sxy = box(x * x) - mx * mx, box(y * y) - my * my, box(x * y) - mx * my     # == mean of centred products
+    ssim = ((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2))
+    d = x - y
+    out = np.ones(pred_u8.shape[:2] + (4,))
+    out[..., :3] = l1 * np.sign(d) + l2 * d + (ld * 0.5 * (1 - ssim) * d if ld > 0 else 0.0)
+    return out, ssim
+
+
+@pytest.mark.parametrize("lam", [(0.8, 0.0, 0.2), (0.5, 0.3, 0.2), (1.0, 0.0, 0.0)], ids=["default", "with-l2", "l1-only"])
+def test_k15_loss_gradient_is_the_formula(orc, lam):
+    """K15 against a float64 restatement that uses scipy's box filter with edge replication (E[ab] - E[a]E[b] form; the shader sums
+    centred products): every lane within 2e-6 on images with smooth and noisy regions, equal and unequal pixels, non-multiple-of-16
+    size; and the DSSIM factor really is 0.5 (1 - SSIM) with SSIM in [-1, 1]."""
+    rng = np.random.default_rng(5)
+    h, w = 45, 71
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 127 + 90 * np.sin(xx / 9.0)[..., None] * np.cos(yy / 7.0)[..., None] * np.array([1.0, 0.7, -0.5, 0.0])
+    pred = np.clip(base + rng.normal(0, 25, (h, w, 4)), 0, 255).astype(np.uint8)
+    targ = np.clip(base + rng.normal(0, 6, (h, w, 4)), 0, 255).astype(np.uint8)
+    targ[10:20, 10:30] = pred[10:20, 10:30]                      # an exactly matching region: sign(0) = 0, gradient 0
+    pred[30:, :8] = 0; targ[30:, :8] = 255                       # saturated difference at an image edge
+    cfg = orc.training_config(lambda_l1=lam[0], lambda_l2=lam[1], lambda_dssim=lam[2])
+    got = orc.loss_grad(pred, targ, cfg)
+    want, ssim = _loss_gradient_fp64(pred, targ, float(cfg[0]), float(cfg[1]), float(cfg[2]), float(cfg[3]), float(cfg[4]))
+    assert got.shape == want.shape and np.all(got[..., 3] == 1.0)
+    assert np.abs(got - want).max() < 2e-6, np.abs(got - want).max()
+    assert np.all(got[10:20, 10:30, :3] == 0)
+    assert ssim.min() >= -1 - 1e-9 and ssim.max() <= 1 + 1e-9 and ssim[12:18, 12:28].min() > 0.999999      # identical windows: SSIM = 1
+    assert np.abs(got[..., :3]).max() <= lam[0] + lam[1] + lam[2] + 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------- (f) K21-K24, K31
+def test_k21_k23_metric_map_in_exact_integer_arithmetic(orc):
+    """The per-pixel error is floor(1e6 * sum|d rgb| / 765) -- evaluated here in exact integers -- to within the one unit a float32
+    product can fall short of an integer; min / max are those of the stored errors; the flag is (e - min) / (max - min) > threshold, exact
+    except within 1e-6 of the threshold.  Constant images (max == min) flag nothing."""
+    rng = np.random.default_rng(9)
+    h, w = 37, 53
+    pred = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    targ = np.clip(pred.astype(np.int64) + rng.integers(-40, 41, (h, w, 4)), 0, 255).astype(np.uint8)
+    targ[0, 0] = pred[0, 0]                                       # a zero-error pixel
+    for thr in (0.1, 0.5, 0.9):
+        err, mm, flags = orc.metric_map(pred, targ, thr)
+        s = np.abs(pred[..., :3].astype(np.int64) - targ[..., :3].astype(np.int64)).sum(-1)
+        want = (s * 1_000_000) // 765
+        assert np.abs(err.astype(np.int64) - want).max() <= 1 and (err.astype(np.int64) == want).mean() > 0.9
+        assert mm[0] == err.min() == 0 and mm[1] == err.max()
+        num, den = err.astype(np.int64) - int(mm[0]), int(mm[1]) - int(mm[0])
+        exact = num > thr * den
+        near = np.abs(num / den - thr) < 1e-6
+        assert np.array_equal(flags.astype(bool)[~near], exact[~near]) and 0 < flags.sum() < flags.size
+    err, mm, flags = orc.metric_map(pred, pred, 0.0)
+    assert not err.any() and not flags.any() and mm[0] == mm[1] == 0
+
+
+@pytest.mark.parametrize("shape", [((64, 96), (32, 48)), ((45, 71), (22, 35)), ((40, 40), (40, 40)), ((30, 50), (10, 25))],
+                         ids=["half", "odd-half", "same-size", "third-by-half"])
+def test_k31_downsample_is_the_linear_sampler(orc, shape):
+    """The ground truth is drawn into the metric target with a linear sampler, clamp-to-edge (trainer.ts:303-328): float64 restatement
+    of bilinear sampling at destination texel centres, then unorm8 rounding; the oracle may differ by one level only where the float64
+    value sits within 1e-4 of a rounding boundary.  Exact halving is the 2x2 box average; same size is the identity."""
+    (sh_, sw_), (dh, dw) = shape
+    rng = np.random.default_rng(13)
+    src = rng.integers(0, 256, (sh_, sw_, 4), dtype=np.uint8)
+    got = orc.downsample_bilinear(src, dw, dh)
+    u = (np.arange(dw) + 0.5) / dw * sw_ - 0.5
+    v = (np.arange(dh) + 0.5) / dh * sh_ - 0.5
+    x0, y0 = np.floor(u).astype(int), np.floor(v).astype(int)
+    wu, wv = (u - x0)[None, :, None], (v - y0)[:, None, None]
+    cx = lambda a: np.clip(a, 0, sw_ - 1)
+    cy = lambda a: np.clip(a, 0, sh_ - 1)
+    s = src.astype(np.float64)
+    top = s[cy(y0)][:, cx(x0)] * (1 - wu) + s[cy(y0)][:, cx(x0 + 1)] * wu
+    bot = s[cy(y0 + 1)][:, cx(x0)] * (1 - wu) + s[cy(y0 + 1)][:, cx(x0 + 1)] * wu
+    val = top * (1 - wv) + bot * wv
+    want = np.floor(val + 0.5)
+    on_boundary = np.abs(val + 0.5 - np.round(val + 0.5)) < 1e-4
+    diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert diff[~on_boundary].max() == 0 and diff.max() <= 1
+    if (sh_, sw_) == (2 * dh, 2 * dw):
+        box = s.reshape(dh, 2, dw, 2, 4).mean((1, 3))
+        assert np.abs(val - box).max() < 1e-9
+    if (sh_, sw_) == (dh, dw):
+        assert np.array_equal(got, src)
+
+
+def test_k24_metric_counts_are_the_flagged_contributions(orc):
+    """K24 recounted in float64 from the forward pass's own lists: for every flagged pixel, +1 for each of the first n_contrib entries of
+    its tile whose alpha = min(0.99, sigma * exp(-q/2)) reaches 1/255 (no extent test: SURVEY Q21).  Identical except where the float64
+    alpha is within 1e-4 (relative) of the cut."""
+    cfg, g, sh, cam = _scene(base="c1", n=3000, w=96, h=64, view=2)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    fw = orc.forward(g, sh, cam, st, ti)
+    rng = np.random.default_rng(3)
+    flags = (rng.random((cfg.height, cfg.width)) < 0.3).astype(np.uint32)
+    n = g.shape[0]
+    counts = np.zeros(n, np.uint32)
+    e = fw["total_entries"]
+    orc.metric_count(st, fw["tile_ranges"], fw["sorted_values"][:e].copy(), e, fw["splats"], flags, fw["n_contrib"], counts)
+
+    sp = fw["splats"].view(np.float16).reshape(-1, 12).astype(np.float64)
+    centre = (sp[:, 0:2] * np.array([0.5, -0.5]) + 0.5) * np.array([cfg.width, cfg.height])
+    want = np.zeros(n, np.int64)
+    unsure = np.zeros(n, bool)
+    ntx = (cfg.width + 15) // 16
+    nc = fw["n_contrib"].reshape(cfg.height, cfg.width)
+    for py, px in zip(*np.nonzero(flags)):
+        k = int(nc[py, px])
+        start = int(fw["tile_ranges"][(py // 16) * ntx + px // 16])
+        if k == 0 or start == 0xFFFFFFFF:
+            continue
+        ids = fw["sorted_values"][start:start + k].astype(np.int64)
+        d = np.array([px + 0.5, py + 0.5]) - centre[ids]
+        q = sp[ids, 4] * d[:, 0] ** 2 + 2 * sp[ids, 5] * d[:, 0] * d[:, 1] + sp[ids, 6] * d[:, 1] ** 2
+        alpha = np.minimum(0.99, sp[ids, 11] * np.exp(-0.5 * q))
+        np.add.at(want, ids, alpha >= 1 / 255)
+        np.logical_or.at(unsure, ids, np.abs(alpha * 255 - 1) < 1e-4)
+    assert want.sum() > 1000
+    assert np.array_equal(counts[~unsure], want[~unsure]) and np.abs(counts.astype(np.int64) - want).max() <= 1
