@@ -75,7 +75,9 @@ WD_DEV int cvt_fixed(float scaled) {
 
 // WPW = waves per workgroup: 1 (default: workgroup = one 8x8 block; the four blocks of a tile are numbered so that they are dispatched back
 // to back on one XCD and share its L2 lines of the entry list) or 4 (workgroup = tile, round 2's form).
-template <u32 WPW>
+// LDS_SUMS: the wave sums of eight of the nine contributions go through a transposition in wave-private LDS (below) instead of the
+// register butterfly.
+template <u32 WPW, bool LDS_SUMS>
 __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     __shared__ float4 s_con_all[WPW][64];  // conic.x, conic.y, conic.z, opacity
     __shared__ float4 s_col_all[WPW][64];  // r, g, b, gaussian index (bits)
     __shared__ float4 s_aux_all[WPW][64];  // position of the entry in the tile's list (bits), 2*conic.xyz
+    __shared__ int s_sum_all[LDS_SUMS ? WPW : 1u][LDS_SUMS ? 8u * 64u : 1u];  // [slot 0..7][pixel lane]: one iteration's contributions
 
     // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
     // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
@@ -117,6 +120,15 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const u32 quad_lane = lane & 3u;
+    // LDS_SUMS: lane (q, part) = (lane >> 3, lane & 7) adds up the eight contributions [q][8 part .. 8 part + 7] -- two 16-byte reads, the
+    // halves taken in opposite order by odd q, which makes both reads conflict-free in ds_read_b128's lane groups
+    int* const s_sum = s_sum_all[LDS_SUMS ? slot : 0u];
+    const u32 sum_q = lane >> 3, sum_first = (sum_q & 1u) * 4u;
+    const int4* const sum_rd0 = reinterpret_cast<const int4*>(s_sum + (LDS_SUMS ? sum_q * 64u + (lane & 7u) * 8u + sum_first : 0u));
+    const int4* const sum_rd1 = reinterpret_cast<const int4*>(s_sum + (LDS_SUMS ? sum_q * 64u + (lane & 7u) * 8u + (4u - sum_first) : 0u));
+    const bool sum_lane = LDS_SUMS ? ((lane & 7u) == 0u) : false;
+    const bool atomic_lane = LDS_SUMS ? ((lane & 7u) == 0u || (lane & 15u) == 1u) : ((lane & 15u) < 3u);
+    const u32 atomic_slot = LDS_SUMS ? (sum_lane ? sum_q : 8u + (lane >> 4)) : ((quad_lane == 2u) ? 8u + (lane >> 4) : 2u * (lane >> 4) + quad_lane);
 
     const u32 range_start = ranges[tile_id];
     const u32 range_end = ranges[tile_id + 1u];
@@ -245,6 +257,28 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             // conic.y term: the reference's ((mhG * 2) * dx) * dy, scaled by dL_dG and 1e6.  A factor 2 commutes with every rounding, so it
             // is taken out of the chain -- which then starts from the mhG * dx of the conic.x term -- and folded into the scale (2e6 is exact).
             const int f_cy = cvt_fixed((dL_dG * ((mhG * d.x) * d.y)) * (2.0f * FIXED_SCALE));
+            int m;
+            if (LDS_SUMS) {
+                // ---- nine wave sums.  A cross-lane VALU operation is expensive on gfx950 when it is counted in issue time rather than in
+                // instructions (scripts/microbench/valu_issue.hip, profiles/r03s_valu_issue_w7.txt: v_permlane*_swap 10-13 cycles and a DPP
+                // add 5-8 among ordinary arithmetic, which costs 2.4), and the halving butterfly needs six swaps and nine DPP steps.  Eight
+                // of the sums therefore go through LDS, whose pipe this kernel leaves idle: every pixel lane stores its eight contributions
+                // as a column of an [8][64] array, lane (q, part) reads back eight consecutive entries of row q and adds them with plain
+                // integer adds, and three DPP steps inside the eight lanes of a row's group finish the sum.  LDS operations of one wave
+                // execute in order, so the stores, the transposed reads and the next iteration's stores need no barrier between them.
+                s_sum[0u * 64u + lane] = f_mx; s_sum[1u * 64u + lane] = f_my; s_sum[2u * 64u + lane] = f_cx; s_sum[3u * 64u + lane] = f_cy;
+                s_sum[4u * 64u + lane] = f_cz; s_sum[5u * 64u + lane] = f_op; s_sum[6u * 64u + lane] = f_r; s_sum[7u * 64u + lane] = f_g;
+                const int4 h0 = *sum_rd0, h1 = *sum_rd1;
+                unsigned x = ((unsigned)h0.x + (unsigned)h0.y) + ((unsigned)h0.z + (unsigned)h0.w) + (((unsigned)h1.x + (unsigned)h1.y) + ((unsigned)h1.z + (unsigned)h1.w));
+                x += (unsigned)dpp_xor1((int)x);
+                x += (unsigned)dpp_xor2((int)x);
+                x += (unsigned)dpp_half_mirror((int)x);   // the other quad of the eight-lane group
+                // blue stays in registers: quad sums, then the four quads of a 16-lane row; row r adds its partial sum to slot 8 + r
+                unsigned b = (unsigned)quad_sum(f_b);
+                b += (unsigned)dpp_ror4((int)b);
+                b += (unsigned)dpp_ror8((int)b);
+                m = sum_lane ? (int)x : (int)b;
+            } else {
             // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
             // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
             const int w0 = fold32(f_mx, f_cz), w1 = fold32(f_my, f_op), w2 = fold32(f_cx, f_r), w3 = fold32(f_cy, f_g);
@@ -255,12 +289,12 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             // register (two rotations by whole quads) instead of once per register.  Blue is not folded across the four rows: row r
             // adds its partial sum to slot 8 + r (the accumulator row has twelve words; geometry_backward adds the four up), so the
             // twelve atomic lanes of a splat hit twelve different consecutive words.
-            int m = (quad_lane == 0u) ? u0 : (quad_lane == 1u ? u1 : q8);
+            m = (quad_lane == 0u) ? u0 : (quad_lane == 1u ? u1 : q8);
             m = (int)((unsigned)m + (unsigned)dpp_ror4(m));
             m = (int)((unsigned)m + (unsigned)dpp_ror8(m));
-            if ((lane & 15u) < 3u) {
-                const u32 row = lane >> 4;
-                const u32 slot = (quad_lane == 2u) ? 8u + row : 2u * row + quad_lane;
+            }
+            if (atomic_lane) {
+                const u32 slot = atomic_slot;
                 const u32 gidx = __float_as_uint(col.w);
 #ifdef WDGS_EXPERIMENT_NO_ATOMICS  // timing experiment only (results are wrong): what the kernel costs without its global atomics
                 asm volatile("" ::"v"(m), "v"(gidx), "v"(slot));
@@ -303,14 +337,18 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
     // one 8x8 block (one wave) per workgroup: nothing is shared inside a tile's workgroup but cache lines, and single-wave workgroups are
     // placed as soon as ONE wave slot is free -- a shorter tail: 303 -> 295.5 us at c3, same box (r03l).  WDGS_BWR_WPW=4: workgroup = tile.
     static const bool one_wave = !(std::getenv("WDGS_BWR_WPW") && std::getenv("WDGS_BWR_WPW")[0] == '4');
+    // WDGS_BWR_SUMS=butterfly: round 2's register-only reduction (same-box A/B; the LDS form is 6 KB of LDS per wave instead of 4)
+    static const bool lds_sums = !(std::getenv("WDGS_BWR_SUMS") && std::getenv("WDGS_BWR_SUMS")[0] == 'b');
+#define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
+    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), 0, st, num_tiles_x, tiles, (const u32*)ranges, \
+                (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
-        WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel<1u>, dim3(slots), dim3(64), 0, st, num_tiles_x, tiles, (const u32*)ranges, (const u32*)instances,
-                    (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty);
+        if (lds_sums) { WDGS_BWR_LAUNCH(1u, true, slots, 64); } else { WDGS_BWR_LAUNCH(1u, false, slots, 64); }
     } else {
-        WDGS_LAUNCH(dev, "backward_rasterize", backward_rasterize_kernel<4u>, dim3(tiles), dim3(256), 0, st, num_tiles_x, tiles, (const u32*)ranges, (const u32*)instances,
-                    (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty);
+        if (lds_sums) { WDGS_BWR_LAUNCH(4u, true, tiles, 256); } else { WDGS_BWR_LAUNCH(4u, false, tiles, 256); }
     }
+#undef WDGS_BWR_LAUNCH
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
