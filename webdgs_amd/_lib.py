@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwebdgs_hip.so")
+# WDGS_LIB_PATH: another build of the same library (same-box A/B measurements of two source states); never a different implementation
+LIB_PATH = os.environ.get("WDGS_LIB_PATH") or os.path.join(_HERE, "lib", "libwebdgs_hip.so")
 
 WDGS_OK, WDGS_E_INVALID, WDGS_E_HIP, WDGS_E_CAPACITY, WDGS_E_STATE = 0, -1, -2, -3, -4
 

@@ -87,7 +87,6 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y
     __shared__ float4 s_con_all[WPW][64];  // conic.x, conic.y, conic.z, opacity
     __shared__ float4 s_col_all[WPW][64];  // r, g, b, gaussian index (bits)
-    __shared__ float4 s_aux_all[WPW][64];  // position of the entry in the tile's list (bits), 2*conic.xyz
     __shared__ int s_sum_all[LDS_SUMS ? WPW : 1u][LDS_SUMS ? 8u * 64u : 1u];  // [slot 0..7][pixel lane]: one iteration's contributions
 
     // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     float4* const s_geo = s_geo_all[slot];  // wave-private record sets
     float4* const s_con = s_con_all[slot];
     float4* const s_col = s_col_all[slot];
-    float4* const s_aux = s_aux_all[slot];
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -180,8 +178,12 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             s_geo[slot] = make_float4(cx, cy, ex, ey);
             s_con[slot] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
             s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx_c));
-            s_aux[slot] = make_float4(__uint_as_float(lo + lane), 2.0f * wd_unpack_lo(w23.x), 2.0f * wd_unpack_hi(w23.x), 2.0f * wd_unpack_lo(w23.y));
         }
+        // A pixel composited the entries at positions below its n_contrib: of this chunk, lanes j < pix_n - lo, i.e. -- the compaction keeps
+        // the order -- the first `mine` records of the list.  (Counting them here, once per chunk, replaces a fourth record array with the
+        // entry's position and its read in every iteration: 3 KB of records + 2 KB of sums = 5 KB per wave, 32 resident waves per CU.)
+        const u32 rel = (pix_n > lo) ? min(pix_n - lo, 64u) : 0u;
+        const u32 mine = (u32)__popcll(m & ((rel >= 64u) ? ~0ull : ((1ull << rel) - 1ull)));
         // next chunk's Splat gather and the index fetch of the chunk after it: in flight while this chunk is processed
         gidx_c = gidx_n;
         if (gidx_c != 0xFFFFFFFFu) {
@@ -193,16 +195,19 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         __builtin_amdgcn_wave_barrier();
 
         for (u32 i = n_list; i-- > 0u;) {  // back to front
-            // all four records at once: one LDS round trip per iteration (after the block-level alpha test nearly every iteration
+            // all three records at once: one LDS round trip per iteration (after the block-level alpha test nearly every iteration
             // has a contributing pixel, so the early exits the staged reads used to serve are rare)
             const float4 geo = s_geo[i];
-            const float4 aux = s_aux[i];  // entry position (bits), 2*conic.x, 2*conic.y, 2*conic.z
             const float4 con = s_con[i];
             const float4 col = s_col[i];
             const f2 d = pxy - f2{geo.x, geo.y};
             // (bitwise, not short-circuit: no branches for the three tests)
-            const bool cand = ((int)(__float_as_uint(aux.x) < pix_n) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
-            const float t1 = __builtin_fmaf(con.x, d.x, aux.z * d.y);
+            const bool cand = ((int)(i < mine) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
+            // The reference's 2 * conic factors (tiled-backward-rasterize.wgsl:96-99, 141-142) are powers of two: they commute with every
+            // rounding, so they are applied to products instead of being stored per record -- (2 c.y) d.y = 2 (c.y d.y), and further down
+            // (-0.5 G) (2 w) = -(G w).  Same bits (no operand here is small enough for a product to be subnormal: conics are fp16 values).
+            const float cyd = con.y * d.y;
+            const float t1 = __builtin_fmaf(con.x, d.x, cyd + cyd);
             const float power = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
             // exp with its range handling hoisted out of the common case (dmath.h wd_exp_inrange): an argument above 87 or a NaN -- an
             // indefinite conic after fp16 rounding -- sends the whole wave through the full form; arguments below -80 are clamped, which
@@ -245,10 +250,10 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             ar_b = __builtin_fmaf(alpha_m, col.z, oma * ar_b);
             const float dL_dG = con.w * dL_dalpha;
             const int f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
-            const f2 dpow = f2{__builtin_fmaf(aux.y, d.x, aux.z * d.y), __builtin_fmaf(aux.w, d.y, aux.z * d.x)};  // (dpow/ddx, dpow/ddy)
+            const f2 hpow = f2{__builtin_fmaf(con.x, d.x, cyd), __builtin_fmaf(con.z, d.y, con.y * d.x)};  // half of (dpow/ddx, dpow/ddy)
             const float mhG = -0.5f * G;
-            const f2 dG = mhG * dpow;
-            const f2 fm = (dL_dG * (-dG)) * FIXED_SCALE;
+            const f2 ndG = G * hpow;  // -dG = -(mhG * dpow) = G * (dpow / 2)
+            const f2 fm = (dL_dG * ndG) * FIXED_SCALE;
             const int f_mx = cvt_fixed(fm.x);
             const int f_my = cvt_fixed(fm.y);
             const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;  // conic.x and conic.z terms
@@ -339,8 +344,10 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
     static const bool one_wave = !(std::getenv("WDGS_BWR_WPW") && std::getenv("WDGS_BWR_WPW")[0] == '4');
     // WDGS_BWR_SUMS=butterfly: round 2's register-only reduction (same-box A/B; the LDS form is 6 KB of LDS per wave instead of 4)
     static const bool lds_sums = !(std::getenv("WDGS_BWR_SUMS") && std::getenv("WDGS_BWR_SUMS")[0] == 'b');
+    // WDGS_BWR_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup -- an occupancy experiment (how much does the kernel lose per resident wave less?)
+    static const u32 extra_lds = std::getenv("WDGS_BWR_EXTRA_LDS") ? (u32)std::atoi(std::getenv("WDGS_BWR_EXTRA_LDS")) : 0u;
 #define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
-    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), 0, st, num_tiles_x, tiles, (const u32*)ranges, \
+    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), extra_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
                 (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
