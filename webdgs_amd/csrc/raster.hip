@@ -30,9 +30,10 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                                                         const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                                                         const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
                                                         u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib) {
-    __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y   (pixels)
-    __shared__ float4 s_con_all[WPW][64];  // conic.x, 2*conic.y, conic.z, opacity
-    __shared__ float4 s_col_all[WPW][64];  // r, g, b, position in the tile list + 1 (bits)
+    // (one record more than a chunk holds: the loop below reads one record ahead)
+    __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
+    __shared__ float4 s_con_all[WPW][65];  // conic.x, 2*conic.y, conic.z, opacity
+    __shared__ float4 s_col_all[WPW][65];  // r, g, b, position in the tile list + 1 (bits)
 
     // independent waves (no barrier is ever taken): one per 8x8 block
     u32 tile_id, sub;
@@ -112,19 +113,13 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS records written above are read below by other lanes
             __builtin_amdgcn_wave_barrier();
 
-            for (u32 i = 0; i < cnt; i++) {
-                const float4 geo = s_geo[i];
-                const float dx = px - geo.x, dy = py - geo.y;
-                // (bitwise, not short-circuit: one LDS round trip and no branches for the tests)
-                const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;
-                if (GAUSSIAN_MODE) {
-                    const bool active = ((int)inside & (int)!(A > 0.99f)) != 0;
+            if (GAUSSIAN_MODE) {
+                auto composite = [&](const float4 geo, const float4 con, const float4 col) {
+                    const float dx = px - geo.x, dy = py - geo.y;
+                    // (bitwise, not short-circuit: no branches for the tests)
+                    const bool active = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w) & (int)!(A > 0.99f)) != 0;
                     // (no wave-wide "nobody is active" early-out: after the compaction nearly every splat has an active pixel, and the
                     // test cost two VALU operations per iteration; an iteration without one falls through the empty exec mask below)
-                    const float4 con = s_con[i];
-                    const float4 col = s_col[i];
-                    u32 entry_pos = __float_as_uint(col.w);
-                    asm volatile("" : "+v"(entry_pos));  // keep the record a single ds_read_b128 (no second, conditional LDS round trip)
                     if (active) {
                         const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
                         const float q = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
@@ -145,10 +140,26 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                         cg = __builtin_fmaf(col.y, w, cg);
                         cb = __builtin_fmaf(col.z, w, cb);
                         A = A + w;
-                        last_contributor = (alpha >= (1.0f / 255.0f)) ? entry_pos : last_contributor;
+                        last_contributor = (alpha >= (1.0f / 255.0f)) ? __float_as_uint(col.w) : last_contributor;
                     }
-                } else {
+                };
+                // The records of the next iteration are fetched while this one composites: an LDS round trip (~100 cycles) is as long as
+                // an iteration's arithmetic, and read at the top of the iteration that uses them it cost a third of the wave's time in
+                // waiting.  Two iterations per trip through the loop, so that the two record sets swap roles without register copies.
+                float4 geo_a = s_geo[0], con_a = s_con[0], col_a = s_col[0];  // (cnt == 0: a stale record, never used)
+                for (u32 i = 0; i < cnt; i += 2u) {
+                    const float4 geo_b = s_geo[i + 1u], con_b = s_con[i + 1u], col_b = s_col[i + 1u];  // (i + 1 <= 64: the spare record)
+                    composite(geo_a, con_a, col_a);
+                    if (i + 1u >= cnt) break;
+                    geo_a = s_geo[i + 2u]; con_a = s_con[i + 2u]; col_a = s_col[i + 2u];   // (i + 2 <= 64)
+                    composite(geo_b, con_b, col_b);
+                }
+            } else {
+                for (u32 i = 0; i < cnt; i++) {
                     // point-cloud preview (tiled-rasterizer.wgsl:212-222): paints yellow discs, no saturation test
+                    const float4 geo = s_geo[i];
+                    const float dx = px - geo.x, dy = py - geo.y;
+                    const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;
                     if (inside) {
                         const float dist_sq = dx * dx + dy * dy;
                         const float limit = fminf(settings.point_size_px, cap);
