@@ -302,7 +302,8 @@ def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int, barri
             return list(values)
         import torch.distributed as dist
         t = torch.tensor(list(values), dtype=torch.float64, device=dev.torch_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        with parallel.collective_stream(dev.torch_device):  # (never on the stream the Trainer records on: parallel.collective_stream)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t.tolist()]
 
     first, first_dev = one_block()
@@ -428,7 +429,8 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
         ones = torch.ones(1, dtype=torch.int32, device=dev.torch_device)
-        dist.all_reduce(ones)
+        with parallel.collective_stream(dev.torch_device):
+            dist.all_reduce(ones)
         n_ranks_seen = int(ones.item())
 
     cfg = synth.CONFIGS[args.config]
@@ -474,7 +476,8 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([exchange_ms], dtype=torch.float64, device=dev.torch_device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        with parallel.collective_stream(dev.torch_device):
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exchange_ms = float(tt[0].item())
 
     # ---- per-kernel durations: the same K steps again, launched eagerly with a hipEvent pair around every kernel on the

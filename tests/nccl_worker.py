@@ -64,10 +64,12 @@ def main():
     capi.destroy()
     parallel.barrier()
     tt = torch.tensor([1.25], dtype=torch.float64, device=dev.torch_device)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    with parallel.collective_stream(dev.torch_device):
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     same = lambda a, b: all(np.array_equal(x, y) for x, y in zip(a, b))  # noqa: E731
     ok = same(plain, via_torch) and same(plain, via_capi) and float(tt.item()) == 1.25
-    dist.barrier()
+    with parallel.collective_stream(dev.torch_device):
+        dist.barrier()
     # deterministic teardown: dataset buffers, the library device (drains the stream), then the process group, then exit
     del data, tt
     dev.destroy()

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         if (ok) {
             const u32 slot = (u32)__popcll(m & lt_mask);
             s_geo[slot] = make_float4(cx, cy, ex, ey);
-            s_con[slot] = make_float4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+            s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -0.5f * wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));  // s = -conic / 2
             s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx_c));
         }
         // A pixel composited the entries at positions below its n_contrib: of this chunk, lanes j < pix_n - lo, i.e. -- the compaction keeps
@@ -203,16 +203,17 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             const f2 d = pxy - f2{geo.x, geo.y};
             // (bitwise, not short-circuit: no branches for the three tests)
             const bool cand = ((int)(i < mine) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
-            // The reference's 2 * conic factors (tiled-backward-rasterize.wgsl:96-99, 141-142) are powers of two: they commute with every
-            // rounding, so they are applied to products instead of being stored per record -- (2 c.y) d.y = 2 (c.y d.y), and further down
-            // (-0.5 G) (2 w) = -(G w).  Same bits (no operand here is small enough for a product to be subnormal: conics are fp16 values).
-            const float cyd = con.y * d.y;
-            const float t1 = __builtin_fmaf(con.x, d.x, cyd + cyd);
-            const float power = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
+            // The reference's factors -0.5 (exponent) and 2 (off-diagonal conic term, dpow: tiled-backward-rasterize.wgsl:96-99, 141-142)
+            // are powers of two: they commute with every rounding of the products and sums they pass through.  The record therefore holds
+            // s = -0.5 * conic, which gives the exponent's argument directly, and the derivative terms further down carry the factor
+            // that is left into the fixed-point scale.  Same bits, no multiplication by 2 or -0.5 per (pixel, splat); no operand here is
+            // small enough for a product to be subnormal (conics are fp16 values).
+            const float syd = con.y * d.y;
+            const float t1 = __builtin_fmaf(con.x, d.x, syd + syd);
             // exp with its range handling hoisted out of the common case (dmath.h wd_exp_inrange): an argument above 87 or a NaN -- an
             // indefinite conic after fp16 rounding -- sends the whole wave through the full form; arguments below -80 are clamped, which
             // only changes G on lanes whose alpha is far below 1/255 either way, and G is not used on those.
-            const float xe = -0.5f * power;
+            const float xe = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);  // -0.5 * power
             float xc;  // max(xe, -80): one v_max_f32 (fmaxf would first quiet a NaN, which the test below sends to the full form)
             asm("v_max_f32 %0, 0xc2a00000, %1" : "=v"(xc) : "v"(xe));  // 0xc2a00000 = -80.0f
             float G = wd_exp_inrange(xc);
@@ -250,10 +251,11 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             ar_b = __builtin_fmaf(alpha_m, col.z, oma * ar_b);
             const float dL_dG = con.w * dL_dalpha;
             const int f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
-            const f2 hpow = f2{__builtin_fmaf(con.x, d.x, cyd), __builtin_fmaf(con.z, d.y, con.y * d.x)};  // half of (dpow/ddx, dpow/ddy)
+            // with q = (fma(s.x, dx, s.y dy), fma(s.z, dy, s.y dx)) = -dpow / 4:  -dG = -(mhG * dpow) = -((-0.5 G) * (-4 q)) = -2 (G q),
+            // and the -2 rides on the scale (-2e6 is exact)
+            const f2 qpow = f2{__builtin_fmaf(con.x, d.x, syd), __builtin_fmaf(con.z, d.y, con.y * d.x)};
             const float mhG = -0.5f * G;
-            const f2 ndG = G * hpow;  // -dG = -(mhG * dpow) = G * (dpow / 2)
-            const f2 fm = (dL_dG * ndG) * FIXED_SCALE;
+            const f2 fm = (dL_dG * (G * qpow)) * (-2.0f * FIXED_SCALE);
             const int f_mx = cvt_fixed(fm.x);
             const int f_my = cvt_fixed(fm.y);
             const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;  // conic.x and conic.z terms

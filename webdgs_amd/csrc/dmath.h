@@ -47,7 +47,14 @@ WD_DEV float wd_exp_inrange(float x) {
     const float LN2_LO = wd_bits2f(0xB95E8083u);
     const float C2 = wd_bits2f(1056964604u), C3 = wd_bits2f(1042983495u), C4 = wd_bits2f(1026207148u),
                 C5 = wd_bits2f(1007230415u), C6 = wd_bits2f(984890875u);
-    const float n = __builtin_rintf(x * LOG2E);
+    // n = rint(x * log2e) by adding and subtracting 1.5 * 2^23: in round-to-nearest-even the sum keeps exactly the integer rint would
+    // return (|x * log2e| < 2^22), and its low mantissa bits are n in two's complement -- so 2^n is applied by adding those bits,
+    // shifted to the exponent field, to p's (one v_lshl_add_u32; everything of the constant is shifted out).  p is in [0.7, 1.42] and n in
+    // [-124, 126]: the result is a normal number and the addition is the exact multiplication.  Three ordinary operations where
+    // v_rndne_f32, v_cvt_i32_f32 and v_ldexp_f32 were (same bits; tests/test_gpu_math.py walks the interval).
+    const float MAGIC = 12582912.0f;
+    const float t = x * LOG2E + MAGIC;
+    const float n = t - MAGIC;
     float r = __builtin_fmaf(-n, LN2_HI, x);
     r = __builtin_fmaf(-n, LN2_LO, r);
     float p = __builtin_fmaf(C6, r, C5);
@@ -56,9 +63,7 @@ WD_DEV float wd_exp_inrange(float x) {
     p = __builtin_fmaf(p, r, C2);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
-    // p * 2^n with n in [-124, 126] and p in [0.7, 1.42]: exact either way, and v_ldexp_f32 is one instruction where building the power
-    // of two and multiplying by it are two
-    return __builtin_ldexpf(p, (int)n);
+    return wd_bits2f(wd_f2bits(p) + (wd_f2bits(t) << 23));
 }
 
 // Two-component float value with component-wise IEEE operations, written out as scalar instructions.  (On gfx950 a wave64 VALU

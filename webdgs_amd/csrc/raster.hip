@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                                                         u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib) {
     // (one record more than a chunk holds: the loop below reads one record ahead)
     __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
-    __shared__ float4 s_con_all[WPW][65];  // conic.x, 2*conic.y, conic.z, opacity
+    __shared__ float4 s_con_all[WPW][65];  // -0.5*conic.x, -conic.y, -0.5*conic.z, opacity (Gaussian mode: see the record build below)
     __shared__ float4 s_col_all[WPW][65];  // r, g, b, position in the tile list + 1 (bits)
 
     // independent waves (no barrier is ever taken): one per 8x8 block
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
             if (ok) {
                 const u32 slot = (u32)__popcll(m & lt_mask);
                 s_geo[slot] = make_float4(cx, cy, ex, ey);
-                s_con[slot] = make_float4(wd_unpack_lo(w23.x), 2.0f * wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+                // the exponent's argument is -0.5 * (c.x dx^2 + 2 c.y dx dy + c.z dy^2) (tiled-rasterizer.wgsl:229-231): the factors -0.5 and 2
+                // are powers of two, which commute with every rounding of the products and sums they pass through, so they are applied to
+                // the conic once per record instead of to the power once per (pixel, splat) -- same bits, one multiplication less
+                s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
                 s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(chunk * 64u + lane + 1u));
             }
             // issue the next chunk's gather and the (key, index) loads of the chunk after it; they land while this chunk composites
@@ -122,19 +125,19 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                     // test cost two VALU operations per iteration; an iteration without one falls through the empty exec mask below)
                     if (active) {
                         const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
-                        const float q = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
-                        // exp with its range handling hoisted out of the common case (dmath.h wd_exp_inrange): an argument above 87 or a
-                        // NaN -- an indefinite conic after fp16 rounding -- sends the wave through the full form.  Below -86, where wd_exp
-                        // returns 0, the argument is clamped instead: alpha is then at most exp(-86) = 4.5e-38 rather than 0, a weight that
-                        // every colour sum and the alpha sum absorb without a trace (the smallest weight that matters is above 1e-10 of
-                        // the sums; alone, it quantises to 0 and leaves T = 1 - A = 1); the 1/255 test for n_contrib is far away.
-                        // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G in [0, inf]), so the hardware min/max equal
-                        // WGSL's select-based clamp, and with a finite G the lower clamp is the identity and is left out.
-                        const float xe = -0.5f * q;
-                        float xc;  // max(xe, -86): one v_max_f32 (fmaxf would first quiet a NaN, which the test below sends to the full form)
-                        asm("v_max_f32 %0, 0xc2ac0000, %1" : "=v"(xc) : "v"(xe));  // 0xc2ac0000 = -86.0f
-                        float alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(xe <= 87.0f)) != 0ull, 0)) alpha = fminf(fmaxf(wd_exp(xe) * con.w, 0.0f), 0.99f);
+                        const float xe = __builtin_fmaf(t1, dx, (con.z * dy) * dy);  // = -0.5 * power (the record holds the scaled conic)
+                        // exp with its range handling taken out (dmath.h wd_exp_inrange) by ONE clamp of the argument to [-86, 87]
+                        // (v_med3_f32), exact where it matters:
+                        //  * above 87 -- an indefinite conic after fp16 rounding -- exp is at least 6e37 either way and alpha = min(.., 0.99) = 0.99;
+                        //  * below -86, where wd_exp returns 0, alpha is at most exp(-86) = 4.5e-38 rather than 0: a weight that every colour
+                        //    sum and the alpha sum absorb without a trace (the smallest weight that matters is above 1e-10 of the sums;
+                        //    alone, it quantises to 0 and leaves T = 1 - A = 1); the 1/255 test for n_contrib is far away;
+                        //  * a NaN argument (an infinite fp16 conic) leaves v_med3_f32 as -86, i.e. as the same vanishing weight, where
+                        //    WGSL's clamp of a NaN alpha would give 0.
+                        // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G finite), so the hardware min equals WGSL's
+                        // select-based clamp, and the lower clamp is the identity and is left out.
+                        const float xc = __builtin_amdgcn_fmed3f(xe, -86.0f, 87.0f);
+                        const float alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
                         const float w = alpha * (1.0f - A);
                         cr = __builtin_fmaf(col.x, w, cr);
                         cg = __builtin_fmaf(col.y, w, cg);

@@ -19,6 +19,7 @@ the all-reduce's 2 (W-1)/W x 60 (105 MB).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Optional, Sequence
 
@@ -46,6 +47,33 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
     return rank, world, local_rank
 
 
+_side_streams: dict = {}
+
+
+@contextlib.contextmanager
+def collective_stream(device=None):
+    """Runs the enclosed ``torch.distributed`` calls of an ``nccl`` (RCCL) group on a side stream of torch's, ordered after the current
+    stream on entry and the current stream after it on exit.  Why: c10d issues a blocking collective on the CURRENT stream, leaves an event
+    there and has its watchdog thread query that event until the collective has finished; HIP refuses the query of an event whose stream is
+    recording a graph (``hipErrorCapturedEvent``: "operation not permitted on an event last recorded in a capturing stream"), and the
+    watchdog answers with ``abort()``.  The current stream is the one the Trainer records its command buffers on, often right after an
+    exchange -- so a collective must not leave its event there.  Without an initialised nccl group (gloo, single process) this is a no-op."""
+    if not (dist.is_initialized() and torch.cuda.is_available() and dist.get_backend() == "nccl"):
+        yield
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(dev)
+    current = torch.cuda.current_stream(dev)
+    side.wait_stream(current)
+    try:
+        with torch.cuda.stream(side):
+            yield
+    finally:
+        current.wait_stream(side)
+
+
 def shard_views(view_ids: Sequence[int], rank: int, world: int) -> list[int]:
     """The views of one global batch that ``rank`` processes: a strided split (views rank, rank+world, ...).
 
@@ -57,20 +85,23 @@ def shard_views(view_ids: Sequence[int], rank: int, world: int) -> list[int]:
 def allreduce_gradients(grad_f32: torch.Tensor, visible_i32: torch.Tensor, group=None) -> None:
     """Sums the ``[N*14]`` fp32 gradient block and the ``[N]`` int32 visibility counts over all ranks, in place."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(grad_f32, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(visible_i32, op=dist.ReduceOp.SUM, group=group)
+        with collective_stream(grad_f32.device if grad_f32.is_cuda else None):
+            dist.all_reduce(grad_f32, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(visible_i32, op=dist.ReduceOp.SUM, group=group)
 
 
 def allreduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
     """Sums integer per-Gaussian counters (densify metric counts) over all ranks, in place."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        with collective_stream(counts.device if counts.is_cuda else None):
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts
 
 
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        with collective_stream():
+            dist.barrier()
 
 
 def shutdown() -> None:
@@ -193,11 +224,13 @@ class TorchExchange(Exchange):
         dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group)
         mine.copy_(out)
 
-    def _pre(self):
+    @contextlib.contextmanager
+    def _section(self):
+        """The collectives of one exchange: host-fenced on gloo, on the side stream on nccl (``collective_stream``)."""
         if self.fenced:
             self.device.torch_stream.synchronize()
-
-    def _post(self):
+        with collective_stream(self.device.torch_device):
+            yield
         if self.fenced:
             torch.cuda.synchronize(self.device.torch_device)
 
@@ -208,15 +241,14 @@ class TorchExchange(Exchange):
         g = self._t(grad_ptr, w * slice_pts * GRAD_FLOATS, torch.float32)
         v = self._t(visible_ptr, w * slice_pts, torch.int32)
         f = self._t(flag_ptr, 1, torch.int32)
-        self._pre()
-        if self.backend == "nccl":
-            self._reduce_scatter(g, slice_pts * GRAD_FLOATS)
-            self._reduce_scatter(v, slice_pts)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group)
-        self._post()
+        with self._section():
+            if self.backend == "nccl":
+                self._reduce_scatter(g, slice_pts * GRAD_FLOATS)
+                self._reduce_scatter(v, slice_pts)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group)
 
     def allgather_rows(self, rows_ptr, slice_pts):
         if self._idle():
@@ -224,36 +256,34 @@ class TorchExchange(Exchange):
         w, r = self.world_size, self.rank
         t = self._t(rows_ptr, w * slice_pts * 8, torch.int32)
         mine = t[r * slice_pts * 8:(r + 1) * slice_pts * 8]
-        self._pre()
-        if self.backend == "nccl":
-            if self._in_place:
-                try:
-                    dist.all_gather_into_tensor(t, mine, group=self.group)
-                except RuntimeError as e:
-                    self._out_of_place(e)
-            if not self._in_place:
-                dist.all_gather_into_tensor(t, mine.clone(), group=self.group)
-        else:
-            dist.all_gather([t[i * slice_pts * 8:(i + 1) * slice_pts * 8] for i in range(w)], mine.clone(), group=self.group)
-        self._post()
+        with self._section():
+            if self.backend == "nccl":
+                if self._in_place:
+                    try:
+                        dist.all_gather_into_tensor(t, mine, group=self.group)
+                    except RuntimeError as e:
+                        self._out_of_place(e)
+                if not self._in_place:
+                    dist.all_gather_into_tensor(t, mine.clone(), group=self.group)
+            else:
+                dist.all_gather([t[i * slice_pts * 8:(i + 1) * slice_pts * 8] for i in range(w)], mine.clone(), group=self.group)
 
     def broadcast(self, ptr, nbytes, root):
         if self._idle() or nbytes == 0:
             return
-        self._pre()
-        dist.broadcast(self._t(ptr, nbytes, torch.uint8), src=root, group=self.group)
-        self._post()
+        with self._section():
+            dist.broadcast(self._t(ptr, nbytes, torch.uint8), src=root, group=self.group)
 
     def allreduce_counts(self, ptr, count):
         if self._idle() or count == 0:
             return
-        self._pre()
-        dist.all_reduce(self._t(ptr, count, torch.int32), op=dist.ReduceOp.SUM, group=self.group)
-        self._post()
+        with self._section():
+            dist.all_reduce(self._t(ptr, count, torch.int32), op=dist.ReduceOp.SUM, group=self.group)
 
     def barrier(self):
         if self.world_size > 1:
-            dist.barrier(group=self.group)
+            with collective_stream(self.device.torch_device):
+                dist.barrier(group=self.group)
 
 
 class CapiExchange(Exchange):
@@ -286,7 +316,8 @@ class CapiExchange(Exchange):
 
     def barrier(self):
         if dist.is_initialized() and dist.get_world_size(self._group) > 1:
-            dist.barrier(group=self._group)
+            with collective_stream(self.device.torch_device):
+                dist.barrier(group=self._group)
 
     def destroy(self):
         self.comm.destroy()
@@ -334,7 +365,8 @@ class Communicator:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         box = [cls.uniqueId() if rank == 0 else None]
         if world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
+            with collective_stream(device.torch_device):
+                dist.broadcast_object_list(box, src=0, group=group)
         return cls(device, box[0], world, rank)
 
     def allreduceGradients(self, gradF32, visibleCounts, numPoints: int) -> None:
