@@ -386,10 +386,15 @@ def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, 
         if raster_ms > 0:
             roof["flop_frac_fwd_plus_bwd"] = round((f_fwd + f_bwd) / (raster_ms / 1e3) / 157.3e12, 4)
         peak_issue = 1024 * 2.4e9 / 2.0  # wave-instructions per second the chip can issue
+        # What a stream of independent or dependent v_fma_f32 really sustains at this kernel's occupancy (scripts/microbench/valu_issue.hip,
+        # profiles/r03s_valu_issue_w7.txt: 1022 G/s -- the clock the chip holds under a full vector load is below 2.4 GHz); conversions,
+        # compares, selects and DPP steps cost the same in a mix, v_rcp_f32 and v_permlane*_swap about five times as much.
+        attainable = 1022.0e9
         insts = pk[dom].get("SQ_INSTS_VALU") if pk is not None and dom in pk else None
-        roof.update(bound="valu_issue", unit="G wave-instr/s", peak=round(peak_issue / 1e9, 1))
+        roof.update(bound="valu_issue", unit="G wave-instr/s", peak=round(peak_issue / 1e9, 1), attainable_measured=round(attainable / 1e9, 1))
         if insts:
-            roof.update(achieved=round(insts / dur_s / 1e9, 1), frac=round(insts / dur_s / peak_issue, 4), valu_insts_per_launch=round(insts))
+            roof.update(achieved=round(insts / dur_s / 1e9, 1), frac=round(insts / dur_s / peak_issue, 4), frac_of_attainable=round(insts / dur_s / attainable, 4),
+                        valu_insts_per_launch=round(insts))
         else:
             roof.update(achieved=None, frac=None, note="VALU instruction count needs a PMC profile of this kernel version (scripts/pmc.sh); hbm_frac and flop_frac are live")
     return roof
