@@ -383,6 +383,8 @@ def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, 
         f_fwd, f_bwd = 256.0 * e * 23.0, 256.0 * e * 12.0 + pairs * 60.0   # SURVEY 8(d) "Algorithmic flops (raster)"
         flops = f_fwd if dom == "rasterize" else f_bwd
         roof["flop_frac"] = round(flops / dur_s / 157.3e12, 4) if dur_s > 0 else None
+        roof["flop_frac_note"] = ("SURVEY 8(d)'s count charges every (pixel, entry) pair of the reference's loops; the kernels skip most of them (block culling, "
+                                  "saturation), so this says how much work is avoided -- it can exceed 1 -- not how busy the pipes are: that is `frac`")
         if raster_ms > 0:
             roof["flop_frac_fwd_plus_bwd"] = round((f_fwd + f_bwd) / (raster_ms / 1e3) / 157.3e12, 4)
         peak_issue = 1024 * 2.4e9 / 2.0  # wave-instructions per second the chip can issue
