@@ -25,29 +25,31 @@ WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
     return g;
 }
 
-// Compact training copy "cs": float[N][CS_STRIDE], one 112-byte row per Gaussian holding what the reference spreads over three arrays with
-// padding or long strides -- position {param, m, v} (OptVec4: a fourth, unused lane each), log-scale {param, m, v} (same), SH-DC {param, m,
-// v} (192- / 384-byte strides in paramSH / stateSH):
+// Compact training copy "cs": what the reference spreads over three arrays with padding or long strides -- position {param, m, v} (OptVec4:
+// a fourth, unused lane each), log-scale {param, m, v} (same), SH-DC {param, m, v} (192- / 384-byte strides in paramSH / stateSH) -- as 27
+// floats per Gaussian in SEVEN PLANES of float4: plane k holds quad k of every Gaussian, planes[k * pitch + idx], so that the 64 lanes of a
+// wave read 1 KB of consecutive bytes per plane.  (As one 112-byte row per Gaussian -- round 3's first form -- every load instruction
+// touched 7 KB for 1 KB of data: scripts/microbench/hbm_stream.hip measures 4.5-4.7 TB/s for that shape against 6.1 for consecutive
+// 16-byte elements, profiles/r04j_hbm_stream.txt.)  The quads of a Gaussian, in plane order:
 //   [0-2] pos p  [3-5] pos m  [6-8] pos v  [9-11] scale p  [12-14] scale m  [15-17] scale v  [18-20] dc p  [21-23] dc m  [24-26] dc v  [27] pad
 // The reference-layout arrays are brought up to date at every hand-over (cs_flush: get_state / release_state / destroy) and loaded when
 // state is adopted, unpacked or rewritten from outside (cs_load).  Rotation (no padding) and opacity stay where they are.
-constexpr u32 CS_STRIDE = 28;
+// (CsView: common.h)
 
 // Adam on one Gaussian's 14 trained scalars (SH: DC only) followed by the fp16 re-pack of that Gaussian.
 // rows_out (nullable): the re-packed row -- 6 Gaussian words, SH word 0, low half of SH word 1 -- also goes to rows_out[idx*8 ..],
 // the 32-byte form in which a data-parallel rank publishes the Gaussians it owns (wdgs_comm_allgather_rows).
 WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_rot,
-                            float* __restrict__ opt_opacity, float* __restrict__ cs, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer,
+                            float* __restrict__ opt_opacity, const CsView cs, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer,
                             u32* __restrict__ rows_out = nullptr, u32* __restrict__ dc_words = nullptr) {
-    float4* row = reinterpret_cast<float4*>(cs + (size_t)idx * CS_STRIDE);
-    const float4 q0 = row[0], q2 = row[2], q4 = row[4], q5 = row[5];
+    const float4 q0 = cs.quad(0, idx), q2 = cs.quad(2, idx), q4 = cs.quad(4, idx), q5 = cs.quad(5, idx);
     float4 R = opt_rot[(size_t)idx * 3];
     float op = opt_opacity[(size_t)idx * 3];
     float Px = q0.x, Py = q0.y, Pz = q0.z;          // position
     float Sx = q2.y, Sy = q2.z, Sz = q2.w;          // log-scale
     float c0 = q4.z, c1 = q4.w, c2 = q5.x;          // SH DC
     if (update) {
-        const float4 q1 = row[1], q3 = row[3], q6 = row[6];
+        const float4 q1 = cs.quad(1, idx), q3 = cs.quad(3, idx), q6 = cs.quad(6, idx);
         const Adam3 px = adam_step(h, Px, g.pos[0], q0.w, q1.z, h.lr_pos), py = adam_step(h, Py, g.pos[1], q1.x, q1.w, h.lr_pos),
                     pz = adam_step(h, Pz, g.pos[2], q1.y, q2.x, h.lr_pos);
         Px = px.p; Py = py.p; Pz = pz.p;
@@ -74,13 +76,13 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
         const Adam3 r0 = adam_step(h, c0, g.color[0], q5.y, q6.x, h.lr_color), r1 = adam_step(h, c1, g.color[1], q5.z, q6.y, h.lr_color),
                     r2 = adam_step(h, c2, g.color[2], q5.w, q6.z, h.lr_color);
         c0 = r0.p; c1 = r1.p; c2 = r2.p;
-        row[0] = make_float4(px.p, py.p, pz.p, px.m);
-        row[1] = make_float4(py.m, pz.m, px.v, py.v);
-        row[2] = make_float4(pz.v, sx.p, sy.p, sz.p);
-        row[3] = make_float4(sx.m, sy.m, sz.m, sx.v);
-        row[4] = make_float4(sy.v, sz.v, r0.p, r1.p);
-        row[5] = make_float4(r2.p, r0.m, r1.m, r2.m);
-        row[6] = make_float4(r0.v, r1.v, r2.v, 0.0f);
+        cs.quad(0, idx) = make_float4(px.p, py.p, pz.p, px.m);
+        cs.quad(1, idx) = make_float4(py.m, pz.m, px.v, py.v);
+        cs.quad(2, idx) = make_float4(pz.v, sx.p, sy.p, sz.p);
+        cs.quad(3, idx) = make_float4(sx.m, sy.m, sz.m, sx.v);
+        cs.quad(4, idx) = make_float4(sy.v, sz.v, r0.p, r1.p);
+        cs.quad(5, idx) = make_float4(r2.p, r0.m, r1.m, r2.m);
+        cs.quad(6, idx) = make_float4(r0.v, r1.v, r2.v, 0.0f);
     }
     struct { float x, y, z; } P = {Px, Py, Pz}, S = {Sx, Sy, Sz};
     // re-pack (update-gaussians.wgsl:41-75): whole Gaussian, SH word 0, low half of SH word 1

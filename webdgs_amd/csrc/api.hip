@@ -29,19 +29,19 @@ int launch_project_count_views(wdgs_device*, u32, u32, const void*, const void*,
                                void* const*, void* const*, void* const*, void* const*, const void*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*);
 int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
-                                  const wdgs_optimizer_state&, void*, void*, const void*, void*);
+                                  const wdgs_optimizer_state&, const CsView&, void*, const void*, void*);
 int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*, void*, void*, void*, const void*, void*,
                                         const void*, u32);
-int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*, void*,
+int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, const CsView&, void*, void*,
                        const void*, void*);
-int launch_adam_repack_f32(wdgs_device*, u32, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, void*, void*,
+int launch_adam_repack_f32(wdgs_device*, u32, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, const CsView&, void*,
                            void*, const void*, void*, void*, void*);
 int launch_apply_rows(wdgs_device*, u32, const void*, u32, u32, const void*, void*, void*, void*, void*);
 int launch_dc_words_load(wdgs_device*, u32, const void*, void*);
 int launch_dc_words_flush(wdgs_device*, u32, const void*, void*);
 int launch_guard_accumulate(wdgs_device*, void*, const void*, u32);
-int launch_cs_load(wdgs_device*, u32, const wdgs_optimizer_state&, void*);
-int launch_cs_flush(wdgs_device*, u32, const void*, const wdgs_optimizer_state&);
+int launch_cs_load(wdgs_device*, u32, const wdgs_optimizer_state&, const CsView&);
+int launch_cs_flush(wdgs_device*, u32, const CsView&, const wdgs_optimizer_state&);
 int launch_accumulate_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
 int launch_store_gradients(wdgs_device*, u32, const void*, const void*, void*, void*);
 int launch_unpack(wdgs_device*, u32, const void*, const void*, const wdgs_optimizer_state&);
@@ -167,7 +167,9 @@ struct wdgs_optimizer {
     wdgs_optimizer_state state;
     bool owns_state;
     u32 iteration;
-    float* dc;        // compact training copy float[N][28]: position, log-scale and SH-DC {param, m, v} (adam.h CS_STRIDE; optimizer.hip "HBM layout note"); always owned
+    float* dc;        // compact training copy, float4[7][max(N, 1)] planes: position, log-scale and SH-DC {param, m, v} (adam.h; optimizer.hip "HBM layout note"); always owned
+    static u32 cs_pitch(u32 n) { return (std::max(n, 1u) + 15u) & ~15u; }  // planes start on 256-byte boundaries
+    CsView cs() const { return CsView{reinterpret_cast<float4*>(dc), cs_pitch(num_points)}; }
     bool dc_dirty;    // it is ahead of state.opt_pos / opt_scale / param_sh / state_sh
     const void* guard;  // device word: non-zero at execution time turns step / step_f32 into a no-op (wdgs_optimizer_set_guard)
     // Deferred SH writes (wdgs_optimizer_set_deferred_sh): the steps write the trained DC halves to dc_words (u32[N][2]) instead of the
@@ -180,7 +182,7 @@ struct wdgs_optimizer {
 // Brings the reference-layout arrays (position, log-scale, SH) up to date with the compact training copy (no-op when nothing was trained since).
 static int optimizer_flush_dc(wdgs_optimizer* op) {
     if (!op->dc_dirty) return WDGS_OK;
-    WDGS_TRY(launch_cs_flush(op->dev, op->num_points, op->dc, op->state));
+    WDGS_TRY(launch_cs_flush(op->dev, op->num_points, op->cs(), op->state));
     op->dc_dirty = false;
     return WDGS_OK;
 }
@@ -1183,8 +1185,8 @@ int wdgs_optimizer_create(wdgs_device* d, uint32_t n, const wdgs_adam_hyperparam
         if (r != WDGS_OK) { optimizer_free_state(op); delete op; return r; }
         op->iteration = 0;
     }
-    int r = wdgs_alloc((void**)&op->dc, sizeof(float) * 28 * (size_t)std::max(n, 1u), true, d->stream);
-    if (r == WDGS_OK) r = launch_cs_load(d, n, op->state, op->dc);
+    int r = wdgs_alloc((void**)&op->dc, sizeof(float4) * CS_PLANES * (size_t)wdgs_optimizer::cs_pitch(n), true, d->stream);
+    if (r == WDGS_OK) r = launch_cs_load(d, n, op->state, op->cs());
     if (r != WDGS_OK) { free_dev(op->dc); if (op->owns_state) optimizer_free_state(op); delete op; return r; }
     op->dc_dirty = false;
     *out = op;
@@ -1205,14 +1207,14 @@ int wdgs_optimizer_init_from_point_cloud(wdgs_optimizer* op, const void* gaussia
     WDGS_REQUIRE(op && gaussians && sh, WDGS_E_INVALID, "wdgs_optimizer_init_from_point_cloud: null argument");
     WDGS_TRY(launch_unpack(op->dev, op->num_points, gaussians, sh, op->state));
     op->dc_dirty = false;
-    return launch_cs_load(op->dev, op->num_points, op->state, op->dc);
+    return launch_cs_load(op->dev, op->num_points, op->state, op->cs());
 }
 int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians, void* sh, const void* gradients, const void* tile_counts) {
     WDGS_REQUIRE(op && gaussians && sh && gradients && tile_counts, WDGS_E_INVALID, "wdgs_optimizer_step: null argument");
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
     if (op->deferred_sh) op->sh_stale = true;
-    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->dc, gaussians, sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
+    return launch_adam_repack(op->dev, op->num_points, op->params, tile_counts, gradients, op->state, op->cs(), gaussians, sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
 }
 // K17 + K18 + K19 in one pass over the Gaussians (the single-view step): `bwd` must have run wdgs_tiled_backward_encode_raster for this view.
 int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera, void* gaussians, void* sh, const void* tile_counts) {
@@ -1223,14 +1225,14 @@ int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* b
     op->dc_dirty = true;
     if (op->deferred_sh) op->sh_stale = true;
     return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradients, op->params, tile_counts, op->state,
-                                         op->dc, sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
+                                         op->cs(), sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");
     op->iteration++;
     op->dc_dirty = true;
     if (op->deferred_sh) op->sh_stale = true;
-    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, nullptr,
+    return launch_adam_repack_f32(op->dev, 0, op->num_points, op->params, visible, grad_f32, op->state, op->cs(), gaussians, sh, op->guard, op->dev->host_guard, nullptr,
                                   op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible, uint32_t first, uint32_t count,
@@ -1241,7 +1243,7 @@ int wdgs_optimizer_step_f32_range(wdgs_optimizer* op, void* gaussians, void* sh,
     op->iteration++;
     op->dc_dirty = true;
     if (op->deferred_sh) op->sh_stale = true;
-    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->dc, gaussians, sh, op->guard, op->dev->host_guard, rows_out,
+    return launch_adam_repack_f32(op->dev, first, count, op->params, visible, grad_f32, op->state, op->cs(), gaussians, sh, op->guard, op->dev->host_guard, rows_out,
                                   op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag) {
@@ -1252,7 +1254,7 @@ int wdgs_optimizer_set_guard(wdgs_optimizer* op, const void* flag) {
 int wdgs_optimizer_state_changed(wdgs_optimizer* op) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
     op->dc_dirty = false;
-    return launch_cs_load(op->dev, op->num_points, op->state, op->dc);
+    return launch_cs_load(op->dev, op->num_points, op->state, op->cs());
 }
 int wdgs_apply_repacked_rows(wdgs_device* d, uint32_t n, const void* rows, uint32_t skip_first, uint32_t skip_count, const void* guard, void* gaussians,
                              void* sh) {

@@ -33,7 +33,7 @@ struct ViewAdam {
     const u32* tile_counts;
     float4* opt_rot;
     float* opt_opacity;
-    float* cs;       // compact training copy (adam.h)
+    CsView cs;       // compact training copy (adam.h)
     u32* gaussians;  // the same buffer K17 reads: this thread's own 24-byte row, read above, re-packed below
     u32* sh;
     const u32* guard;
@@ -315,12 +315,12 @@ __global__ __launch_bounds__(256, 3) void geometry_backward_views_kernel(u32 n, 
 }  // namespace
 
 int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, void* acc, void* acc_dirty, void* gradients,
-                                  const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, void* cs, void* sh,
+                                  const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, const CsView& cs, void* sh,
                                   const void* guard, void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "geometry_backward_adam", geometry_backward_kernel<2>, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st,
                 (const u32*)gaussians, (int*)acc, (u32*)acc_dirty, (u32*)gradients, ViewAccumulate{},
-                (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_rot, (float*)state.opt_opacity, (float*)cs, (u32*)gaussians, (u32*)sh, (const u32*)guard,
+                (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_rot, (float*)state.opt_opacity, cs, (u32*)gaussians, (u32*)sh, (const u32*)guard,
                           (u32*)dc_words}));
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;

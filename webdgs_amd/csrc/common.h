@@ -104,6 +104,14 @@ struct KernelScope {
         hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (dev)->stream, __VA_ARGS__);  \
     } while (0)
 
+// The optimizer's compact training copy (adam.h): seven planes of float4, planes[k * pitch + idx].
+constexpr u32 CS_PLANES = 7;
+struct CsView {
+    float4* planes;
+    u32 pitch;  // Gaussians per plane
+    __device__ __forceinline__ float4& quad(u32 k, u32 idx) const { return planes[(size_t)k * pitch + idx]; }
+};
+
 // Workgroup number for launch slot b of a grid of g.  Slots b, b + 8, b + 16, ... are observed to run on one XCD (round-robin dispatch
 // over the chip's 8 XCDs); this numbering gives XCD k the CONTIGUOUS range of workgroups [start_k, start_k + count_k), so that
 // workgroups writing neighbouring addresses meet in one L2.  A bijection of [0, g) for every g; a speed choice only.

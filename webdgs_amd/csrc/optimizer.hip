@@ -23,7 +23,7 @@ namespace {
 // overflow word (its tile-entry list was truncated: gradients are incomplete), so a step that is going to be reported as
 // WDGS_E_CAPACITY does not first corrupt the optimizer state.
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
-                                                           const u32* __restrict__ gradients, float4* opt_rot, float* opt_opacity, float* cs, u32* gaussians,
+                                                           const u32* __restrict__ gradients, float4* opt_rot, float* opt_opacity, CsView cs, u32* gaussians,
                                                            u32* sh_buffer, const u32* __restrict__ guard, u32* dc_words) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyper
 
 // Gaussians [first, first + count): the slice a data-parallel rank owns (first = 0, count = n on a single GPU).
 __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 count, wdgs_adam_hyperparameters h, const u32* __restrict__ visible,
-                                                               const float* __restrict__ grad_f32, float4* opt_rot, float* opt_opacity, float* cs,
+                                                               const float* __restrict__ grad_f32, float4* opt_rot, float* opt_opacity, CsView cs,
                                                                u32* gaussians, u32* sh_buffer,
                                                                const u32* __restrict__ guard, u32* __restrict__ guard_seen_host, u32* __restrict__ rows_out,
                                                                u32* dc_words) {
@@ -105,9 +105,9 @@ __global__ void guard_accumulate_kernel(u32* __restrict__ flag, const u32* __res
     *flag = prev | (*src != 0u ? 1u : 0u);
 }
 
-// reference layout -> compact training copy (adam.h: CS_STRIDE)
+// reference layout -> compact training copy (adam.h: CsView)
 __global__ __launch_bounds__(256) void cs_load_kernel(u32 n, const float4* __restrict__ opt_pos, const float4* __restrict__ opt_scale, const float* __restrict__ param_sh,
-                                                       const float2* __restrict__ state_sh, float* __restrict__ cs) {
+                                                       const float2* __restrict__ state_sh, CsView cs) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const float4 pp = opt_pos[(size_t)idx * 3], pm = opt_pos[(size_t)idx * 3 + 1], pv = opt_pos[(size_t)idx * 3 + 2];
@@ -120,24 +120,22 @@ __global__ __launch_bounds__(256) void cs_load_kernel(u32 n, const float4* __res
         cm[c] = mv.x;
         cv[c] = mv.y;
     }
-    float4* row = reinterpret_cast<float4*>(cs + (size_t)idx * CS_STRIDE);
-    row[0] = make_float4(pp.x, pp.y, pp.z, pm.x);
-    row[1] = make_float4(pm.y, pm.z, pv.x, pv.y);
-    row[2] = make_float4(pv.z, sp.x, sp.y, sp.z);
-    row[3] = make_float4(sm.x, sm.y, sm.z, sv.x);
-    row[4] = make_float4(sv.y, sv.z, cp[0], cp[1]);
-    row[5] = make_float4(cp[2], cm[0], cm[1], cm[2]);
-    row[6] = make_float4(cv[0], cv[1], cv[2], 0.0f);
+    cs.quad(0, idx) = make_float4(pp.x, pp.y, pp.z, pm.x);
+    cs.quad(1, idx) = make_float4(pm.y, pm.z, pv.x, pv.y);
+    cs.quad(2, idx) = make_float4(pv.z, sp.x, sp.y, sp.z);
+    cs.quad(3, idx) = make_float4(sm.x, sm.y, sm.z, sv.x);
+    cs.quad(4, idx) = make_float4(sv.y, sv.z, cp[0], cp[1]);
+    cs.quad(5, idx) = make_float4(cp[2], cm[0], cm[1], cm[2]);
+    cs.quad(6, idx) = make_float4(cv[0], cv[1], cv[2], 0.0f);
 }
 
 // compact training copy -> reference layout.  The fourth lanes get the constants the reference's Adam writes (adam.wgsl:108, 142: position
 // w = 1, scale w = 0, their moments 0) -- which is also what unpack and the densify scatter leave in Gaussians that were never updated.
-__global__ __launch_bounds__(256) void cs_flush_kernel(u32 n, const float* __restrict__ cs, float4* __restrict__ opt_pos, float4* __restrict__ opt_scale,
+__global__ __launch_bounds__(256) void cs_flush_kernel(u32 n, const CsView cs, float4* __restrict__ opt_pos, float4* __restrict__ opt_scale,
                                                         float* __restrict__ param_sh, float2* __restrict__ state_sh) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const float4* row = reinterpret_cast<const float4*>(cs + (size_t)idx * CS_STRIDE);
-    const float4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6];
+    const float4 q0 = cs.quad(0, idx), q1 = cs.quad(1, idx), q2 = cs.quad(2, idx), q3 = cs.quad(3, idx), q4 = cs.quad(4, idx), q5 = cs.quad(5, idx), q6 = cs.quad(6, idx);
     opt_pos[(size_t)idx * 3] = make_float4(q0.x, q0.y, q0.z, 1.0f);
     opt_pos[(size_t)idx * 3 + 1] = make_float4(q0.w, q1.x, q1.y, 0.0f);
     opt_pos[(size_t)idx * 3 + 2] = make_float4(q1.z, q1.w, q2.x, 0.0f);
@@ -209,20 +207,20 @@ __global__ __launch_bounds__(256) void unpack_kernel(u32 n, const u32* __restric
 }  // namespace
 
 int launch_adam_repack(wdgs_device* dev, u32 n, const wdgs_adam_hyperparameters& h, const void* tile_counts, const void* gradients,
-                       const wdgs_optimizer_state& st, void* cs, void* gaussians, void* sh, const void* guard, void* dc_words) {
+                       const wdgs_optimizer_state& st, const CsView& cs, void* gaussians, void* sh, const void* guard, void* dc_words) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack", adam_repack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, h, (const u32*)tile_counts, (const u32*)gradients,
-                (float4*)st.opt_rot, (float*)st.opt_opacity, (float*)cs, (u32*)gaussians, (u32*)sh, (const u32*)guard, (u32*)dc_words);
+                (float4*)st.opt_rot, (float*)st.opt_opacity, cs, (u32*)gaussians, (u32*)sh, (const u32*)guard, (u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
 int launch_adam_repack_f32(wdgs_device* dev, u32 first, u32 count, const wdgs_adam_hyperparameters& h, const void* visible, const void* grad_f32,
-                           const wdgs_optimizer_state& st, void* cs, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out,
+                           const wdgs_optimizer_state& st, const CsView& cs, void* gaussians, void* sh, const void* guard, void* guard_seen_host, void* rows_out,
                            void* dc_words) {
     if (count == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "adam_repack_f32", adam_repack_f32_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, first, count, h, (const u32*)visible,
-                (const float*)grad_f32, (float4*)st.opt_rot, (float*)st.opt_opacity, (float*)cs, (u32*)gaussians,
+                (const float*)grad_f32, (float4*)st.opt_rot, (float*)st.opt_opacity, cs, (u32*)gaussians,
                 (u32*)sh, (const u32*)guard, (u32*)guard_seen_host, (u32*)rows_out, (u32*)dc_words);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
@@ -257,17 +255,17 @@ int launch_guard_accumulate(wdgs_device* dev, void* flag, const void* src, u32 o
     return WDGS_OK;
 }
 
-int launch_cs_load(wdgs_device* dev, u32 n, const wdgs_optimizer_state& st, void* cs) {
+int launch_cs_load(wdgs_device* dev, u32 n, const wdgs_optimizer_state& st, const CsView& cs) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "optimizer_cs_load", cs_load_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float4*)st.opt_pos, (const float4*)st.opt_scale,
-                (const float*)st.param_sh, (const float2*)st.state_sh, (float*)cs);
+                (const float*)st.param_sh, (const float2*)st.state_sh, cs);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
-int launch_cs_flush(wdgs_device* dev, u32 n, const void* cs, const wdgs_optimizer_state& st) {
+int launch_cs_flush(wdgs_device* dev, u32 n, const CsView& cs, const wdgs_optimizer_state& st) {
     if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "optimizer_cs_flush", cs_flush_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)cs, (float4*)st.opt_pos, (float4*)st.opt_scale,
+    WDGS_LAUNCH(dev, "optimizer_cs_flush", cs_flush_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, cs, (float4*)st.opt_pos, (float4*)st.opt_scale,
                 (float*)st.param_sh, (float2*)st.state_sh);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
