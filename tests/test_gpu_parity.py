@@ -88,3 +88,17 @@ def test_train_step_bit_exact(orc, hip_device, base, kw):
         assert pipe.opt.getIteration() == 2
     finally:
         pipe.destroy()
+
+
+@pytest.mark.parametrize("env", [dict(WDGS_BWR_SUMS="butterfly"), dict(WDGS_BWR_WPW="4", WDGS_RASTER_WPW="1")], ids=["register-butterfly", "other-workgroup-shapes"])
+def test_alternative_kernel_forms_stay_bit_exact(env):
+    """The forms kept for same-box A/B measurements -- backward_rasterize's register-only reduction (round 2) and the other
+    waves-per-workgroup shapes of the two rasterization kernels -- are selected by environment variables that the library reads once per
+    process: the train-step parity case runs again in a child process under each."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", "test_train_step_bit_exact and c1"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -346,10 +346,8 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
     static const bool one_wave = !(std::getenv("WDGS_BWR_WPW") && std::getenv("WDGS_BWR_WPW")[0] == '4');
     // WDGS_BWR_SUMS=butterfly: round 2's register-only reduction (same-box A/B; the LDS form is 6 KB of LDS per wave instead of 4)
     static const bool lds_sums = !(std::getenv("WDGS_BWR_SUMS") && std::getenv("WDGS_BWR_SUMS")[0] == 'b');
-    // WDGS_BWR_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup -- an occupancy experiment (how much does the kernel lose per resident wave less?)
-    static const u32 extra_lds = std::getenv("WDGS_BWR_EXTRA_LDS") ? (u32)std::atoi(std::getenv("WDGS_BWR_EXTRA_LDS")) : 0u;
 #define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
-    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), extra_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
+    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), 0, st, num_tiles_x, tiles, (const u32*)ranges, \
                 (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
