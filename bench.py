@@ -58,8 +58,6 @@ def algorithmic_bytes(kernel: str, n: int, v: int, e: int, p: int, t: int, k_coe
         "adam_repack": 4 * n + 416 * v + 100 * n,
         # K17 + K18 + K19 in one pass (single-view step): the packed gradient is written (32 N) but not read back
         "geometry_backward_adam": 96 * n + 4 * n + 416 * v + 100 * n - 32 * n,
-        # ... and K1 of the next view by the same thread (project-ahead): K1's bytes without its 24 N read of the Gaussian
-        "geometry_backward_adam_project": (96 * n + 4 * n + 416 * v + 100 * n - 32 * n) + (n * (24 + 6 * k_coef) + 28 * v + 4 * n) - 24 * n,
     }
     return float(table.get(kernel, 0))
 
@@ -255,7 +253,7 @@ class TrainingSnapshot:
         bufs.update(gaussians=pc.gaussian_3d_buffer, sh=pc.sh_buffer)
         self.views = {k: parallel._tensor_at(dev, b.ptr, b.size, __import__("torch").uint8) for k, b in bufs.items() if b.size > 0}
         self.copies = {k: v.clone() for k, v in self.views.items()}
-        self.iteration, self.rng, self.ahead_view = trainer.iteration, trainer._rng.getstate(), trainer._ahead_view
+        self.iteration, self.rng = trainer.iteration, trainer._rng.getstate()
         self.opt_iteration = trainer.optimizer.getIteration()
 
     def restore(self) -> None:
@@ -270,7 +268,6 @@ class TrainingSnapshot:
         t.optimizer.advanceIteration((self.opt_iteration - t.optimizer.getIteration()) & 0xFFFFFFFF)
         t.iteration = self.iteration
         t._rng.setstate(self.rng)
-        t._ahead_view, t._projected_view = self.ahead_view, None  # (the view drawn ahead is part of the sequence; its projection belonged to the overwritten cloud)
 
 
 def timed_blocks(trainer, dev, steps: int, min_seconds: float, world: int, barrier=None):
@@ -526,7 +523,7 @@ def main() -> None:
         gl, gms = groups.get(gname, (0, 0.0))
         groups[gname] = (gl + launches, gms + ms)
     per_view_kernels = ("project_count", "scan", "emit", "sort", "tile_ranges", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward", "geometry_backward_adam",
-                        "geometry_backward_adam_project", "store_gradients", "accumulate_gradients", "guard_accumulate", "acc_clear")
+                        "store_gradients", "accumulate_gradients", "guard_accumulate", "acc_clear")
     per_step = {k: v[1] / max(1, args.steps) / (vpr if k in per_view_kernels else 1) for k, v in groups.items()}
     dom = max(per_step, key=per_step.get) if per_step else None
     roofline = None

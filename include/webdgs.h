@@ -340,12 +340,6 @@ int wdgs_optimizer_step(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, c
  * the fp16-rounded values in registers -- optimizer.step() of trainer.ts:635 without a second pass over N and a read-back of the gradient. */
 int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera_dev, void* gaussians_dev, void* sh_dev,
                                       const void* tile_counts_dev);
-/* ... and, for a host that already knows the view of its NEXT step (trainer.ts:573 draws it at the start of the step; drawing it one step
- * earlier consumes the same random sequence): the thread that has re-packed a Gaussian also projects it under `next_camera_dev` into
- * `next`'s buffers -- K1 of the next forward pass (tiled-forward.wgsl:161-294), which then starts at its scan:
- * wdgs_tiled_forward_encode_projected(next).  `next` may be the pass whose tile counts `tile_counts_dev` are (one pass serving every view). */
-int wdgs_optimizer_step_with_geometry_project(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera_dev, void* gaussians_dev, void* sh_dev,
-                                              const void* tile_counts_dev, wdgs_tiled_forward* next, const void* next_camera_dev);
 /* Data-parallel variant: gradients are fp32 sums over views, 14 f32 per Gaussian in GaussianGradient
  * component order {pos3, opacity, rot4, logsigma3, rgb3}, plus u32 visibility counts (Adam runs where count > 0). */
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians_dev, void* sh_dev, const void* grad_f32_dev, const void* visible_counts_dev);
@@ -391,9 +385,6 @@ int wdgs_tiled_forward_set_dc_source(wdgs_tiled_forward* op, const void* dc_word
  * wdgs_tiled_forward_encode_projected, on any lane, recorded or not.  Results are those of wdgs_tiled_forward_encode per view, bit for bit. */
 int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void* const* cameras_dev, uint32_t count, const void* gaussians_dev, const void* sh_dev);
 int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op);
-/* 1 while the pass holds a projection that wdgs_tiled_forward_encode_projected has not consumed yet and no wdgs_tiled_forward_encode has
- * overwritten (the scan works in place on K1's workgroup sums: the rest of the pass can run once per projection). */
-int wdgs_tiled_forward_is_projected(const wdgs_tiled_forward* op);
 /* ... and K17 of all V views in one launch: per view the accumulators of `ops[v]` (wdgs_tiled_backward_encode_raster ran for it) are turned
  * into the view's fp16 gradient under `cameras_dev[v]` and summed, in view order, into the step's fp32 block `sums_f32_dev` [N][14] with the
  * visibility counts `visible_dev` [N] and the guard word (OR of the views' overflow words `overflow_words_dev[v]`) -- what V calls of

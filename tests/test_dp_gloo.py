@@ -61,18 +61,6 @@ def _worker(rank, world, port, views, out_dir):
     dist.destroy_process_group()
 
 
-def test_collective_stream_is_transparent_without_an_nccl_group():
-    """``parallel.collective_stream`` moves nccl collectives off the stream the Trainer records on; with no process group (and on gloo:
-    the two-rank tests below run their collectives inside it) it must do nothing, once, and pass exceptions through."""
-    entered = []
-    with parallel.collective_stream():
-        entered.append(1)
-    assert entered == [1]
-    with pytest.raises(ZeroDivisionError):
-        with parallel.collective_stream():
-            1 / 0
-
-
 def test_shard_views_partitions_the_batch():
     for world in (1, 2, 3, 8):
         views = list(range(17))

@@ -18,16 +18,13 @@ STATE_KEYS = dict(optPosBuffer=("opt_pos", 12), optRotBuffer=("opt_rot", 12), op
 
 
 class _FixedViews:
-    """Stands in for the trainer's ``random.Random``: hands out a fixed list of view indices (the reference draws Math.random()).
-    The single-view Trainer draws each step's view one step AHEAD (``Trainer.project_ahead``), so after the last step of a run it
-    holds one sample more than the list -- a view nobody trains on: that one draw past the end is answered with view 0."""
+    """Stands in for the trainer's ``random.Random``: hands out a fixed list of view indices (the reference draws Math.random())."""
 
     def __init__(self, views):
         self.views, self.i = list(views), 0
 
     def randrange(self, n):
-        assert self.i <= len(self.views), "more than one draw past the end of the fixed sequence"
-        v = self.views[self.i] if self.i < len(self.views) else 0
+        v = self.views[self.i]
         self.i += 1
         assert 0 <= v < n
         return v
@@ -54,9 +51,8 @@ def _compare(t, o, what):
     assert t.getIteration() == o.iteration and t.optimizer.getIteration() == o.optimizer_iteration, what
 
 
-@pytest.mark.parametrize("use_cb,ahead", [(True, True), (True, False), (False, True), (False, False)],
-                         ids=["recorded-ahead", "recorded", "eager-ahead", "eager"])
-def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb, ahead):
+@pytest.mark.parametrize("use_cb", [True, False])
+def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb):
     from oracle import oracle_trainer
     dev = hip_device
     cfg = harness.small_config("c2", num_points=5000, width=128, height=96, s0=0.01)
@@ -71,27 +67,20 @@ def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb, a
 
     o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, list(cams), imgs, densify=dens)
     t = Trainer(dev, seed=0, use_command_buffers=use_cb)
-    t.project_ahead = ahead
     t.setDensifyPruneConfig(dens)
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
     t.start()
     sizes = [t.getPointCount()]
-    # ONE sequence for the whole run, in the order the reference consumes Math.random(): a step's own view, then -- after a step that
-    # densifies -- the metric views.  The plain trainer draws a step's view at the start of that step (trainer.ts:573); with
-    # `project_ahead` it draws it at the end of the step before, unless that step densifies: the same sequence, one sample early.
-    sequence = [v for i in range(steps) for v in [train_views[i]] + metric_views.get(i + 1, [])]
-    t._rng = _FixedViews(sequence)
-    drawn = 0
     try:
         for i in range(steps):
             it = i + 1
             draws = [train_views[i]] + metric_views.get(it, [])
-            drawn += len(draws)
+            t._rng = _FixedViews(draws)
             assert o.should_densify() == (it in metric_views)
             o.step(train_views[i], metric_view_ids=metric_views.get(it))
             t.step()
-            assert t._rng.i == drawn + (1 if ahead and it not in metric_views else 0), "the trainer drew a different number of views than the schedule says"
+            assert t._rng.i == len(draws), "the trainer drew a different number of views than the schedule says"
             sizes.append(t.getPointCount())
             if it in metric_views or it in (1, 2, 11, 13, 21, 23, steps):
                 _compare(t, o, f"after iteration {it}")
@@ -125,8 +114,9 @@ def test_multi_view_metric_accumulation_and_decisions_equal_the_oracle(hip_devic
     t.start()
     try:
         mviews = [4, 1, 4, 2]
-        t._rng = _FixedViews([0, 3, 1] + mviews)  # (one sequence: the trainer may draw a step's view one step ahead, project_ahead)
         for it, v in enumerate([0, 3, 1], start=1):
+            draws = [v] + (mviews if it == 3 else [])
+            t._rng = _FixedViews(draws)
             if it == 3:  # keep the densify inputs: the trainer swaps the cloud inside step()
                 captured = {}
                 orig = t.densifyPrune.encodePrepare

@@ -148,7 +148,6 @@ SIGNATURES = {
     "wdgs_tiled_forward_set_dc_source": (_I, [_P, _P]),
     "wdgs_tiled_forward_project_views": (_I, [_P, _P, _U, _P, _P]),
     "wdgs_tiled_forward_encode_projected": (_I, [_P]),
-    "wdgs_tiled_forward_is_projected": (_I, [_P]),
     "wdgs_tiled_backward_encode_geometry_views": (_I, [_P, _P, _P, _P, _U, _P, _P, _P, _P, _I, _I]),
     "wdgs_guard_accumulate": (_I, [_P, _P, _P, _I]),
     "wdgs_optimizer_state_changed": (_I, [_P]),
@@ -218,7 +217,6 @@ SIGNATURES = {
     "wdgs_optimizer_init_from_point_cloud": (_I, [_P, _P, _P]),
     "wdgs_optimizer_step": (_I, [_P, _P, _P, _P, _P]),
     "wdgs_optimizer_step_with_geometry": (_I, [_P, _P, _P, _P, _P, _P]),
-    "wdgs_optimizer_step_with_geometry_project": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "wdgs_optimizer_step_f32": (_I, [_P, _P, _P, _P, _P]),
     "wdgs_accumulate_gradients": (_I, [_P, _U, _P, _P, _P, _P]),
     "wdgs_store_gradients": (_I, [_P, _U, _P, _P, _P, _P]),

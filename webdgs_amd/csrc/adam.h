@@ -36,15 +36,12 @@ WD_DEV Grad14 unpack_gradient(const u32* __restrict__ gradients, u32 idx) {
 // state is adopted, unpacked or rewritten from outside (cs_load).  Rotation (no padding) and opacity stay where they are.
 // (CsView: common.h)
 
-// What the re-pack has written for one Gaussian: its six words and the two SH words that hold the DC coefficients (sh1: low half only).
-struct Repacked { uint2 w01, w23, w45; u32 sh0, sh1lo; };
-
 // Adam on one Gaussian's 14 trained scalars (SH: DC only) followed by the fp16 re-pack of that Gaussian.
 // rows_out (nullable): the re-packed row -- 6 Gaussian words, SH word 0, low half of SH word 1 -- also goes to rows_out[idx*8 ..],
 // the 32-byte form in which a data-parallel rank publishes the Gaussians it owns (wdgs_comm_allgather_rows).
 WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_adam_hyperparameters& h, float4* __restrict__ opt_rot,
                             float* __restrict__ opt_opacity, const CsView cs, u32* __restrict__ gaussians, u32* __restrict__ sh_buffer,
-                            u32* __restrict__ rows_out = nullptr, u32* __restrict__ dc_words = nullptr, Repacked* __restrict__ repacked = nullptr) {
+                            u32* __restrict__ rows_out = nullptr, u32* __restrict__ dc_words = nullptr) {
     const float4 q0 = cs.quad(0, idx), q2 = cs.quad(2, idx), q4 = cs.quad(4, idx), q5 = cs.quad(5, idx);
     float4 R = opt_rot[(size_t)idx * 3];
     float op = opt_opacity[(size_t)idx * 3];
@@ -108,13 +105,6 @@ WD_DEV void adam_and_repack(u32 idx, bool update, const Grad14& g, const wdgs_ad
         u32* shp = sh_buffer + (size_t)idx * 24;
         shp[0] = sh0;
         reinterpret_cast<unsigned short*>(shp)[2] = (unsigned short)sh1lo;
-    }
-    if (repacked) {  // (a caller that goes on with this Gaussian: backward.hip, geometry_backward_adam_project)
-        repacked->w01 = make_uint2(wd_pack2(P.x, P.y), wd_pack2(P.z, op));
-        repacked->w23 = make_uint2(wd_pack2(R.x, R.y), wd_pack2(R.z, R.w));
-        repacked->w45 = make_uint2(wd_pack2(S.x, S.y), wd_pack2(S.z, 0.0f));
-        repacked->sh0 = sh0;
-        repacked->sh1lo = sh1lo;
     }
     if (rows_out) {
         uint4* ro = reinterpret_cast<uint4*>(rows_out + (size_t)idx * 8);

@@ -30,9 +30,6 @@ int launch_project_count_views(wdgs_device*, u32, u32, const void*, const void*,
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*);
 int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
                                   const wdgs_optimizer_state&, const CsView&, void*, const void*, void*);
-int launch_geometry_backward_adam_project(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
-                                          const wdgs_optimizer_state&, const CsView&, void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, void*, void*,
-                                          void*, void*, void*, void*);
 int launch_geometry_backward_accumulate(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*, void*, void*, void*, const void*, void*,
                                         const void*, u32);
 int launch_adam_repack(wdgs_device*, u32, const wdgs_adam_hyperparameters&, const void*, const void*, const wdgs_optimizer_state&, const CsView&, void*, void*,
@@ -800,7 +797,6 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     // single-workgroup kernel scans those N/256 sums (and publishes the stats block: update_stats, K5, as its epilogue), and emit adds
     // its own in-workgroup prefix -- writing the per-Gaussian offsets table on the way.  Three launches instead of five.
     const bool columns = forward_uses_columns(op, skip_sort);
-    op->projected = false;  // (K1 overwrites whatever projection the buffers held)
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
                                   op->block_counts, columns ? op->column_counts : nullptr, op->dc_source));
     return forward_encode_rest(op, skip_sort, columns);
@@ -831,14 +827,9 @@ int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void*
 }
 int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_encode_projected: null op");
-    WDGS_REQUIRE(op->projected, WDGS_E_STATE,
-                 "wdgs_tiled_forward_encode_projected: the pass holds no projection (wdgs_tiled_forward_project_views / wdgs_optimizer_step_with_geometry_project), or "
-                 "a later encode has consumed or overwritten it");
-    op->projected = false;  // the scan consumes K1's workgroup sums in place: the rest of the pass can run ONCE per projection
+    WDGS_REQUIRE(op->projected, WDGS_E_STATE, "wdgs_tiled_forward_encode_projected: the pass has not been projected (wdgs_tiled_forward_project_views)");
     return forward_encode_rest(op, 0, op->projected_columns);
 }
-
-int wdgs_tiled_forward_is_projected(const wdgs_tiled_forward* op) { return (op && op->projected) ? 1 : 0; }
 
 int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t h) {
     WDGS_REQUIRE(op && w > 0 && h > 0, WDGS_E_INVALID, "wdgs_tiled_forward_set_viewport: invalid argument");
@@ -1235,25 +1226,6 @@ int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* b
     if (op->deferred_sh) op->sh_stale = true;
     return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradients, op->params, tile_counts, op->state,
                                          op->cs(), sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
-}
-int wdgs_optimizer_step_with_geometry_project(wdgs_optimizer* op, wdgs_tiled_backward* bwd, const void* camera, void* gaussians, void* sh, const void* tile_counts,
-                                              wdgs_tiled_forward* next, const void* next_camera) {
-    WDGS_REQUIRE(op && bwd && camera && gaussians && sh && tile_counts && next && next_camera, WDGS_E_INVALID, "wdgs_optimizer_step_with_geometry_project: null argument");
-    WDGS_REQUIRE(bwd->cfg.num_points == op->num_points && next->cfg.num_points == op->num_points, WDGS_E_STATE,
-                 "wdgs_optimizer_step_with_geometry_project: the backward pass holds %u Gaussians, the next forward pass %u, the optimizer %u", bwd->cfg.num_points,
-                 next->cfg.num_points, op->num_points);
-    WDGS_REQUIRE(next->dev == op->dev, WDGS_E_INVALID, "wdgs_optimizer_step_with_geometry_project: the forward pass belongs to another device");
-    op->iteration++;  // optimizer.ts:301
-    op->dc_dirty = true;
-    if (op->deferred_sh) op->sh_stale = true;
-    const bool columns = forward_uses_columns(next, 0);
-    WDGS_TRY(launch_geometry_backward_adam_project(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradients, op->params, tile_counts,
-                                                   op->state, op->cs(), sh, op->guard, op->deferred_sh ? op->dc_words : nullptr, next_camera, next->settings, next->tile_info,
-                                                   next->splats, next->depths, next->scanner->input, next->stats + 4, next->block_counts,
-                                                   columns ? next->column_counts : nullptr));
-    next->projected = true;
-    next->projected_columns = columns;
-    return WDGS_OK;
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {
     WDGS_REQUIRE(op && gaussians && sh && grad_f32 && visible, WDGS_E_INVALID, "wdgs_optimizer_step_f32: null argument");

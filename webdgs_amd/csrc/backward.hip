@@ -7,7 +7,6 @@
 #include "common.h"
 #include "wgslm.h"
 #include "adam.h"
-#include "project_math.h"
 
 namespace {
 
@@ -239,79 +238,6 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
 }
 
 
-// The single-view step's last kernel when the NEXT step's view is already known (the Trainer draws it one step ahead): K17 + Adam + re-pack
-// as in geometry_backward_kernel<2>, and then K1 -- projection, SH colour, tile count, the workgroup sums (project_math.h) -- of the
-// Gaussian the thread has just re-packed, under the next view's camera, into the forward pass's buffers.  The next step then starts at
-// its scan (wdgs_tiled_forward_encode_projected).  K1 alone is a latency-bound pass over all N that re-reads what this kernel has in
-// registers (the Gaussian's six words, the trained SH-DC halves); here its arithmetic runs beside a bandwidth-bound kernel's memory traffic.
-// `pj.tile_counts` may be the buffer `ad.tile_counts` points at (one forward pass serving every view): the thread reads its word for
-// this view before it writes the one for the next.
-struct ProjectNext {
-    const float* camera;
-    RenderSettings settings;   // the forward pass's
-    TileInfo ti;
-    u32* splats; u32* depths; u32* tile_counts; u32* visible_shards; u32* block_counts; u32* column_counts /*nullable*/;
-};
-__global__ __launch_bounds__(256) void geometry_backward_adam_project_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings, int* __restrict__ acc,
-                                                                               u32* __restrict__ acc_dirty, u32* __restrict__ gradients, ViewAdam ad, ProjectNext pj) {
-    __shared__ u32 s_col[256];
-    __shared__ u32 s_vis[4], s_cnt[4];
-    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0u) *acc_dirty = 0u;
-    if (pj.column_counts) {
-        s_col[threadIdx.x] = 0u;
-        __syncthreads();
-    }
-    bool visible = false;
-    u32 num_tiles_out = 0u, box_x0 = 1u, box_x1 = 0u, box_rows = 0u;
-    if (idx < n) {
-        int4* ap = reinterpret_cast<int4*>(acc + (size_t)idx * ACC_STRIDE);
-        const int4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-        if ((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w | a2.x | a2.y | a2.z | a2.w) != 0) {
-            const int4 z = make_int4(0, 0, 0, 0);
-            ap[0] = z; ap[1] = z; ap[2] = z;
-        }
-        const u32* gp = ad.gaussians + (size_t)idx * 6;
-        Repacked rp;
-        rp.w01 = *reinterpret_cast<const uint2*>(gp); rp.w23 = *reinterpret_cast<const uint2*>(gp + 2); rp.w45 = *reinterpret_cast<const uint2*>(gp + 4);
-        uint4 o0, o1;
-        geometry_chain(a0, a1, a2, rp.w01, rp.w23, rp.w45, camera_f, settings, o0, o1);
-        uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
-        op[0] = o0;
-        op[1] = o1;
-        const u32 sh_deg = wd_to_u32(pj.settings.sh_deg);
-        bool stepped = false;
-        // guard: a step whose tile-entry list overflowed is skipped (optimizer.hip: adam_repack_kernel) -- the projection below then sees the
-        // Gaussian as it was
-        if (!(ad.guard && *ad.guard != 0u)) {
-            const bool update = ad.tile_counts[idx] != 0u;
-            Grad14 g = {};
-            if (update) {
-                g.pos[0] = wd_unpack_lo(o0.x); g.pos[1] = wd_unpack_hi(o0.x); g.pos[2] = wd_unpack_lo(o0.y); g.opac = wd_unpack_hi(o0.y);
-                g.rot[0] = wd_unpack_lo(o0.z); g.rot[1] = wd_unpack_hi(o0.z); g.rot[2] = wd_unpack_lo(o0.w); g.rot[3] = wd_unpack_hi(o0.w);
-                g.scale[0] = wd_unpack_lo(o1.x); g.scale[1] = wd_unpack_hi(o1.x); g.scale[2] = wd_unpack_lo(o1.y);
-                g.color[0] = wd_unpack_lo(o1.z); g.color[1] = wd_unpack_hi(o1.z); g.color[2] = wd_unpack_lo(o1.w);
-            }
-            adam_and_repack(idx, update, g, ad.h, ad.opt_rot, ad.opt_opacity, ad.cs, ad.gaussians, ad.sh, nullptr, ad.dc_words, &rp);
-            stepped = true;
-        }
-        // ---- K1 of the next view on the re-packed Gaussian.  The SH row's trained halves come from the registers of the re-pack (in
-        // deferred mode the row in memory is behind; in direct mode this thread has only just stored them).
-        ShRow sh_row = load_sh_row(ad.sh, idx, sh_deg);
-        if (stepped) {
-            sh_row.w[0] = rp.sh0;
-            sh_row.w[1] = (sh_row.w[1] & 0xFFFF0000u) | (rp.sh1lo & 0xFFFFu);
-        } else if (ad.dc_words) {
-            const uint2 dcw = *reinterpret_cast<const uint2*>(ad.dc_words + (size_t)idx * 2);
-            sh_row.w[0] = dcw.x;
-            sh_row.w[1] = (sh_row.w[1] & 0xFFFF0000u) | (dcw.y & 0xFFFFu);
-        }
-        visible = project_one(idx, rp.w01, rp.w23, rp.w45, sh_row, pj.camera, pj.settings, pj.ti, pj.splats, pj.depths, num_tiles_out, box_x0, box_x1, box_rows);
-        pj.tile_counts[idx] = num_tiles_out;
-    }
-    project_block_epilogue(visible, num_tiles_out, box_x0, box_x1, box_rows, pj.ti.num_tiles_x, s_col, s_vis, s_cnt, pj.visible_shards, pj.block_counts, pj.column_counts);
-}
-
 // K17 for ALL the views of a batched step in one pass over the Gaussians (the Trainer's view-batched step; no reference counterpart: the
 // reference is batch-1).  Per view the thread reads that view's accumulator row (and puts it back to zero), evaluates the same chain rule
 // under that view's camera, rounds the gradient to fp16 as K17 does, and adds it -- in VIEW ORDER, fp32, the first visible view's value
@@ -396,20 +322,6 @@ int launch_geometry_backward_adam(wdgs_device* dev, u32 n, const void* camera, c
                 (const u32*)gaussians, (int*)acc, (u32*)acc_dirty, (u32*)gradients, ViewAccumulate{},
                 (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_rot, (float*)state.opt_opacity, cs, (u32*)gaussians, (u32*)sh, (const u32*)guard,
                           (u32*)dc_words}));
-    WDGS_CHECK_HIP(hipGetLastError());
-    return WDGS_OK;
-}
-
-int launch_geometry_backward_adam_project(wdgs_device* dev, u32 n, const void* camera, const RenderSettings& st, void* gaussians, void* acc, void* acc_dirty, void* gradients,
-                                          const wdgs_adam_hyperparameters& h, const void* tile_counts, const wdgs_optimizer_state& state, const CsView& cs, void* sh,
-                                          const void* guard, void* dc_words, const void* next_camera, const RenderSettings& fwd_settings, const TileInfo& ti, void* splats,
-                                          void* depths, void* next_tile_counts, void* visible_shards, void* block_counts, void* column_counts) {
-    if (n == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "geometry_backward_adam_project", geometry_backward_adam_project_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const float*)camera, st,
-                (int*)acc, (u32*)acc_dirty, (u32*)gradients,
-                (ViewAdam{h, (const u32*)tile_counts, (float4*)state.opt_rot, (float*)state.opt_opacity, cs, (u32*)gaussians, (u32*)sh, (const u32*)guard, (u32*)dc_words}),
-                (ProjectNext{(const float*)next_camera, fwd_settings, ti, (u32*)splats, (u32*)depths, (u32*)next_tile_counts, (u32*)visible_shards, (u32*)block_counts,
-                             (u32*)column_counts}));
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

@@ -353,11 +353,6 @@ class TiledForwardPass:
         counterpart)."""
         check(self.device.lib.wdgs_tiled_forward_encode_projected(self.handle))
 
-    def isProjected(self) -> bool:
-        """True while the pass holds a projection (``projectViews`` / ``Optimizer.stepWithGeometryAndProject``) that no ``encode*`` call
-        made through this host has consumed or overwritten since."""
-        return bool(self.device.lib.wdgs_tiled_forward_is_projected(self.handle))
-
     def setCameraBuffer(self, buffer: HipBuffer) -> None:
         self.cameraBuffer = buffer
 
@@ -701,14 +696,6 @@ class Optimizer:
         pass over the Gaussians: geometry backward (the packed gradient still lands in the pass's gradient buffer), Adam, re-pack."""
         check(self.device.lib.wdgs_optimizer_step_with_geometry(self.handle, backwardPass.handle, cameraBuffer.ptr, coefficients.gaussian_3d_buffer.ptr,
                                                                 coefficients.sh_buffer.ptr, tileCountsBuffer.ptr))
-
-    def stepWithGeometryAndProject(self, encoder, coefficients: PointCloud, backwardPass: "TiledBackwardPass", cameraBuffer: HipBuffer, tileCountsBuffer: HipBuffer,
-                                   nextForwardPass: "TiledForwardPass", nextCameraBuffer: HipBuffer) -> None:
-        """``stepWithGeometry`` for a host that knows its next view: the thread that has re-packed a Gaussian also projects it under
-        ``nextCameraBuffer`` into ``nextForwardPass``'s buffers (K1 of the next step, ``wdgs_optimizer_step_with_geometry_project``);
-        that pass then continues with ``encodeProjected``."""
-        check(self.device.lib.wdgs_optimizer_step_with_geometry_project(self.handle, backwardPass.handle, cameraBuffer.ptr, coefficients.gaussian_3d_buffer.ptr,
-                                                                        coefficients.sh_buffer.ptr, tileCountsBuffer.ptr, nextForwardPass.handle, nextCameraBuffer.ptr))
 
     def stepF32(self, encoder, coefficients: PointCloud, gradF32: HipBuffer, visibleCounts: HipBuffer) -> None:
         """Data-parallel step on fp32 gradients summed over views."""

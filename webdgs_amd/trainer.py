@@ -74,12 +74,6 @@ class Trainer:
         self.pipeline_depth = max(1, min(int(pipeline_depth), 4))
         self.reuse_passes = True  # applyPointCloudSwap resizes the passes instead of rebuilding them (False: the reference's teardown)
         self.fuse_geometry_adam = True  # the single-view step runs K17, Adam and the re-pack as one kernel (False: the reference's three)
-        # The single-view step draws its view one step AHEAD (the same random sequence as trainer.ts:573, consumed one call earlier), so the
-        # kernel that updates a Gaussian can also project it for the next view (K1; ops.Optimizer.stepWithGeometryAndProject) and the next
-        # step starts at its scan.  Only when the views are drawn here (``step()`` without ids), on one GPU; WDGS_PROJECT_AHEAD=0 switches it off.
-        self.project_ahead = os.environ.get("WDGS_PROJECT_AHEAD", "1") != "0"
-        self._ahead_view: Optional[int] = None      # drawn for the next step
-        self._projected_view: Optional[int] = None  # the forward pass's buffers hold K1 of this view for the CURRENT cloud
         # Adam writes the trained SH-DC halves to a compact array that K1 reads, instead of 6 bytes into every 96-byte SH row each step; the
         # rows are flushed at hand-over points (Optimizer.setDeferredSH).  False: the reference's write pattern.  Results are identical.
         self.deferred_sh = os.environ.get("WDGS_DEFERRED_SH", "1") != "0"
@@ -153,7 +147,6 @@ class Trainer:
         every pass and constructs new ones; here the passes are kept and resized (``setPointCloud``: buffers reused, or re-allocated
         with headroom when the cloud outgrew them) -- only the optimizer, which adopts the rebuilt state arrays, is new.  Passes that
         cannot follow (another SH degree) are rebuilt as the reference does."""
-        self._projected_view = None
         self.drain()
         self.device.synchronize()
         oldParams = self.optimizer.getHyperparameters() if self.optimizer else None
@@ -207,7 +200,6 @@ class Trainer:
             c.destroy()
         self._cmd_cache = {}
         self._eager_steps = 0
-        self._projected_view = None  # (whatever changed may have changed what K1 sees)
         if deferred is not None:
             raise deferred
 
@@ -408,29 +400,17 @@ class Trainer:
             for _ in range(2 if v == 0 else 1):
                 self.step([v] * n_views)
                 taken += 1
-        if self.project_ahead and n_views == 1 and self.fuse_geometry_adam:
-            # the project-ahead form of the single-view step: once round the views with each step naming its successor records every
-            # view's command buffer that starts at the scan (and view 0's that starts at K1, as the first step after a densify pass does)
-            V = len(self.trainCameras)
-            for k in range(V + 1):
-                self.step([k % V], _next_view=(k + 1) % V)
-                taken += 1
         return taken
 
-    def step(self, view_ids: Optional[list] = None, _next_view: Optional[int] = None) -> None:
+    def step(self, view_ids: Optional[list] = None) -> None:
         """One training iteration (trainer.ts:568-660).  ``view_ids``: the global batch's views (default: drawn at random, as the
-        reference picks ``Math.random()`` per step); with ``world_size > 1`` each rank takes its shard.  (``_next_view``: internal --
-        ``warmupCommandBuffers`` names the next step's view to record the project-ahead form.)"""
+        reference picks ``Math.random()`` per step); with ``world_size > 1`` each rank takes its shard."""
         if not self.isTraining or self.pointCloud is None:
             return
         stepStart = time.perf_counter()
         n_views = self.world_size * self.views_per_rank
-        drawn_here = view_ids is None
         if view_ids is None:
-            if n_views == 1 and self._ahead_view is not None:
-                view_ids, self._ahead_view = [self._ahead_view], None
-            else:
-                view_ids = [self._rng.randrange(len(self.trainCameras)) for _ in range(n_views)]
+            view_ids = [self._rng.randrange(len(self.trainCameras)) for _ in range(n_views)]
         mine = parallel.shard_views(view_ids, self.rank, self.world_size)
         image0 = self.images[mine[0]]
         self.ensurePipelines(image0["width"], image0["height"])
@@ -440,19 +420,10 @@ class Trainer:
         warmup, interval, stop = s["warmupIterations"], max(1, s["interval"]), s["stopIterations"]
         shouldDensify = s["enabled"] and warmup <= nextIteration <= stop and (nextIteration == warmup or (nextIteration - warmup) % interval == 0)
 
-        # the next step's view, when it is this trainer that draws it and nothing comes between the two steps that would draw from the
-        # same sequence or change the cloud (the densify pass samples its metric views: trainer.ts:373-497)
-        ahead = None
-        if self.project_ahead and n_views == 1 and self.fuse_geometry_adam and not shouldDensify and self.iteration + 1 < self.maxIterations:
-            if drawn_here:
-                ahead = self._ahead_view = self._rng.randrange(len(self.trainCameras))
-            elif _next_view is not None:
-                ahead = int(_next_view)
         try:
             if n_views == 1:
-                self._step_single_view(mine[0], ahead)
+                self._step_single_view(mine[0])
             else:
-                self._projected_view = None
                 self._step_batched(mine)
         except BaseException as orig:
             # a failed encode (capacity, first-use allocation inside a recording, a Python error) must not leave the stream in
@@ -504,26 +475,9 @@ class Trainer:
         self.device.queue.submit([cmd])
         return False
 
-    def _step_single_view(self, view: int, next_view: Optional[int] = None) -> None:
-        """The reference's step (trainer.ts:603-645): one view, Adam straight from the packed fp16 gradients.  ``next_view``: the view
-        of the next step, if already drawn -- the step's last kernel then projects for it too (``project_ahead``)."""
+    def _step_single_view(self, view: int) -> None:
+        """The reference's step (trainer.ts:603-645): one view, Adam straight from the packed fp16 gradients."""
         tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
-        # (the pass itself knows whether the projection is still there: anybody may have encoded another view with it since)
-        projected, self._projected_view = (self._projected_view == view and self.forwardPass.isProjected()), None
-        if next_view is not None or projected:
-            # [scan .. backward raster] as the view's recorded command buffer (with K1 in front unless the previous step has done it),
-            # then ONE eager launch: K17 + Adam + re-pack (+ K1 of the next view) -- its two cameras would otherwise make a recording
-            # per pair of views
-            self._run(("views", view, projected), lambda encoder: self._encode_view(encoder, view, geometry=False, projected=projected))
-            if next_view is not None:
-                self.optimizer.stepWithGeometryAndProject(None, self.pointCloud, self.backwardPass, self._camera_buffers[view], tileCounts, self.forwardPass,
-                                                          self._camera_buffers[next_view])
-                self._projected_view = next_view
-            else:
-                self.optimizer.stepWithGeometry(None, self.pointCloud, self.backwardPass, self._camera_buffers[view], tileCounts)
-            if not self.use_command_buffers or self._eager_steps < 1:
-                self._eager_steps += 1
-            return
 
         def encode(encoder):
             if self.fuse_geometry_adam:  # K1..K16, then K17 + Adam + re-pack in one pass over the Gaussians
