@@ -385,6 +385,9 @@ int wdgs_tiled_forward_set_dc_source(wdgs_tiled_forward* op, const void* dc_word
  * wdgs_tiled_forward_encode_projected, on any lane, recorded or not.  Results are those of wdgs_tiled_forward_encode per view, bit for bit. */
 int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void* const* cameras_dev, uint32_t count, const void* gaussians_dev, const void* sh_dev);
 int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op);
+/* 1 while the pass holds a projection that wdgs_tiled_forward_encode_projected has not consumed yet and no wdgs_tiled_forward_encode has
+ * overwritten (the scan works in place on K1's workgroup sums: the rest of the pass can run once per projection). */
+int wdgs_tiled_forward_is_projected(const wdgs_tiled_forward* op);
 /* ... and K17 of all V views in one launch: per view the accumulators of `ops[v]` (wdgs_tiled_backward_encode_raster ran for it) are turned
  * into the view's fp16 gradient under `cameras_dev[v]` and summed, in view order, into the step's fp32 block `sums_f32_dev` [N][14] with the
  * visibility counts `visible_dev` [N] and the guard word (OR of the views' overflow words `overflow_words_dev[v]`) -- what V calls of

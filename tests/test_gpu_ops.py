@@ -372,3 +372,33 @@ def test_resized_passes_behave_like_fresh_ones(hip_device):
         assert not pipe.fwd.setPointCloud(other_deg), "another SH degree: the pass cannot follow and says so"
     finally:
         pipe.destroy()
+
+
+def test_a_projection_is_consumed_once(hip_device, orc):
+    """``projectViews`` + ``encodeProjected`` (the view-batched K1): the scan works in place on K1's workgroup sums, so the rest of a pass
+    can run once per projection -- a second ``encodeProjected``, or one after a plain ``encode`` has overwritten the projection, is refused
+    (it would index with offsets scanned twice), and ``isProjected`` says which state the pass is in.  The projected pass equals the plain one."""
+    cfg = harness.small_config("c1", num_points=4000)
+    g, sh, cam = harness.scene(cfg)
+    pipe = harness.HipPipeline(hip_device, cfg, g, sh, cam)
+    try:
+        fw = pipe.fwd
+        assert not fw.isProjected()
+        ops.projectViews([fw], [pipe.camera], pipe.pc)
+        assert fw.isProjected()
+        fw.encodeProjected(None)
+        assert not fw.isProjected()
+        with pytest.raises(ops.StateError):
+            fw.encodeProjected(None)
+        st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+        ref = orc.forward(g, sh, cam, st, ti)
+        e = ref["total_entries"]
+        harness.assert_bits_equal(fw.getSortedIndicesBuffer().read(np.uint32)[:e], ref["sorted_values"][:e], "sorted indices of the projected pass")
+        ops.projectViews([fw], [pipe.camera], pipe.pc)
+        fw.encode(None)   # K1 again: the projection is gone
+        assert not fw.isProjected()
+        with pytest.raises(ops.StateError):
+            fw.encodeProjected(None)
+        harness.assert_bits_equal(fw.getSortedIndicesBuffer().read(np.uint32)[:e], ref["sorted_values"][:e], "sorted indices after the plain encode")
+    finally:
+        pipe.destroy()

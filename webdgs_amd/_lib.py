@@ -148,6 +148,7 @@ SIGNATURES = {
     "wdgs_tiled_forward_set_dc_source": (_I, [_P, _P]),
     "wdgs_tiled_forward_project_views": (_I, [_P, _P, _U, _P, _P]),
     "wdgs_tiled_forward_encode_projected": (_I, [_P]),
+    "wdgs_tiled_forward_is_projected": (_I, [_P]),
     "wdgs_tiled_backward_encode_geometry_views": (_I, [_P, _P, _P, _P, _U, _P, _P, _P, _P, _I, _I]),
     "wdgs_guard_accumulate": (_I, [_P, _P, _P, _I]),
     "wdgs_optimizer_state_changed": (_I, [_P]),

@@ -797,6 +797,7 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     // single-workgroup kernel scans those N/256 sums (and publishes the stats block: update_stats, K5, as its epilogue), and emit adds
     // its own in-workgroup prefix -- writing the per-Gaussian offsets table on the way.  Three launches instead of five.
     const bool columns = forward_uses_columns(op, skip_sort);
+    op->projected = false;  // (K1 overwrites whatever projection the buffers held)
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
                                   op->block_counts, columns ? op->column_counts : nullptr, op->dc_source));
     return forward_encode_rest(op, skip_sort, columns);
@@ -827,9 +828,13 @@ int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void*
 }
 int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_encode_projected: null op");
-    WDGS_REQUIRE(op->projected, WDGS_E_STATE, "wdgs_tiled_forward_encode_projected: the pass has not been projected (wdgs_tiled_forward_project_views)");
+    WDGS_REQUIRE(op->projected, WDGS_E_STATE,
+                 "wdgs_tiled_forward_encode_projected: the pass holds no projection (wdgs_tiled_forward_project_views), or a later encode has consumed or overwritten it");
+    op->projected = false;  // the scan consumes K1's workgroup sums in place: the rest of the pass can run ONCE per projection
     return forward_encode_rest(op, 0, op->projected_columns);
 }
+
+int wdgs_tiled_forward_is_projected(const wdgs_tiled_forward* op) { return (op && op->projected) ? 1 : 0; }
 
 int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t h) {
     WDGS_REQUIRE(op && w > 0 && h > 0, WDGS_E_INVALID, "wdgs_tiled_forward_set_viewport: invalid argument");

@@ -353,6 +353,11 @@ class TiledForwardPass:
         counterpart)."""
         check(self.device.lib.wdgs_tiled_forward_encode_projected(self.handle))
 
+    def isProjected(self) -> bool:
+        """True while the pass holds a projection (``projectViews``) that no ``encode*`` call made through this host has consumed or
+        overwritten since (the rest of the pass can run once per projection)."""
+        return bool(self.device.lib.wdgs_tiled_forward_is_projected(self.handle))
+
     def setCameraBuffer(self, buffer: HipBuffer) -> None:
         self.cameraBuffer = buffer
 
