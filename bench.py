@@ -43,8 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def algorithmic_bytes(kernel: str, n: int, v: int, e: int, p: int, t: int, k_coef: int, passes: int) -> float:
-    """SURVEY.md section 8(d) per-stage algorithmic bytes for one training view."""
+def algorithmic_bytes(kernel: str, n: int, v: int, e: int, p: int, t: int, k_coef: int, passes: int, views: int = 1) -> float:
+    """SURVEY.md section 8(d) per-stage algorithmic bytes for one training view (the view-batched kernels: for one step of `views` views)."""
     table = {
         "project_count": n * (24 + 6 * k_coef) + 28 * v + 4 * n,
         "scan": 8 * n,
@@ -58,6 +58,10 @@ def algorithmic_bytes(kernel: str, n: int, v: int, e: int, p: int, t: int, k_coe
         "adam_repack": 4 * n + 416 * v + 100 * n,
         # K17 + K18 + K19 in one pass (single-view step): the packed gradient is written (32 N) but not read back
         "geometry_backward_adam": 96 * n + 4 * n + 416 * v + 100 * n - 32 * n,
+        # the view-batched K1 / K17: Gaussian and SH row once per step, per view the splat, depth and count / the
+        # accumulator row read and put back to zero, then the step's fp32 gradient row and visibility count written once
+        "project_count_views": n * (24 + 6 * k_coef) + views * (28 * v + 4 * n),
+        "geometry_backward_views": 24 * n + views * (96 * n + 4 * n) + 60 * n,
     }
     return float(table.get(kernel, 0))
 
@@ -340,7 +344,8 @@ def source_sha(kernel: str) -> str:
         return ""
 
 
-def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, tiles: int, k_coef: int, passes: int, config: str, pairs: int, raster_ms: float) -> dict:
+def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, tiles: int, k_coef: int, passes: int, config: str, pairs: int, raster_ms: float,
+                   views: int = 1) -> dict:
     """The `roofline` object for the dominant kernel.  The two rasterization kernels (K14 / K16) are bound by fp32 VALU issue (SURVEY
     8(d)): for them `bound` = "valu_issue", achieved / peak are wave-instructions per second (a wave64 VALU instruction occupies its
     SIMD-32 for 2 cycles: 1024 SIMDs x 2.4 GHz / 2), the HBM fraction is kept as `hbm_frac` and SURVEY 8(d)'s flop fraction
@@ -348,7 +353,7 @@ def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, 
     passes of their own (scripts/pmc.sh -> profiles/*_pmc.json): they are taken from the newest profile whose recorded hash of the
     kernel's source file equals the working tree's, and refused (null, with the reason) otherwise."""
     dur_s = dur_ms / 1e3
-    abytes = algorithmic_bytes(dom, n, v, e, p_pix, tiles, k_coef, passes)
+    abytes = algorithmic_bytes(dom, n, v, e, p_pix, tiles, k_coef, passes, views)
     hbm_gbps = abytes / dur_s / 1e9 if dur_s > 0 else 0.0
     roof = dict(bound="hbm", kernel=dom, achieved=round(hbm_gbps, 2), peak=8000.0, unit="GB/s", frac=round(hbm_gbps / 8000.0, 5), traffic=None,
                 avg_ms_per_launch=round(dur_ms, 4), algorithmic_bytes=abytes, hbm_frac=round(hbm_gbps / 8000.0, 5))
@@ -525,16 +530,17 @@ def main() -> None:
     per_view_kernels = ("project_count", "scan", "emit", "sort", "tile_ranges", "rasterize", "loss_grad", "backward_rasterize", "geometry_backward", "geometry_backward_adam",
                         "store_gradients", "accumulate_gradients", "guard_accumulate", "acc_clear")
     per_step = {k: v[1] / max(1, args.steps) / (vpr if k in per_view_kernels else 1) for k, v in groups.items()}
-    dom = max(per_step, key=per_step.get) if per_step else None
+    # (the dominant kernel by time per STEP: a per-view kernel runs once per view of the step)
+    dom = max(per_step, key=lambda k: per_step[k] * (vpr if k in per_view_kernels else 1)) if per_step else None
     roofline = None
     if dom:
         roofline = build_roofline(dom, per_step[dom], n, v_visible, e_entries, p_pix, tiles, k_coef, passes, args.config, pairs,
-                                  per_step.get("rasterize", 0.0) + per_step.get("backward_rasterize", 0.0))
+                                  per_step.get("rasterize", 0.0) + per_step.get("backward_rasterize", 0.0), views=vpr)
 
     # every stage against the HBM roof (algorithmic bytes / live duration): the streaming stages are the ones it binds
     hbm_by_stage = {}
     for k, ms in per_step.items():
-        ab = algorithmic_bytes(k, n, v_visible, e_entries, p_pix, tiles, k_coef, passes)
+        ab = algorithmic_bytes(k, n, v_visible, e_entries, p_pix, tiles, k_coef, passes, vpr)
         if ab > 0 and ms > 0:
             hbm_by_stage[k] = dict(GBps=round(ab / (ms / 1e3) / 1e9, 1), frac=round(ab / (ms / 1e3) / 8.0e12, 4))
 
