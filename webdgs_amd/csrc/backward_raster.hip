@@ -9,15 +9,19 @@
 //   * the chunk is compacted (ballot + prefix popcount, order preserving) to the splats whose extent box overlaps the block,
 //     into 3 KB of wave-private LDS; no workgroup barrier exists, so a block with few contributors never waits for a
 //     neighbour with many;
-//   * the 9 per-pixel contributions are summed across the wave in registers by a halving butterfly
-//     (v_permlane32_swap, v_permlane16_swap, DPP quad sums, one merged row rotation: 22 VALU ops for all nine sums instead of 9 full reductions)
-//     and land in twelve lanes (eight slots, and blue as one partial sum per 16-lane row) that issue ONE atomic instruction per
-//     (wave, splat) on twelve consecutive words -- instead of 9 per (pixel, splat);
-//   * a tile's four waves share a workgroup (one CU, one XCD), so its entries and splats come from that XCD's L2 (raster.hip).
+//   * eight of the 9 per-pixel contributions are summed across the wave through a transposition in wave-private LDS (every lane stores a
+//     column of an [8][64] array, lane (q, part) adds eight consecutive entries of row q, three DPP steps finish the sum) and blue in
+//     registers; the sums land in twelve lanes (eight slots, and blue as one partial sum per 16-lane row) that issue ONE atomic
+//     instruction per (wave, splat) on twelve consecutive words -- instead of 9 per (pixel, splat).  (Round 2 summed in registers with a
+//     halving butterfly -- v_permlane32_swap, v_permlane16_swap, DPP -- which costs few instructions but much issue time on gfx950:
+//     DESIGN.md section 4, "What a VALU instruction costs".  That form is kept behind WDGS_BWR_SUMS=butterfly for same-box comparisons.)
+//   * one wave per workgroup; a tile's four blocks are numbered so that they are dispatched back to back on one XCD and share its L2
+//     lines of the entry list (WDGS_BWR_WPW=4: workgroup = tile).
 // The contributions keep the reference's semantics exactly: each is truncated to i32 at x1e6 per pixel
 // (common.wgsl:113-116) and integer addition is order-free, so the result is bit-reproducible and equal to the oracle's.
-// Bound: fp32 VALU issue -- about 129 wave-instructions per (wave, splat) with a contributing pixel: the pinned exp (14), one division (8),
-// the per-pixel gradient arithmetic (about 55), the reduction (22) and the bookkeeping around them; DESIGN.md section 4 has the counters.
+// Bound: fp32 VALU issue -- about 113 wave-instructions per (wave, splat) with a contributing pixel: the pinned exp (12), one division (8),
+// nine fixed-point conversions (18), the per-pixel gradient arithmetic (about 45), the reduction (17) and the tests and bookkeeping
+// around them, at 0.96-0.99 of the rate this chip sustains for a pure FMA stream; DESIGN.md section 4 has the counters.
 #include <algorithm>
 #include <cstdlib>
 

@@ -6,7 +6,8 @@
 //     Splat one chunk ahead are fetched into registers, so both global round trips overlap with compositing;
 //   * the chunk is compacted to the splats whose extent box overlaps the wave's 8x8 block (ballot + prefix popcount, order
 //     preserving) into a 3 KB wave-private LDS record set; the per-pixel extent test of the reference still decides;
-//   * the inner loop reads the compacted records by broadcast ds_read_b128;
+//   * the inner loop reads the compacted records by broadcast ds_read_b128, one iteration ahead of their use (two iterations per loop
+//     trip, the two register sets swapping roles);
 //   * no workgroup barrier exists: a wave stops as soon as ITS 64 pixels are saturated (A > 0.99) or the tile's entries
 //     end -- after saturation the reference's loop `continue`s without touching C, A or last_contributor (lines 224-226),
 //     so stopping cannot change an output.  (A 256-thread version spent half its wave-cycles waiting at barriers for the
@@ -14,7 +15,8 @@
 //   * the four waves of a tile share a workgroup (hence a CU and an XCD), so the tile's entries and splats are fetched once and
 //     served to the other three waves by L1/L2; tiles are dealt to the 8 XCDs round-robin (blockIdx order) -- giving each XCD one
 //     contiguous band of the image instead was measured 15-30 % slower (the bands' loads differ, the XCDs finish apart).
-// Bound: fp32 VALU issue (about 40 lane-ops per accepted pixel-splat pair incl. the deterministic exp), not HBM.
+// Bound: fp32 VALU issue -- 33 wave-instructions per (wave, splat) iteration incl. the deterministic exp (12), at 0.86 of the rate this chip
+// sustains for a pure FMA stream -- not HBM.
 // Arithmetic is the pinned contraction of DESIGN.md "raster math", bit-identical to the parity oracle.
 #include "common.h"
 #include <cstdlib>
