@@ -51,3 +51,19 @@ def test_single_rank_does_not_launch():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["self_launched"] is False
+
+
+def test_the_newest_counter_profile_describes_the_kernel_sources_in_the_tree():
+    """``bench.py`` takes the dominant kernel's VALU count and HBM traffic from the newest ``profiles/*_pmc.json`` whose recorded hash
+    of that kernel's source file equals the working tree's, and reports ``frac`` null otherwise.  This is the
+    reminder to collect the counter passes again (scripts/collect_profiles.sh) after the last edit of backward_raster.hip."""
+    import glob
+    import json
+    import bench
+    files = sorted(glob.glob(os.path.join(bench.ROOT, "profiles", "*_pmc.json")), key=os.path.basename, reverse=True)
+    assert files, "no counter profile under profiles/"
+    newest = json.load(open(files[0]))
+    for kernel in ("backward_rasterize", "rasterize"):
+        assert (newest.get("source_sha") or {}).get(kernel) == bench.source_sha(kernel), \
+            f"{os.path.basename(files[0])} was collected for another version of {kernel}'s source: run scripts/collect_profiles.sh on the GPU and commit its profiles"
+        assert newest["kernels"][kernel].get("SQ_INSTS_VALU", 0) > 0
