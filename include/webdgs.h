@@ -294,6 +294,10 @@ void* wdgs_tiled_backward_gradients(wdgs_tiled_backward* op);     /* getGradient
 void* wdgs_tiled_backward_metric_counts(wdgs_tiled_backward* op); /* getMetricCountsBuffer: u32[N] */
 void* wdgs_tiled_backward_loss_image(wdgs_tiled_backward* op);    /* getLossTextureView: rgba32float W*H */
 void* wdgs_tiled_backward_metric_map(wdgs_tiled_backward* op);    /* getMetricMapTextureView: u32[W*H] */
+/* Whether the fused step (wdgs_optimizer_step_with_geometry) also writes K17's packed GaussianGradient[N] to the pass's gradient buffer
+ * (default 1, as tiled-backward-pass.ts:629-640 does).  A host that never reads getGradientsBuffer() -- trainer.ts hands it to
+ * optimizer.step() only, which the fused step replaces -- saves the 32 bytes per Gaussian.  The separate K17 always writes it. */
+int wdgs_tiled_backward_set_gradient_output(wdgs_tiled_backward* op, int enabled);
 void* wdgs_tiled_backward_accumulators(wdgs_tiled_backward* op);  /* INTERNAL i32[N*12] (for parity tests) */
 void* wdgs_tiled_backward_metric_minmax(wdgs_tiled_backward* op); /* u32[2] global (min,max) of the last metric map */
 /* Bilinear down-sample of an rgba8 image (the blit render pass of trainer.ts:303-328, shaders/blit.wgsl fs_main). */

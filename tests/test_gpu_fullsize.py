@@ -84,6 +84,7 @@ def test_c3_train_step_is_deterministic_and_mode_independent(hip_device):
     digests = []
     for use_cb in (False, False, True):
         t = Trainer(dev, seed=5, use_command_buffers=use_cb)
+        t.keep_gradients = True   # (the fused step fills the packed-gradient buffer only on request; its digest is compared below)
         t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg)); t.setDataset(cameras, images); t.start()
         for _ in range(4):
             t.step()

@@ -209,6 +209,7 @@ SIGNATURES = {
     "wdgs_tiled_backward_loss_image": (_P, [_P]),
     "wdgs_tiled_backward_metric_map": (_P, [_P]),
     "wdgs_tiled_backward_accumulators": (_P, [_P]),
+    "wdgs_tiled_backward_set_gradient_output": (_I, [_P, _I]),
     "wdgs_tiled_backward_metric_minmax": (_P, [_P]),
     "wdgs_downsample_rgba8": (_I, [_P, _P, _U, _U, _P, _U, _U]),
     "wdgs_image_sse_rgb8": (_I, [_P, _P, _P, _U, _P]),

@@ -151,6 +151,7 @@ struct wdgs_tiled_backward {
     int* acc;            // i32[N*12], followed by the state word below
     u32* acc_dirty;      // device word behind the accumulators: 0 = all rows are zero (a consuming K17 left them so), 1 = they hold sums
     u32* gradients;      // GaussianGradient[N]
+    bool gradient_output;  // the fused K17 + Adam step also writes the packed gradient (wdgs_tiled_backward_set_gradient_output; default on)
     float* loss_image;   // rgba32f
     u32* metric_counts;  // u32[N]
     u32* metric_err;     // u32[W*H]
@@ -1024,6 +1025,7 @@ int wdgs_tiled_backward_create(wdgs_device* d, const wdgs_tiled_backward_config*
     std::memset(op, 0, sizeof(*op));
     op->dev = d;
     op->cfg = *cfg;
+    op->gradient_output = true;
     if (op->cfg.training.c1 == 0.f) op->cfg.training.c1 = 0.01f * 0.01f;  // tiled-backward-pass.ts:172-173
     if (op->cfg.training.c2 == 0.f) op->cfg.training.c2 = 0.03f * 0.03f;
     op->settings = RenderSettings{cfg->gaussian_scale != 0.f ? cfg->gaussian_scale : 1.0f, (float)cfg->sh_deg, (float)cfg->viewport_width,
@@ -1042,6 +1044,11 @@ int wdgs_tiled_backward_destroy(wdgs_tiled_backward* op) {
     free_dev(op->acc); free_dev(op->gradients); free_dev(op->loss_image); free_dev(op->metric_counts);
     free_dev(op->metric_err); free_dev(op->metric_flags); free_dev(op->metric_minmax);
     delete op;
+    return WDGS_OK;
+}
+int wdgs_tiled_backward_set_gradient_output(wdgs_tiled_backward* op, int enabled) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_backward_set_gradient_output: null op");
+    op->gradient_output = enabled != 0;
     return WDGS_OK;
 }
 int wdgs_tiled_backward_compute_loss_only(wdgs_tiled_backward* op, const void* pred, const void* targ) {
@@ -1229,7 +1236,8 @@ int wdgs_optimizer_step_with_geometry(wdgs_optimizer* op, wdgs_tiled_backward* b
     op->iteration++;  // optimizer.ts:301
     op->dc_dirty = true;
     if (op->deferred_sh) op->sh_stale = true;
-    return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradients, op->params, tile_counts, op->state,
+    return launch_geometry_backward_adam(op->dev, op->num_points, camera, bwd->settings, gaussians, bwd->acc, bwd->acc_dirty, bwd->gradient_output ? bwd->gradients : nullptr,
+                                         op->params, tile_counts, op->state,
                                          op->cs(), sh, op->guard, op->deferred_sh ? op->dc_words : nullptr);
 }
 int wdgs_optimizer_step_f32(wdgs_optimizer* op, void* gaussians, void* sh, const void* grad_f32, const void* visible) {

@@ -199,9 +199,11 @@ __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const 
     const uint2 w01 = *reinterpret_cast<const uint2*>(gp), w23 = *reinterpret_cast<const uint2*>(gp + 2), w45 = *reinterpret_cast<const uint2*>(gp + 4);
     uint4 o0, o1;
     geometry_chain(a0, a1, a2, w01, w23, w45, camera_f, settings, o0, o1);
-    uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
-    op[0] = o0;
-    op[1] = o1;
+    if (MODE != 2 || gradients) {   // (MODE 2, the fused step: only for a host that reads the packed gradient -- wdgs_tiled_backward_set_gradient_output)
+        uint4* op = reinterpret_cast<uint4*>(gradients + (size_t)idx * 8);
+        op[0] = o0;
+        op[1] = o1;
+    }
     if (ACC) {
         const bool vis = va.tile_counts[idx] != 0u;
         float* a = va.sums + (size_t)idx * 14;  // 56-byte rows: 8-byte aligned

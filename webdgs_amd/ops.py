@@ -560,6 +560,11 @@ class TiledBackwardPass:
         tc = _training_config(self.trainingConfig)
         check(self.device.lib.wdgs_tiled_backward_set_training_config(self.handle, C.byref(tc)))
 
+    def setGradientOutput(self, enabled: bool) -> None:
+        """Whether ``Optimizer.stepWithGeometry`` also writes K17's packed gradient to ``getGradientsBuffer()`` (default: yes, as the
+        reference's K17 does).  A host that never reads it saves 32 bytes per Gaussian and step; ``encode`` / ``encodeGeometry`` always write it."""
+        check(self.device.lib.wdgs_tiled_backward_set_gradient_output(self.handle, 1 if enabled else 0))
+
     def getGradientsBuffer(self) -> HipBuffer:
         return self.device.view(self.device.lib.wdgs_tiled_backward_gradients(self.handle), 32 * max(1, self.pointCloud.num_points))
 

@@ -74,6 +74,7 @@ class Trainer:
         self.pipeline_depth = max(1, min(int(pipeline_depth), 4))
         self.reuse_passes = True  # applyPointCloudSwap resizes the passes instead of rebuilding them (False: the reference's teardown)
         self.fuse_geometry_adam = True  # the single-view step runs K17, Adam and the re-pack as one kernel (False: the reference's three)
+        self.keep_gradients = os.environ.get("WDGS_KEEP_GRADIENTS", "0") == "1"  # the fused step also fills backwardPass.getGradientsBuffer()
         # Adam writes the trained SH-DC halves to a compact array that K1 reads, instead of 6 bytes into every 96-byte SH row each step; the
         # rows are flushed at hand-over points (Optimizer.setDeferredSH).  False: the reference's write pattern.  Results are identical.
         self.deferred_sh = os.environ.get("WDGS_DEFERRED_SH", "1") != "0"
@@ -309,6 +310,9 @@ class Trainer:
             self.rasterizer = ops.TiledRasterizer(dict(device=self.device, forwardPass=self.forwardPass, format="rgba8unorm"))
         if self.backwardPass is None:
             self.backwardPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
+            # the fused K17 + Adam step keeps the gradient in registers; nothing in the trainer reads the packed copy (trainer.ts hands it to
+            # optimizer.step() only), so the step does not write it unless asked to (``keep_gradients``)
+            self.backwardPass.setGradientOutput(self.keep_gradients or not self.fuse_geometry_adam)
         else:
             self.backwardPass.setViewport(w, h)
         for more in self._more_op_sets:
