@@ -1,11 +1,13 @@
 // node bindings/napi/trainer_run.js <dir> -- drives bindings/ts/trainer.js (the reference-shaped Trainer over the N-API addon) on a
 // dataset written by tests/test_gpu_napi.py, with the view draws fixed by the test, and dumps the trained cloud and optimizer state
-// for a byte-for-byte comparison with the Python host's run of the same schedule.  Also exercises get_prefix_scanner /
-// get_dynamic_sorter and the pinned asynchronous read-back.
+// for a byte-for-byte comparison with the Python host's run of the same schedule.  meta.json selects the step's form: `views_per_step`
+// (a batched step), `lanes`, `pipeline_depth`, `comm` ('capi': the sliced exchange through the library's RCCL communicator in a world
+// of one), `keep_gradients`.  Also exercises get_prefix_scanner / get_dynamic_sorter and the pinned asynchronous read-back.
 'use strict';
 const fs = require('fs');
 const path = require('path');
 const hip = require(path.join(__dirname, '..', 'ts', 'webdgs_hip.js'));
+const parallel = require(path.join(__dirname, '..', 'ts', 'parallel.js'));
 const { Trainer } = require(path.join(__dirname, '..', 'ts', 'trainer.js'));
 
 const dir = process.argv[2];
@@ -24,26 +26,39 @@ async function main() {
     cameras.push({ camera: cams.slice(v * 68, v * 68 + 68), width: meta.width, height: meta.height });
     images.push({ texture: upload(imgBytes.subarray(v * imgSize, (v + 1) * imgSize)), width: meta.width, height: meta.height });
   }
-  // the view draws, in order: one per step, plus the metric views of a step that densifies
+  // the view draws, in order: views_per_step per step, plus the metric views of a step that densifies
   const draws = meta.draws.slice();
   let drawn = 0;
   const random = () => { if (drawn >= draws.length) throw new Error('more view draws than the schedule holds'); return (draws[drawn++] + 0.5) / meta.views; };
-  const t = new Trainer(dev, undefined, { random });
+  const exchange = meta.comm === 'capi' ? new parallel.CapiExchange(dev, hip.Communicator.uniqueId(), 1, 0) : new parallel.Exchange();
+  const t = new Trainer(dev, undefined, { random, viewsPerStep: meta.views_per_step || 1, lanes: meta.lanes || 0, pipelineDepth: meta.pipeline_depth || 1,
+    keepGradients: !!meta.keep_gradients, exchange });
   t.setDensifyPruneConfig(meta.densify);
   t.setPointCloud(pc);
   t.setDataset(cameras, images);
   t.start();
   const sizes = [t.getPointCount()];
-  for (let i = 0; i < meta.steps; i++) { await t.step(); sizes.push(t.getPointCount()); }
+  let staleRowsSeen = false;
+  for (let i = 0; i < meta.steps; i++) {
+    await t.step();
+    sizes.push(t.getPointCount());
+  }
+  t.drain();
   if (drawn !== draws.length) throw new Error(`drew ${drawn} views, schedule has ${draws.length}`);
   dev.synchronize();
   const n = t.getPointCount();
-  t.flushPointCloud();   // deferred SH writes: the rows are brought up to date before the host reads them
+  // deferred SH writes: a raw device copy of the rows (no hook) is stale, a host read through the buffer is current -- no flushPointCloud() call here
+  if (t.deferredSH) {
+    const raw = new Uint32Array(hip.addon.copyToHost(dev.handle, t.pointCloud.sh_buffer.ptr, n * 96));
+    const viaHook = new Uint32Array(dev.readBuffer(t.pointCloud.sh_buffer, n * 96));
+    for (let i = 0; i < raw.length && !staleRowsSeen; i++) if (raw[i] !== viaHook[i]) staleRowsSeen = true;
+  }
   fs.writeFileSync(path.join(dir, 'out_gaussians.bin'), Buffer.from(dev.readBuffer(t.pointCloud.gaussian_3d_buffer, n * 24)));
   fs.writeFileSync(path.join(dir, 'out_sh.bin'), Buffer.from(dev.readBuffer(t.pointCloud.sh_buffer, n * 96)));
   const st = t.optimizer.getStateBuffers();
   const rowBytes = { optPosBuffer: 48, optRotBuffer: 48, optScaleBuffer: 48, optOpacityBuffer: 12, paramSH: 192, stateSH: 384 };
   for (const k of Object.keys(rowBytes)) fs.writeFileSync(path.join(dir, `out_state_${k}.bin`), Buffer.from(dev.readBuffer(st[k], n * rowBytes[k])));
+  if (meta.keep_gradients) fs.writeFileSync(path.join(dir, 'out_gradients.bin'), Buffer.from(dev.readBuffer(t.backwardPass.getGradientsBuffer(), n * 32)));
 
   // ---- get_prefix_scanner / get_dynamic_sorter (prefix.ts:140, sort_dynamic.ts:252) and the pinned asynchronous read-back
   const count = 5000;
@@ -70,9 +85,12 @@ async function main() {
 
   fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
     last_densify: t.getLastDensifyPruneIteration(), next_densify: t.getNextDensifyPruneIteration(), iters_per_s: t.getItersPerSec(), scan_ok: scanOk, sort_ok: sortOk,
-    recorded_views: t.commandBuffers.size }));
+    recorded_views: t.commandBuffers.size, recorded_keys: Array.from(t.commandBuffers.keys()), lanes: t.lanes, op_sets: t.opSets, stale_rows_seen: staleRowsSeen,
+    exchange: exchange.name }));
+  const last = t.pointCloud;
   t.destroy();
-  pc.gaussian_3d_buffer.destroy(); pc.sh_buffer.destroy();
+  exchange.destroy();
+  last.gaussian_3d_buffer.destroy(); last.sh_buffer.destroy();
   for (const im of images) im.texture.destroy();
   dev.destroy();
   console.log('TRAINER_RUN_OK');

@@ -695,6 +695,118 @@ static napi_value commInfo(napi_env env, napi_callback_info info) {  // (comm) -
     return o;
 }
 
+
+// ---- additions of round 4: the fused single-view step, the view-batched K1 / K17, lane marks, per-kernel timing, RCCL groups --------
+static napi_value optimizerStepWithGeometry(napi_env env, napi_callback_info info) {  // (optimizer, backward, cameraPtr, gaussiansPtr, shPtr, tileCountsPtr)
+    ARGS(6);
+    WDGS_OK_OR_THROW(wdgs_optimizer_step_with_geometry((wdgs_optimizer*)get_ptr(env, argv[0]), (wdgs_tiled_backward*)get_ptr(env, argv[1]), get_ptr(env, argv[2]),
+                                                       get_ptr(env, argv[3]), get_ptr(env, argv[4]), get_ptr(env, argv[5])));
+    return js_undefined(env);
+}
+static napi_value optimizerApplyRepackedRows(napi_env env, napi_callback_info info) {  // (optimizer, rowsPtr, skipFirst, skipCount, guardPtr | null, gaussiansPtr, shPtr)
+    ARGS(7);
+    WDGS_OK_OR_THROW(wdgs_optimizer_apply_repacked_rows((wdgs_optimizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3]),
+                                                        get_ptr(env, argv[4]), get_ptr(env, argv[5]), get_ptr(env, argv[6])));
+    return js_undefined(env);
+}
+static napi_value tiledBackwardEncodeRaster(napi_env env, napi_callback_info info) {  // (op, predPtr, targetPtr, resources{...Ptr})
+    ARGS(4);
+    wdgs_tiled_backward_resources r;
+    read_backward_resources(env, argv[3], &r);
+    WDGS_OK_OR_THROW(wdgs_tiled_backward_encode_raster((wdgs_tiled_backward*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), &r));
+    return js_undefined(env);
+}
+static napi_value tiledBackwardEncodeGeometry(napi_env env, napi_callback_info info) {
+    // (op, cameraPtr, gaussiansPtr, into | null): into = {sums, visible, tileCounts, guard, overflowWord (pointers), first}
+    ARGS(4);
+    wdgs_view_accumulate a; std::memset(&a, 0, sizeof(a));
+    napi_valuetype t; napi_typeof(env, argv[3], &t);
+    const bool has = t == napi_object;
+    if (has) {
+        a.sums = prop_ptr(env, argv[3], "sums"); a.visible = prop_ptr(env, argv[3], "visible"); a.tile_counts = prop_ptr(env, argv[3], "tileCounts");
+        a.guard = prop_ptr(env, argv[3], "guard"); a.overflow_word = prop_ptr(env, argv[3], "overflowWord"); a.first = (int)prop_f64(env, argv[3], "first", 0);
+    }
+    WDGS_OK_OR_THROW(wdgs_tiled_backward_encode_geometry((wdgs_tiled_backward*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), has ? &a : nullptr));
+    return js_undefined(env);
+}
+static napi_value tiledBackwardSetGradientOutput(napi_env env, napi_callback_info info) {  // (op, enabled)
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_tiled_backward_set_gradient_output((wdgs_tiled_backward*)get_ptr(env, argv[0]), (int)get_u32(env, argv[1])));
+    return js_undefined(env);
+}
+// a JS array of BigInt handles / device pointers -> a C array (at most WDGS_MAX_BATCH_VIEWS entries)
+static uint32_t read_ptr_array(napi_env env, napi_value arr, void** out) {
+    uint32_t n = 0;
+    napi_get_array_length(env, arr, &n);
+    if (n > WDGS_MAX_BATCH_VIEWS) n = WDGS_MAX_BATCH_VIEWS + 1;
+    for (uint32_t i = 0; i < n && i < WDGS_MAX_BATCH_VIEWS; i++) { napi_value v; napi_get_element(env, arr, i, &v); out[i] = get_ptr(env, v); }
+    return n;
+}
+static napi_value tiledForwardProjectViews(napi_env env, napi_callback_info info) {  // (forwardHandles[], cameraPtrs[], gaussiansPtr, shPtr)
+    ARGS(4);
+    void* ops[WDGS_MAX_BATCH_VIEWS]; void* cams[WDGS_MAX_BATCH_VIEWS];
+    const uint32_t n = read_ptr_array(env, argv[0], ops), m = read_ptr_array(env, argv[1], cams);
+    if (n != m || n == 0 || n > WDGS_MAX_BATCH_VIEWS) { napi_throw_range_error(env, nullptr, "projectViews: 1..16 passes and as many cameras"); return nullptr; }
+    WDGS_OK_OR_THROW(wdgs_tiled_forward_project_views((wdgs_tiled_forward* const*)ops, (const void* const*)cams, n, get_ptr(env, argv[2]), get_ptr(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value tiledForwardEncodeProjected(napi_env env, napi_callback_info info) { ARGS(1); WDGS_OK_OR_THROW(wdgs_tiled_forward_encode_projected((wdgs_tiled_forward*)get_ptr(env, argv[0]))); return js_undefined(env); }
+static napi_value tiledForwardIsProjected(napi_env env, napi_callback_info info) { ARGS(1); return make_u32(env, (uint32_t)wdgs_tiled_forward_is_projected((const wdgs_tiled_forward*)get_ptr(env, argv[0]))); }
+static napi_value tiledBackwardGeometryViews(napi_env env, napi_callback_info info) {
+    // (backwardHandles[], cameraPtrs[], tileCountsPtrs[], overflowWordPtrs[], gaussiansPtr, sumsPtr, visiblePtr, guardPtr, writeGradients, continues)
+    ARGS(10);
+    void* ops[WDGS_MAX_BATCH_VIEWS]; void* cams[WDGS_MAX_BATCH_VIEWS]; void* counts[WDGS_MAX_BATCH_VIEWS]; void* words[WDGS_MAX_BATCH_VIEWS];
+    const uint32_t n = read_ptr_array(env, argv[0], ops);
+    if (n == 0 || n > WDGS_MAX_BATCH_VIEWS || read_ptr_array(env, argv[1], cams) != n || read_ptr_array(env, argv[2], counts) != n || read_ptr_array(env, argv[3], words) != n) {
+        napi_throw_range_error(env, nullptr, "geometryViews: 1..16 passes and as many cameras, tile counts and overflow words");
+        return nullptr;
+    }
+    WDGS_OK_OR_THROW(wdgs_tiled_backward_encode_geometry_views((wdgs_tiled_backward* const*)ops, (const void* const*)cams, (const void* const*)counts, (const void* const*)words, n,
+                                                               get_ptr(env, argv[4]), get_ptr(env, argv[5]), get_ptr(env, argv[6]), get_ptr(env, argv[7]),
+                                                               (int)get_u32(env, argv[8]), (int)get_u32(env, argv[9])));
+    return js_undefined(env);
+}
+static napi_value deviceLaneMark(napi_env env, napi_callback_info info) {  // (device, lane, mark)
+    ARGS(3);
+    WDGS_OK_OR_THROW(wdgs_device_lane_mark((wdgs_device*)get_ptr(env, argv[0]), (int)get_u32(env, argv[1]), (int)get_u32(env, argv[2])));
+    return js_undefined(env);
+}
+static napi_value deviceLaneWaitMark(napi_env env, napi_callback_info info) {  // (device, lane, mark)
+    ARGS(3);
+    WDGS_OK_OR_THROW(wdgs_device_lane_wait_mark((wdgs_device*)get_ptr(env, argv[0]), (int)get_u32(env, argv[1]), (int)get_u32(env, argv[2])));
+    return js_undefined(env);
+}
+static napi_value deviceKernelTimes(napi_env env, napi_callback_info info) {
+    // (device, op): 0 profiling off | 1 profiling on | 2 reset | 3 read -> {name: {launches, totalMs}} (after a synchronize)
+    ARGS(2);
+    wdgs_device* d = (wdgs_device*)get_ptr(env, argv[0]);
+    const uint32_t op = get_u32(env, argv[1]);
+    if (op <= 1) { WDGS_OK_OR_THROW(wdgs_device_set_profiling(d, (int)op)); return js_undefined(env); }
+    if (op == 2) { WDGS_OK_OR_THROW(wdgs_device_reset_kernel_times(d)); return js_undefined(env); }
+    static wdgs_kernel_time recs[128];
+    uint32_t n = 0;
+    WDGS_OK_OR_THROW(wdgs_device_get_kernel_times(d, recs, 128, &n));
+    napi_value o; napi_create_object(env, &o);
+    for (uint32_t i = 0; i < n && i < 128; i++) {
+        napi_value r, ms; napi_create_object(env, &r);
+        set_prop(env, r, "launches", make_u32(env, recs[i].launches));
+        napi_create_double(env, recs[i].total_ms, &ms); set_prop(env, r, "totalMs", ms);
+        char name[49]; std::memcpy(name, recs[i].name, 48); name[48] = 0;
+        set_prop(env, o, name, r);
+    }
+    return o;
+}
+static napi_value copyBufferToBuffer(napi_env env, napi_callback_info info) {  // (device, dstPtr, srcPtr, byteLength): encoder.copyBufferToBuffer
+    ARGS(4);
+    WDGS_OK_OR_THROW(wdgs_copy_buffer_to_buffer((wdgs_device*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), (size_t)get_f64(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value commGroup(napi_env env, napi_callback_info info) {  // (end: 0 = wdgs_comm_group_start, 1 = wdgs_comm_group_end)
+    ARGS(1);
+    if (get_u32(env, argv[0])) WDGS_OK_OR_THROW(wdgs_comm_group_end()); else WDGS_OK_OR_THROW(wdgs_comm_group_start());
+    return js_undefined(env);
+}
+
 #define EXPORT_FN(name)                                                              \
     do {                                                                             \
         napi_value fn;                                                               \
@@ -723,6 +835,9 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(optimizerSetGuard); EXPORT_FN(optimizerStepF32Range); EXPORT_FN(optimizerStateChanged); EXPORT_FN(storeGradients); EXPORT_FN(guardAccumulate);
     EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder); EXPORT_FN(queueMark); EXPORT_FN(queueWait); EXPORT_FN(tiledForwardResize); EXPORT_FN(tiledBackwardResize);
     EXPORT_FN(applyRepackedRows); EXPORT_FN(commExchangeGradients); EXPORT_FN(commAllgatherRows); EXPORT_FN(commBroadcast); EXPORT_FN(commInfo);
+    EXPORT_FN(optimizerStepWithGeometry); EXPORT_FN(optimizerApplyRepackedRows); EXPORT_FN(tiledBackwardEncodeRaster); EXPORT_FN(tiledBackwardEncodeGeometry);
+    EXPORT_FN(tiledBackwardSetGradientOutput); EXPORT_FN(tiledForwardProjectViews); EXPORT_FN(tiledForwardEncodeProjected); EXPORT_FN(tiledForwardIsProjected);
+    EXPORT_FN(tiledBackwardGeometryViews); EXPORT_FN(deviceLaneMark); EXPORT_FN(deviceLaneWaitMark); EXPORT_FN(deviceKernelTimes); EXPORT_FN(commGroup); EXPORT_FN(copyBufferToBuffer);
     return exports;
 }
 NAPI_MODULE(webdgs_napi, Init)

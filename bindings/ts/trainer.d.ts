@@ -1,5 +1,8 @@
 // Typings of trainer.js: the public surface of the reference's Trainer (src/trainer.ts:177-566).
 import { AdamHyperparameters, HipBuffer, HipDevice, OptimizerInitialState, PointCloud, TrainingConfig } from './webdgs_hip';
+import { CameraData } from './loaders';
+import { LoadedImage } from './images';
+import { Exchange } from './parallel';
 
 export interface DensifyPruneTrainingConfig {   // trainer.ts:23-40
   schedule: { enabled: boolean; warmupIterations: number; interval: number; stopIterations: number };
@@ -10,17 +13,38 @@ export interface TrainingView { camera: Float32Array; width: number; height: num
 export interface TrainingImage { texture: HipBuffer; width: number; height: number; }    // rgba8, row-major (LoadedImage.texture)
 export interface PointCloudSwapRequest { pointCloud: PointCloud; optimizerInitialState?: OptimizerInitialState; }
 
+export interface TrainerOptions {
+  random?: () => number; useCommandBuffers?: boolean; maxTileEntries?: number; reusePasses?: boolean; deferredSH?: boolean;
+  /** the single-view step runs K17 + Adam + re-pack as one kernel (default true); keepGradients also fills backwardPass.getGradientsBuffer() */
+  fuseGeometryAdam?: boolean; keepGradients?: boolean;
+  /** 1: every step awaits its own completion (trainer.ts:639-645); 2..4: a step awaits the one pipelineDepth - 1 submissions ago */
+  pipelineDepth?: number;
+  /** views per rank per global step (a batched step: BASELINE config c4), device lanes they are dealt to (default 3), view-batched K1 / K17 (default on) */
+  viewsPerStep?: number; lanes?: number; batchViews?: boolean;
+  /** view-sharded data parallelism (parallel.js) */
+  worldSize?: number; rank?: number; exchange?: Exchange;
+}
 export class Trainer {
-  constructor(device: HipDevice, trainingConfig?: TrainingConfig, options?: { random?: () => number; useCommandBuffers?: boolean; maxTileEntries?: number; reusePasses?: boolean; deferredSH?: boolean });
-  /** Deferred SH writes: brings pointCloud.sh_buffer up to date before a host read, an export, or a foreign forward pass (no reference counterpart). */
+  constructor(device: HipDevice, trainingConfig?: TrainingConfig, options?: TrainerOptions);
+  /** Deferred SH writes: brings pointCloud.sh_buffer up to date for a device-side reader of the raw rows (host reads and forward passes built on the cloud follow by themselves). */
   flushPointCloud(): void;
+  /** step() on a given global batch of views (worldSize * viewsPerStep indices); no reference counterpart. */
+  stepViews(viewIds?: number[]): Promise<void>;
+  /** Records every view's command buffers up front; the number of steps taken depends on the dataset size only. */
+  warmupCommandBuffers(): Promise<number>;
+  /** Awaits every step still in flight (pipelineDepth > 1). */
+  drain(): void;
+  /** Data parallelism: every owner broadcasts its slice of the optimizer state (before a densify rebuild, an export). */
+  syncOptimizerState(): void;
+  pipelineDepth: number; keepGradients: boolean; fuseGeometryAdam: boolean; useCommandBuffers: boolean;
+  readonly lanes: number; readonly viewsPerRank: number; readonly worldSize: number; readonly rank: number;
   random: () => number;
   setPointCloud(pointCloud: PointCloud): void;
   requestPointCloudSwap(pointCloud: PointCloud, optimizerInitialState?: OptimizerInitialState): void;
   consumePointCloudSwapRequest(): PointCloudSwapRequest | null;
   requestResizeTo(numPoints: number): void;
   applyPointCloudSwap(request: PointCloudSwapRequest): void;
-  setDataset(cameras: TrainingView[], images: TrainingImage[]): void;
+  setDataset(cameras: (TrainingView | CameraData)[], images: (TrainingImage | LoadedImage)[]): void;
   getTrainingConfig(): TrainingConfig; setTrainingConfig(next: Partial<TrainingConfig>): void;
   getOptimizerHyperparameters(): AdamHyperparameters; setOptimizerHyperparameters(next: Partial<AdamHyperparameters>): void;
   setDensifyPruneConfig(next: Partial<DensifyPruneTrainingConfig>): void;
@@ -33,4 +57,5 @@ export class Trainer {
 }
 export function cameraBlockFor(block: Float32Array, width: number, height: number): Float32Array;
 export function mat4Inverse(m: ArrayLike<number>): Float32Array;
+export function projectionMatrix(znear: number, zfar: number, fovX: number, fovY: number): Float32Array;
 export const DEFAULT_DENSIFY: DensifyPruneTrainingConfig;

@@ -10,66 +10,19 @@
  * viewport (SURVEY Q19); every metric view renders with its own camera because uploads are stream-ordered (Q12); the swap a densify
  * requests is applied inside the step that produced it (the reference defers it to the next animation frame, main.ts:587-593).
  * The view draws go through `this.random` (default Math.random, as trainer.ts:573 and 394), so a test can fix them.
+ *
+ * New, with no counterpart in the reference (whose step is one view on one GPU) and at the level of the Python host
+ * (webdgs_amd/trainer.py): `viewsPerStep` > 1 -- a BATCHED step: K1 of all the step's views in one launch, the views' scan ... K16 dealt
+ * to device lanes, K17 of all views in one launch into the step's fp32 gradient block, one Adam; `worldSize` > 1 -- view-sharded data
+ * parallelism through parallel.js (reduce-scatter -> Adam on the owned slice -> all-gather, BASELINE config c4); `pipelineDepth` 2 --
+ * step() resolves once the PREVIOUS step has finished (tickets: queue.mark / queue.wait), so the device never idles across the step
+ * boundary; the single-view step runs K17 + Adam + re-pack as ONE kernel (Optimizer.stepWithGeometry).  Results are bit-identical to the
+ * one-lane, depth-1, unfused forms (tests/test_gpu_napi.py compares this host with the Python host byte for byte).
  */
 const hip = require('./webdgs_hip.js');
+const parallel = require('./parallel.js');
 
-/** wgpu-matrix 3.2.0 mat4.inverse (the reference's dependency; cofactor expansion in binary64 on the Float32Array's values). */
-function mat4Inverse(m) {
-  const m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3], m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
-  const m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11], m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
-  const tmp0 = m22 * m33, tmp1 = m32 * m23, tmp2 = m12 * m33, tmp3 = m32 * m13, tmp4 = m12 * m23, tmp5 = m22 * m13;
-  const tmp6 = m02 * m33, tmp7 = m32 * m03, tmp8 = m02 * m23, tmp9 = m22 * m03, tmp10 = m02 * m13, tmp11 = m12 * m03;
-  const tmp12 = m20 * m31, tmp13 = m30 * m21, tmp14 = m10 * m31, tmp15 = m30 * m11, tmp16 = m10 * m21, tmp17 = m20 * m11;
-  const tmp18 = m00 * m31, tmp19 = m30 * m01, tmp20 = m00 * m21, tmp21 = m20 * m01, tmp22 = m00 * m11, tmp23 = m10 * m01;
-  const t0 = (tmp0 * m11 + tmp3 * m21 + tmp4 * m31) - (tmp1 * m11 + tmp2 * m21 + tmp5 * m31);
-  const t1 = (tmp1 * m01 + tmp6 * m21 + tmp9 * m31) - (tmp0 * m01 + tmp7 * m21 + tmp8 * m31);
-  const t2 = (tmp2 * m01 + tmp7 * m11 + tmp10 * m31) - (tmp3 * m01 + tmp6 * m11 + tmp11 * m31);
-  const t3 = (tmp5 * m01 + tmp8 * m11 + tmp11 * m21) - (tmp4 * m01 + tmp9 * m11 + tmp10 * m21);
-  const d = 1 / (m00 * t0 + m10 * t1 + m20 * t2 + m30 * t3);
-  const o = new Float32Array(16);
-  o[0] = d * t0; o[1] = d * t1; o[2] = d * t2; o[3] = d * t3;
-  o[4] = d * ((tmp1 * m10 + tmp2 * m20 + tmp5 * m30) - (tmp0 * m10 + tmp3 * m20 + tmp4 * m30));
-  o[5] = d * ((tmp0 * m00 + tmp7 * m20 + tmp8 * m30) - (tmp1 * m00 + tmp6 * m20 + tmp9 * m30));
-  o[6] = d * ((tmp3 * m00 + tmp6 * m10 + tmp11 * m30) - (tmp2 * m00 + tmp7 * m10 + tmp10 * m30));
-  o[7] = d * ((tmp4 * m00 + tmp9 * m10 + tmp10 * m20) - (tmp5 * m00 + tmp8 * m10 + tmp11 * m20));
-  o[8] = d * ((tmp12 * m13 + tmp15 * m23 + tmp16 * m33) - (tmp13 * m13 + tmp14 * m23 + tmp17 * m33));
-  o[9] = d * ((tmp13 * m03 + tmp18 * m23 + tmp21 * m33) - (tmp12 * m03 + tmp19 * m23 + tmp20 * m33));
-  o[10] = d * ((tmp14 * m03 + tmp19 * m13 + tmp22 * m33) - (tmp15 * m03 + tmp18 * m13 + tmp23 * m33));
-  o[11] = d * ((tmp17 * m03 + tmp20 * m13 + tmp23 * m23) - (tmp16 * m03 + tmp21 * m13 + tmp22 * m23));
-  o[12] = d * ((tmp14 * m22 + tmp17 * m32 + tmp13 * m12) - (tmp16 * m32 + tmp12 * m12 + tmp15 * m22));
-  o[13] = d * ((tmp20 * m32 + tmp12 * m02 + tmp19 * m22) - (tmp18 * m22 + tmp21 * m32 + tmp13 * m02));
-  o[14] = d * ((tmp18 * m12 + tmp23 * m32 + tmp15 * m02) - (tmp22 * m32 + tmp14 * m02 + tmp19 * m12));
-  o[15] = d * ((tmp22 * m22 + tmp16 * m02 + tmp21 * m12) - (tmp20 * m12 + tmp23 * m22 + tmp17 * m02));
-  return o;
-}
-
-/** get_projection_matrix (src/camera/camera.ts:29-56), column-major after its transpose. */
-function projectionMatrix(znear, zfar, fovX, fovY) {
-  const tanY = Math.tan(fovY / 2), tanX = Math.tan(fovX / 2);
-  const top = tanY * znear, right = tanX * znear;
-  const p = new Float32Array(16);
-  p[0] = 2 * znear / (2 * right);
-  p[5] = -2 * znear / (2 * top);
-  p[10] = zfar / (zfar - znear);
-  p[11] = 1;
-  p[14] = -(zfar * znear) / (zfar - znear);
-  return p;
-}
-
-/** Camera.set_preset + on_update_canvas + update_buffer (camera.ts:138-205) for a view given as its 68-float block, on a canvas of
- *  width x height: the pose is kept, fovY = 2 atan(height_view / (2 fy_view)), focal = 0.5 height / tan(fovY / 2). */
-function cameraBlockFor(block, width, height) {
-  const fovY = 2 * Math.atan(block[65] / (2 * block[67]));
-  const focal = 0.5 * height / Math.tan(fovY * 0.5);
-  const fovX = 2 * Math.atan(width / (2 * focal));
-  const out = new Float32Array(68);
-  out.set(block.subarray(0, 16), 0);
-  out.set(projectionMatrix(0.01, 100, fovX, fovY), 32);
-  out.set(mat4Inverse(out.subarray(0, 16)), 16);
-  out.set(mat4Inverse(out.subarray(32, 48)), 48);
-  out[64] = width; out[65] = height; out[66] = focal; out[67] = focal;
-  return out;
-}
+const { mat4Inverse, projectionMatrix, cameraBlockFor } = require('./camera-math.js');
 
 const DEFAULT_DENSIFY = {   // trainer.ts:147-164
   schedule: { enabled: true, warmupIterations: 500, interval: 100, stopIterations: 15000 },
@@ -78,17 +31,40 @@ const DEFAULT_DENSIFY = {   // trainer.ts:147-164
 };
 
 class Trainer {
+  /** options: random, useCommandBuffers, maxTileEntries, reusePasses, deferredSH, fuseGeometryAdam, keepGradients, pipelineDepth (1..4),
+   *  viewsPerStep (views per rank per global step), lanes (device lanes of a batched step; default 3), batchViews (view-batched K1 / K17;
+   *  default on), worldSize / rank / exchange (parallel.js; default: from the environment). */
   constructor(device, trainingConfig, options) {
+    const o = options || {};
     this.device = device;
     this.trainingConfig = Object.assign({ lambda_l1: 0.8, lambda_l2: 0.0, lambda_dssim: 0.2 }, trainingConfig || {});  // trainer.ts:100-104
     this.optimizerHyperparameters = Object.assign({}, hip.DEFAULT_ADAM_HYPERPARAMETERS);
-    this.random = (options && options.random) || Math.random;
-    this.useCommandBuffers = !(options && options.useCommandBuffers === false);
-    this.maxTileEntries = (options && options.maxTileEntries) || 0;
-    this.reusePasses = !(options && options.reusePasses === false);   // applyPointCloudSwap resizes the passes instead of rebuilding them
+    this.random = o.random || Math.random;
+    this.useCommandBuffers = o.useCommandBuffers !== false;
+    this.maxTileEntries = o.maxTileEntries || 0;
+    this.reusePasses = o.reusePasses !== false;   // applyPointCloudSwap resizes the passes instead of rebuilding them
     // Adam writes the trained SH-DC halves to a compact array that K1 reads instead of 6 bytes into every 96-byte SH row (Optimizer.setDeferredSH);
-    // the rows are flushed at hand-over points (flushPointCloud).  Results are identical either way.
-    this.deferredSH = !(options && options.deferredSH === false);
+    // the rows are flushed at hand-over points (flushPointCloud; host reads and forward passes built on the cloud follow by themselves).
+    this.deferredSH = o.deferredSH !== false;
+    this.fuseGeometryAdam = o.fuseGeometryAdam !== false;   // the single-view step runs K17, Adam and the re-pack as one kernel
+    this.keepGradients = !!o.keepGradients;                 // ... and still fills backwardPass.getGradientsBuffer() (nothing in the trainer reads it)
+    this.gradientOutputApplied = null;
+    this.pipelineDepth = Math.max(1, Math.min(Math.floor(o.pipelineDepth || 1), 4));
+    this.tickets = [];
+    this.worldSize = Math.max(1, Math.floor(o.worldSize || 1)); this.rank = Math.floor(o.rank || 0);
+    this.viewsPerRank = Math.max(1, Math.floor(o.viewsPerStep || o.viewsPerRank || 1));
+    this.exchange = o.exchange || new parallel.Exchange();
+    if (this.worldSize > 1 && (this.exchange.worldSize !== this.worldSize || this.exchange.rank !== this.rank)) {
+      throw new Error(`exchange is rank ${this.exchange.rank} of ${this.exchange.worldSize}, trainer is rank ${this.rank} of ${this.worldSize}`);
+    }
+    // sliced step (reduce-scatter / owned-slice Adam / all-gather): any real exchange, also a forced one in a world of one
+    this.sliced = this.worldSize > 1 || !!this.exchange.force;
+    const lanes = o.lanes === undefined || o.lanes === null || o.lanes === 0 ? Trainer.DEFAULT_LANES : o.lanes;
+    this.lanes = Math.max(1, Math.min(Math.floor(lanes), this.viewsPerRank, hip.MAX_LANES));
+    this.batchViews = this.viewsPerRank > 1 && o.batchViews !== false;
+    this.opSets = this.batchViews ? Math.min(this.viewsPerRank, hip.MAX_BATCH_VIEWS) : this.lanes;
+    this.moreOpSets = [];   // [forwardPass, rasterizer, backwardPass] of op sets 1.. (set 0 is the three below)
+    this.dpGrad = null; this.dpVisible = null; this.dpRows = null; this.dpFlag = null; this.stateSliced = false;
     this.dcWords = null;
     this.forwardPass = null; this.rasterizer = null; this.backwardPass = null; this.optimizer = null; this.pointCloud = null;
     this.metricsForwardPass = null; this.metricsRasterizer = null; this.metricsPass = null;
@@ -116,7 +92,10 @@ class Trainer {
     if (!this.pointCloud) return;
     this.requestPointCloudSwap(hip.allocatePointCloudLike(this.device, this.pointCloud, { numPoints }));
   }
+  destroyMoreOpSets() { for (const set of this.moreOpSets) for (const op of set) op.destroy(); this.moreOpSets = []; }
+  forwardPasses() { return [this.forwardPass, this.metricsForwardPass].concat(this.moreOpSets.map((m) => m[0])).filter((p) => p); }
   applyPointCloudSwap(request) {   // trainer.ts:201-237
+    this.drain();
     this.device.synchronize();
     const oldParams = this.optimizer ? this.optimizer.getHyperparameters() : null;
     this.invalidateCommandBuffers();
@@ -125,29 +104,44 @@ class Trainer {
     this.pointCloud = request.pointCloud;
     // The reference destroys every pass and constructs new ones; the passes here can follow a cloud of another size
     // (setPointCloud: buffers reused, or re-allocated with headroom), so only the optimizer -- which adopts the rebuilt state -- is new.
-    const passes = [this.forwardPass, this.backwardPass, this.metricsForwardPass, this.metricsPass].filter((p) => p);
-    const kept = this.reusePasses && old && !this.recreateBackward && passes.every((p) => p.setPointCloud(this.pointCloud));
+    const passes = [this.forwardPass, this.backwardPass, this.metricsForwardPass, this.metricsPass];
+    for (const m of this.moreOpSets) passes.push(m[0], m[2]);
+    const kept = this.reusePasses && old && !this.recreateBackward && passes.filter((p) => p).every((p) => p.setPointCloud(this.pointCloud));
     if (!kept) {
       for (const name of ['forwardPass', 'rasterizer', 'backwardPass', 'metricsForwardPass', 'metricsRasterizer', 'metricsPass']) {
         if (this[name]) this[name].destroy();
         this[name] = null;
       }
+      this.destroyMoreOpSets();
+      this.gradientOutputApplied = null;
     }
     this.optimizer = new hip.Optimizer(this.device, this.pointCloud, oldParams || this.optimizerHyperparameters, request.optimizerInitialState);
     this.optimizerHyperparameters = this.optimizer.getHyperparameters();
     this.dcWords = this.deferredSH ? this.optimizer.setDeferredSH(this.pointCloud, true) : null;
-    for (const fw of [this.forwardPass, this.metricsForwardPass]) if (fw) fw.setDcSource(this.dcWords);
+    for (const fw of this.forwardPasses()) fw.setDcSource(this.dcWords);
     if (old && old !== this.pointCloud) { old.gaussian_3d_buffer.destroy(); old.sh_buffer.destroy(); }
+    for (const name of ['dpGrad', 'dpVisible', 'dpRows', 'dpFlag']) { if (this[name]) this[name].destroy(); this[name] = null; }
+    this.stateSliced = false;
     this.ensurePipelines(this.lastViewportWidth, this.lastViewportHeight);
   }
-  /** Brings pointCloud.sh_buffer up to date with what has been trained (deferred SH writes): call before reading the cloud's SH buffer on the
-   *  host, exporting it, or rendering it with a forward pass that is not this trainer's. */
+  /** Brings pointCloud.sh_buffer up to date with what has been trained (deferred SH writes).  Host reads of the buffer and forward passes built
+   *  on the cloud (a Viewer's) follow by themselves; call this before a device-side reader of the raw rows that is neither. */
   flushPointCloud() { if (this.optimizer && this.pointCloud) this.optimizer.flushSH(this.pointCloud); }
-  /** cameras[i] pairs with images[i] (trainer.ts:575-577): { camera: Float32Array(68), width, height } and { texture: HipBuffer, width, height }. */
+  /** cameras[i] pairs with images[i] (trainer.ts:575-577).  Accepted: ready entries { camera: Float32Array(68), width, height } /
+   *  { texture: HipBuffer, width, height }, or the loaders' own shapes -- CameraData (loaders.js; the 68-float block is then built for the
+   *  image size as Camera.set_preset + update_buffer do, trainer.ts:583-586) and LoadedImage (images.js: { bitmap, width, height }). */
   setDataset(cameras, images) {
-    this.trainCameras = cameras.slice(); this.images = images.slice();
+    this.drain();
+    const imgs = images.map((im) => {
+      if (im.texture) return im;
+      const tex = this.device.createBuffer({ size: 4 * im.width * im.height, label: 'gt image' });
+      this.device.queue.writeBuffer(tex, 0, im.bitmap);
+      return Object.assign({}, im, { texture: tex });
+    });
+    const cams = cameras.map((c, i) => (c.camera ? c : Object.assign({}, c, { camera: require('./loaders.js').cameraUniforms(c, imgs[i].width, imgs[i].height) })));
+    this.trainCameras = cams; this.images = imgs;
     for (const b of this.cameraBuffers) b.destroy();
-    this.cameraBuffers = this.trainCameras.map((c) => {
+    this.cameraBuffers = this.trainCameras.map((c) => {   // one resident 272-byte block per view (the reference rewrites a single uniform buffer)
       const b = this.device.createBuffer({ size: 272, label: 'camera uniform' });
       this.device.queue.writeBuffer(b, 0, c.camera);
       return b;
@@ -170,7 +164,7 @@ class Trainer {
     if (!this.pointCloud || this.trainCameras.length === 0) { console.log('Cannot start training: Missing point cloud or dataset.'); return; }
     this.isTraining = true; this.iteration = 0; this.stepItersPerSec = 0; this.stepMs = 0; this.lastDensifyPruneIteration = null;
   }
-  stop() { this.isTraining = false; }
+  stop() { this.isTraining = false; if (this.device.handle !== null && this.tickets.length) this.drain(); }
   getIsTraining() { return this.isTraining; }
   setMaxIterations(n) { this.maxIterations = Math.max(1, Math.floor(n)); }
   getMaxIterations() { return this.maxIterations; }
@@ -189,10 +183,26 @@ class Trainer {
     return next <= stop ? next : null;
   }
 
+  /** Recorded kernels bake pointers, viewport, hyper-parameters and loss weights: any change drops the recordings (after the steps still in
+   *  flight, which replay them, have finished). */
   invalidateCommandBuffers() {
+    let deferred = null;
+    if (this.tickets.length && this.device.handle !== null) {
+      this.tickets = [];
+      try { this.device.synchronize(); } catch (e) { deferred = e; }
+    }
     for (const c of this.commandBuffers.values()) c.destroy();
     this.commandBuffers.clear();
     this.eagerSteps = 0;
+    if (deferred) throw deferred;
+  }
+
+  newOpSet(w, h) {
+    const fw = new hip.TiledForwardPass(this.device, this.pointCloud, this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer,
+      { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+    fw.setDcSource(this.dcWords);
+    return [fw, new hip.TiledRasterizer({ device: this.device, forwardPass: fw, format: 'rgba8unorm' }),
+      new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig })];
   }
 
   ensurePipelines(width, height) {   // trainer.ts:662-692 (the rasterizer follows the viewport here: SURVEY Q19)
@@ -208,10 +218,13 @@ class Trainer {
     if (!this.backwardPass || this.recreateBackward) {
       if (this.backwardPass) this.backwardPass.destroy();
       this.backwardPass = new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig });
-      this.recreateBackward = false;
+      for (const m of this.moreOpSets) { m[2].destroy(); m[2] = new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig }); }
+      this.recreateBackward = false; this.gradientOutputApplied = null;
     } else this.backwardPass.setViewport(w, h);
+    for (const m of this.moreOpSets) { m[0].setViewport(w, h); m[2].setViewport(w, h); }
+    while (this.moreOpSets.length < this.opSets - 1) this.moreOpSets.push(this.newOpSet(w, h));
     // a step whose tile-entry list overflowed is skipped on the device and reported by the next synchronize()
-    this.optimizer.setGuard(this.forwardPass.getStatsBuffer(), 8);
+    if (this.optimizer && this.worldSize * this.viewsPerRank === 1) this.optimizer.setGuard(this.forwardPass.getStatsBuffer(), 8);
   }
 
   ensureMetricsPipelines(baseWidth, baseHeight) {   // trainer.ts:330-371
@@ -229,52 +242,87 @@ class Trainer {
     return { width: w, height: h };
   }
 
-  encodeView(encoder, index) {   // trainer.ts:606-628
+  opsOf(opSet) { return opSet > 0 ? this.moreOpSets[opSet - 1] : [this.forwardPass, this.rasterizer, this.backwardPass]; }
+
+  /** trainer.ts:606-628 for one view on one op set.  geometry = false: the view ends with K16 (K17 follows separately: fused with Adam, or batched);
+   *  projected = true: K1 ran for all the views of the step at once (hip.projectViews), scan / emit / sort remain. */
+  encodeView(encoder, index, opSet, geometry, projected) {
+    const ops = this.opsOf(opSet || 0), forwardPass = ops[0], rasterizer = ops[1], backwardPass = ops[2];
     const image = this.images[index], cam = this.cameraBuffers[index];
-    this.forwardPass.setCameraBuffer(cam);
-    this.forwardPass.encode(encoder);
-    this.rasterizer.encode(encoder, image.width, image.height);
-    this.backwardPass.encode(encoder, this.rasterizer.getOutputTextureView(), image.texture, {
-      splatBuffer: this.forwardPass.getResources().splatBuffer, tileOffsetsBuffer: this.rasterizer.getTileOffsetsBuffer(),
-      tileIndicesBuffer: this.forwardPass.getSortedIndicesBuffer(), cameraBuffer: cam,
-      alphaTexture: this.rasterizer.getAlphaTextureView(), nContribTexture: this.rasterizer.getNContribTextureView() });
-    this.optimizer.step(encoder, this.pointCloud, this.backwardPass.getGradientsBuffer(), this.forwardPass.getResources().tileCountsBuffer);
+    forwardPass.setCameraBuffer(cam);
+    if (projected) forwardPass.encodeProjected(encoder); else forwardPass.encode(encoder);
+    rasterizer.encode(encoder, image.width, image.height);
+    const res = { splatBuffer: forwardPass.getResources().splatBuffer, tileOffsetsBuffer: rasterizer.getTileOffsetsBuffer(),
+      tileIndicesBuffer: forwardPass.getSortedIndicesBuffer(), cameraBuffer: cam,
+      alphaTexture: rasterizer.getAlphaTextureView(), nContribTexture: rasterizer.getNContribTextureView() };
+    if (geometry !== false) backwardPass.encode(encoder, rasterizer.getOutputTextureView(), image.texture, res);
+    else backwardPass.encodeRaster(encoder, rasterizer.getOutputTextureView(), image.texture, res);
   }
 
-  /** One training iteration (trainer.ts:568-660). */
-  async step() {
+  /** Submits the command buffer recorded under `key`; the first time, `encode(encoder)` is encoded -- eagerly while the pipelines still
+   *  allocate on first use, into a recorded command buffer (HIP graph) afterwards.  True if it was replayed. */
+  run(key, encode) {
+    let cmd = this.commandBuffers.get(key);
+    if (cmd) { this.device.queue.submit([cmd]); return true; }
+    const record = this.useCommandBuffers && this.eagerSteps >= 1;
+    const encoder = this.device.createCommandEncoder({ label: 'trainer-' + key, record });
+    try {
+      encode(encoder);
+      cmd = encoder.finish();
+    } catch (e) {
+      encoder.abort();
+      throw e;
+    }
+    if (record) this.commandBuffers.set(key, cmd);
+    this.device.queue.submit([cmd]);
+    return false;
+  }
+
+  /** Records every view's command buffers up front (the first pass over a dataset does this anyway; calling it before a timed region keeps
+   *  recording out of it).  The number of steps taken is a function of the dataset size ONLY: under data parallelism every step is a
+   *  collective, so all ranks must take the same number of them. */
+  async warmupCommandBuffers() {
+    if (!this.useCommandBuffers || !this.isTraining || !this.pointCloud) return 0;
+    const nViews = this.worldSize * this.viewsPerRank;
+    let taken = 0;
+    for (let v = 0; v < this.trainCameras.length; v++) {
+      for (let r = 0; r < (v === 0 ? 2 : 1); r++) { await this.stepViews(new Array(nViews).fill(v)); taken++; }
+    }
+    return taken;
+  }
+
+  /** One training iteration (trainer.ts:568-660): the views are drawn with this.random, as the reference picks Math.random() per step. */
+  async step() { return this.stepViews(undefined); }
+
+  /** step() on a given global batch of views (worldSize * viewsPerStep indices; with worldSize > 1 each rank takes its shard). */
+  async stepViews(viewIds) {
     if (!this.isTraining || !this.pointCloud) return;
-    const stepStart = Date.now() + 0;
     const t0 = process.hrtime();
-    const idx = Math.floor(this.random() * this.trainCameras.length);
-    const image = this.images[idx];
+    const nViews = this.worldSize * this.viewsPerRank;
+    if (!viewIds) { viewIds = []; for (let i = 0; i < nViews; i++) viewIds.push(Math.floor(this.random() * this.trainCameras.length)); }
+    const mine = parallel.shardViews(viewIds, this.rank, this.worldSize);
+    const image = this.images[mine[0]];
     this.ensurePipelines(image.width, image.height);
 
     const s = this.densifyPruneConfig.schedule;   // trainer.ts:593-601: checked on iteration + 1
     const nextIteration = this.iteration + 1, warmup = s.warmupIterations, interval = Math.max(1, s.interval), stop = s.stopIterations;
     const shouldDensify = s.enabled && nextIteration >= warmup && nextIteration <= stop && (nextIteration === warmup || (nextIteration - warmup) % interval === 0);
 
-    let cmd = this.commandBuffers.get(idx);
-    if (cmd) {
-      this.device.queue.submit([cmd]);
-      this.optimizer.advanceIteration(1);
-    } else {
-      // the first step runs eagerly (textures are allocated on first use); afterwards each view is recorded once and replayed
-      const record = this.useCommandBuffers && this.eagerSteps >= 1;
-      const encoder = this.device.createCommandEncoder({ label: 'trainer-step', record });
-      try {
-        this.encodeView(encoder, idx);
-        cmd = encoder.finish();
-      } catch (e) {
-        encoder.abort();
-        this.invalidateCommandBuffers();
-        throw e;
-      }
-      this.device.queue.submit([cmd]);
-      if (record) this.commandBuffers.set(idx, cmd); else this.eagerSteps += 1;
+    try {
+      if (nViews === 1) this.stepSingleView(mine[0]); else this.stepBatched(mine);
+    } catch (e) {
+      // a failed encode must not leave the stream in capture mode or half-recorded command buffers behind
+      if (this.device.handle !== null) hip.addon.encoderAbort(this.device.handle);
+      try { this.invalidateCommandBuffers(); } catch (_deferred) { /* this step's error stays the one raised */ }
+      this.tickets = [];
+      throw e;
     }
-    await this.device.queue.onSubmittedWorkDone();
-    this.device.synchronize();   // deferred device-side checks (tile-entry overflow) surface here as a thrown Error
+    try {
+      await this.finishStep();
+    } catch (e) {
+      this.tickets = [];
+      throw e;
+    }
 
     this.iteration += 1;
     const dt = process.hrtime(t0);
@@ -282,12 +330,146 @@ class Trainer {
     const inst = this.stepMs > 0 ? 1000 / this.stepMs : 0;
     this.stepItersPerSec = this.stepItersPerSec === 0 ? inst : this.stepItersPerSec * 0.9 + inst * 0.1;   // trainer.ts:647-651
     if (shouldDensify) {
+      this.drain();
       await this.runDensifyPruneMultiView();
       const req = this.consumePointCloudSwapRequest();
       if (req) this.applyPointCloudSwap(req);
     }
     if (this.iteration >= this.maxIterations) this.stop();
-    void stepStart;
+  }
+
+  /** `await onSubmittedWorkDone()` (trainer.ts:639-645) + the deferred capacity check.  Depth 1: this step's own completion, through the
+   *  Promise, as the reference awaits it.  Depth d > 1: a ticket for this step is kept and the step d - 1 submissions ago is awaited. */
+  async finishStep() {
+    if (this.pipelineDepth <= 1) {
+      await this.device.queue.onSubmittedWorkDone();
+      this.device.synchronize();   // deferred device-side checks (tile-entry overflow) surface here as a thrown Error
+      return;
+    }
+    this.tickets.push(this.device.queue.mark());
+    while (this.tickets.length >= this.pipelineDepth) this.device.queue.wait(this.tickets.shift());
+  }
+  /** Awaits every step still in flight (a no-op at pipelineDepth 1). */
+  drain() { const t = this.tickets; this.tickets = []; for (const ticket of t) this.device.queue.wait(ticket); }
+
+  applyGradientOutput() {
+    const want = this.keepGradients || !this.fuseGeometryAdam;
+    if (this.gradientOutputApplied === want) return;
+    if (this.gradientOutputApplied !== null) this.invalidateCommandBuffers();   // the recorded fused step baked the old choice
+    this.backwardPass.setGradientOutput(want);
+    this.gradientOutputApplied = want;
+  }
+
+  /** The reference's step (trainer.ts:603-645): one view, Adam straight from the packed fp16 gradients. */
+  stepSingleView(view) {
+    this.applyGradientOutput();
+    const tileCounts = this.forwardPass.getResources().tileCountsBuffer;
+    const replayed = this.run('step/' + view, (encoder) => {
+      if (this.fuseGeometryAdam) {   // K1..K16, then K17 + Adam + re-pack in one pass over the Gaussians
+        this.encodeView(encoder, view, 0, false, false);
+        this.optimizer.stepWithGeometry(encoder, this.pointCloud, this.backwardPass, this.cameraBuffers[view], tileCounts);
+      } else {
+        this.encodeView(encoder, view, 0, true, false);
+        this.optimizer.step(encoder, this.pointCloud, this.backwardPass.getGradientsBuffer(), tileCounts);
+      }
+    });
+    if (replayed) this.optimizer.advanceIteration(1);
+    else if (!this.useCommandBuffers || this.eagerSteps < 1) this.eagerSteps += 1;
+  }
+
+  /** [views -> fp32 block] -> exchange -> [Adam on the owned slice] -> all-gather -> [apply the other ranks' rows]. */
+  stepBatched(mine) {
+    const n = this.pointCloud.num_points, w = this.worldSize, sl = parallel.slicePoints(n, w), dev = this.device;
+    if (!this.dpGrad) {   // (allocated before any recording is opened; sized world * slice so the collectives run in place)
+      this.dpGrad = dev.createBuffer({ size: 4 * parallel.GRAD_FLOATS * w * sl, label: 'dp-grad-f32' });
+      this.dpVisible = dev.createBuffer({ size: 4 * w * sl, label: 'dp-visible' });
+      this.dpFlag = dev.createBuffer({ size: 16, label: 'dp-guard' });
+      this.dpRows = this.sliced ? dev.createBuffer({ size: 32 * w * sl, label: 'dp-repacked-rows' }) : null;
+      this.optimizer.setGuard(this.dpFlag, 0);
+    }
+    const own = parallel.ownedRange(n, w, this.rank);
+    const eagerBefore = this.eagerSteps;
+    if (this.batchViews && mine.length <= this.opSets) this.viewsBatched(mine); else this.viewsOneByOne(mine);
+    this.exchange.exchangeGradients(this.dpGrad, this.dpVisible, this.dpFlag, sl);
+    if (this.run('adam', (encoder) => this.optimizer.stepF32Range(encoder, this.pointCloud, this.dpGrad, this.dpVisible, own.first, own.count, this.dpRows))) {
+      this.optimizer.advanceIteration(1);
+    }
+    if (this.sliced) {
+      this.exchange.allgatherRows(this.dpRows, sl);
+      this.run('apply', (_encoder) => this.optimizer.applyRepackedRows(this.dpRows, own.first, own.count, this.dpFlag, this.pointCloud));
+      this.stateSliced = w > 1;
+    }
+    if (!this.useCommandBuffers || eagerBefore < 1) this.eagerSteps += 1;
+  }
+
+  /** [K1 of all the views, one launch] -> per view, dealt to the lanes: scan, emit, sort, composite, loss, backward raster (one recorded command
+   *  buffer per (view, place in the batch)) -> [K17 of all the views, one launch, into the step's fp32 block].  The batched launches run on a
+   *  lane of their own; each view waits only for the projection, K17 for every view. */
+  viewsBatched(mine) {
+    const dev = this.device, L = this.lanes;
+    const sets = mine.map((_v, k) => this.opsOf(k));
+    const cams = mine.map((v) => this.cameraBuffers[v]);
+    const lanes = L > 1 && this.useCommandBuffers && mine.every((v, k) => this.commandBuffers.has(`viewp/${v}/${k}`));
+    const U = L < hip.MAX_LANES ? L : 0;   // the lane of the batched launches
+    const joinFrom = U ? hip.MAX_LANES : L;
+    try {
+      if (lanes) for (let s = 1; s < joinFrom; s++) dev.laneOrder(s, 0);   // every lane starts behind whatever lane 0 holds
+      if (lanes) dev.selectLane(U);
+      hip.projectViews(sets.map((s) => s[0]), cams, this.pointCloud);
+      if (lanes) dev.laneMark(U, 0);
+      mine.forEach((v, k) => {
+        if (lanes) { dev.laneWaitMark(k % L, 0); dev.selectLane(k % L); }
+        this.run(`viewp/${v}/${k}`, (encoder) => this.encodeView(encoder, v, k, false, true));
+        if (lanes) dev.laneOrder(U, k % L);   // K17 follows every view
+      });
+      if (lanes) dev.selectLane(U);
+      hip.geometryViews(sets.map((s) => s[2]), cams, sets.map((s) => s[0]), this.dpGrad, this.dpVisible, this.dpFlag, this.pointCloud, false, false);
+    } finally {
+      if (lanes) {
+        hip.addon.encoderAbort(dev.handle);   // (a no-op unless an encode above failed mid-recording)
+        dev.selectLane(0);
+        for (let s = 1; s < joinFrom; s++) dev.laneOrder(0, s);   // join: the exchange and the optimizer step follow every lane
+      }
+    }
+  }
+
+  /** Per view K1..K16 recorded, K17 eager per view and ordered across the lanes (one op set per lane): the form for batches larger than
+   *  MAX_BATCH_VIEWS or with batchViews off. */
+  viewsOneByOne(mine) {
+    const dev = this.device, L = Math.min(this.lanes, this.opSets);
+    const lanes = L > 1 && this.useCommandBuffers && mine.every((v, k) => this.commandBuffers.has(`view/${v}/${k % L}`));
+    try {
+      if (lanes) for (let s = 1; s < L; s++) dev.laneOrder(s, 0);
+      mine.forEach((v, k) => {
+        const s = k % L, ops = this.opsOf(s);
+        if (lanes) dev.selectLane(s);
+        this.run(`view/${v}/${s}`, (encoder) => this.encodeView(encoder, v, s, false, false));
+        if (lanes && k > 0) dev.laneOrder(s, (k - 1) % L);   // the fp32 block is filled in view order
+        ops[2].encodeGeometry(null, this.cameraBuffers[v], { sums: this.dpGrad, visible: this.dpVisible, first: k === 0,
+          tileCounts: ops[0].getResources().tileCountsBuffer, guard: this.dpFlag, stats: ops[0].getStatsBuffer() });
+      });
+    } finally {
+      if (lanes) {
+        hip.addon.encoderAbort(dev.handle);
+        dev.selectLane(0);
+        for (let s = 1; s < L; s++) dev.laneOrder(0, s);
+      }
+    }
+  }
+
+  /** Brings every rank's optimizer state up to date: after sliced steps a rank holds current (param, m, v) only for the Gaussians it owns; each
+   *  owner broadcasts its slice of the six state arrays.  A no-op on one rank.  Called before a densify rebuild. */
+  syncOptimizerState() {
+    if (!this.stateSliced || this.worldSize <= 1) return;
+    const n = this.pointCloud.num_points, w = this.worldSize;
+    const bufs = this.optimizer.getStateBuffers();
+    const rows = { optPosBuffer: 48, optRotBuffer: 48, optScaleBuffer: 48, optOpacityBuffer: 12, paramSH: 192, stateSH: 384 };
+    for (let root = 0; root < w; root++) {
+      const own = parallel.ownedRange(n, w, root);
+      for (const k of Object.keys(rows)) this.exchange.broadcast(bufs[k].ptr + BigInt(own.first * rows[k]), own.count * rows[k], root);
+    }
+    this.optimizer.stateChanged();
+    this.stateSliced = false;
   }
 
   /** trainer.ts:373-497 */
@@ -305,6 +487,10 @@ class Trainer {
       const camData = this.trainCameras[idx], image = this.images[idx];
       if (!camData || !image) continue;
       if (image.width !== baseW || image.height !== baseH) continue;
+      // every rank walks the same view list; the work is sharded round-robin and the counts are all-reduced below
+      const take = (usedViews % this.worldSize) === this.rank;
+      usedViews++;
+      if (!take) continue;
       this.device.queue.writeBuffer(this.metricsCameraBuffer, 0, cameraBlockFor(camData.camera, mW, mH));
       this.metricsForwardPass.encode(encoder);
       this.metricsRasterizer.encode(encoder, mW, mH);
@@ -313,9 +499,9 @@ class Trainer {
       this.metricsPass.computeMetricCounts(encoder, { splatBuffer: this.metricsForwardPass.getResources().splatBuffer,
         tileOffsetsBuffer: this.metricsRasterizer.getTileOffsetsBuffer(), tileIndicesBuffer: this.metricsForwardPass.getSortedIndicesBuffer(),
         nContribTexture: this.metricsRasterizer.getNContribTextureView() }, { clear: false });
-      usedViews++;
     }
     if (usedViews === 0) return;
+    if (this.worldSize > 1) this.exchange.allreduceCounts(this.metricsPass.getMetricCountsBuffer(), this.pointCloud.num_points);   // u32 sum, in place
     this.metricsPass.normalizeMetricCounts(encoder, { divisor: usedViews });
     this.densifyPrune.ensureSize(this.pointCloud.num_points);
     const prepared = this.densifyPrune.encodePrepare(encoder, { pointCloud: this.pointCloud, metricCountsBuffer: this.metricsPass.getMetricCountsBuffer() });
@@ -325,7 +511,8 @@ class Trainer {
     const inN = this.pointCloud.num_points;
     const outN = Math.min(outTotal, prepared.maxOutPoints);
     if (outN === 0 || outN === inN) return;
-    this.flushPointCloud();   // the rebuild copies the cloud's SH rows: bring the deferred DC halves in first
+    this.syncOptimizerState();   // every rank rebuilds the whole cloud, so every rank needs the whole state
+    this.flushPointCloud();      // the rebuild copies the cloud's SH rows: bring the deferred DC halves in first
     const outPointCloud = hip.allocatePointCloudLike(this.device, this.pointCloud, { numPoints: outN });
     const outOptimizerState = hip.allocateOptimizerStateBuffers(this.device, outN);
     const scatterEncoder = this.device.createCommandEncoder({ label: 'densify-prune scatter' });
@@ -337,20 +524,26 @@ class Trainer {
     this.lastDensifyPruneIteration = this.iteration;
   }
 
-  /** Deterministic teardown: command buffers, ops, the buffers this trainer allocated (the device belongs to the caller). */
+  /** Deterministic teardown: command buffers, ops, the buffers this trainer allocated (the device and the exchange belong to the caller). */
   destroy() {
-    this.device.synchronize();
+    if (this.device.handle !== null) {
+      hip.addon.encoderAbort(this.device.handle);
+      this.tickets = [];
+      try { this.device.synchronize(); } catch (_e) { /* a deferred report about a step of a trainer that is going away */ }
+    }
     this.invalidateCommandBuffers();
     for (const name of ['forwardPass', 'rasterizer', 'backwardPass', 'metricsForwardPass', 'metricsRasterizer', 'metricsPass', 'optimizer', 'densifyPrune']) {
       if (this[name]) this[name].destroy();
       this[name] = null;
     }
+    this.destroyMoreOpSets();
     for (const b of this.cameraBuffers) b.destroy();
     this.cameraBuffers = [];
-    if (this.metricsTarget) this.metricsTarget.destroy();
+    for (const name of ['dpGrad', 'dpVisible', 'dpRows', 'dpFlag', 'metricsTarget']) { if (this[name]) this[name].destroy(); this[name] = null; }
     this.metricsCameraBuffer.destroy();
     this.isTraining = false;
   }
 }
+Trainer.DEFAULT_LANES = 3;
 
 module.exports = { Trainer, cameraBlockFor, mat4Inverse, projectionMatrix, DEFAULT_DENSIFY };

@@ -4,12 +4,16 @@ export type RenderMode = 'gaussian' | 'pointcloud';
 
 export class HipBuffer {
   readonly device: HipDevice; readonly ptr: bigint; readonly size: number; destroyed: boolean;
+  /** Called before the buffer's content is handed to the host or copied by copyBufferToBuffer (deferred SH writes, the compact training copy). */
+  beforeRead: (() => void) | null;
+  read(byteLength?: number): ArrayBuffer;
   destroy(): void;
 }
 export class HipCommandBuffer { readonly device: HipDevice; destroy(): void; }
 export class HipEncoder {
   readonly device: HipDevice; readonly label: string; readonly record: boolean;
   clearBuffer(buffer: HipBuffer): void;
+  copyBufferToBuffer(src: HipBuffer, srcOffset: number, dst: HipBuffer, dstOffset: number, size: number): void;
   finish(): HipCommandBuffer;
   abort(): void;
 }
@@ -33,11 +37,20 @@ export class HipDevice {
   /** Lanes (include/webdgs.h): lane 0 is the device's stream, 1..3 internal ones; work on different lanes may overlap. */
   selectLane(lane: number): void;
   laneOrder(waiterLane: number, signalLane: number): void;
+  laneMark(lane: number, mark: number): void;
+  laneWaitMark(lane: number, mark: number): void;
+  /** Per-kernel hipEvent timing (wdgs_device_set_profiling / wdgs_device_get_kernel_times). */
+  setProfiling(enabled: boolean): void;
+  kernelTimes(reset?: boolean): { [kernel: string]: { launches: number; totalMs: number } };
   destroy(): void;
 }
+export const MAX_LANES: number;
+export const MAX_BATCH_VIEWS: number;
 
 export interface PointCloud {          // src/utils/load-pointcloud.ts:16-23
   type: 'full' | 'normal'; num_points: number; sh_deg?: number; gaussian_3d_buffer: HipBuffer; sh_buffer?: HipBuffer;
+  /** Set while an Optimizer trains this cloud with deferred SH writes: the compact SH-DC array forward passes built on the cloud read. */
+  dcWords?: HipBuffer | null;
 }
 export function allocatePointCloudLike(device: HipDevice, template: PointCloud, options: { numPoints: number }): PointCloud;
 
@@ -73,6 +86,11 @@ export class TiledForwardPass {
   setPointCloud(pointCloud: PointCloud): boolean;
   /** K1 takes the SH-DC halves from the optimizer's compact array (Optimizer.setDeferredSH); null restores the rows. */
   setDcSource(dcWords: HipBuffer | null): void;
+  /** Follows pointCloud.dcWords (called by encode / projectViews): a pass built on a cloud in training renders the trained colours by itself. */
+  syncDcSource(): void;
+  /** The rest of encode (scan, emit, sort) after projectViews ran K1 for this pass (view-batched step; no reference counterpart). */
+  encodeProjected(encoder: HipEncoder | null): void;
+  isProjected(): boolean;
   setRenderMode(mode: RenderMode): void; setPointSize(value: number): void; setGaussianScale(value: number): void; setViewport(width: number, height: number): void;
   getResources(): TiledForwardResources;
   getSortedIndicesBuffer(): HipBuffer; getSortedKeysBuffer(): HipBuffer; getTileOffsetsBuffer(): HipBuffer; getStatsBuffer(): HipBuffer;
@@ -94,6 +112,12 @@ export interface TiledBackwardResources {  // tiled-backward-pass.ts:40-50
 export class TiledBackwardPass {
   constructor(device: HipDevice, pointCloud: PointCloud, config: { viewportWidth: number; viewportHeight: number; trainingConfig: TrainingConfig; maxSplatRadiusPx?: number });
   encode(encoder: HipEncoder | null, predictedTexture: HipBuffer, targetTexture: HipBuffer, resources: TiledBackwardResources, options?: {}): void;
+  /** The two halves of encode (a batched step; the fused single-view step): K15 + clear + K16, then K17. */
+  encodeRaster(encoder: HipEncoder | null, predictedTexture: HipBuffer, targetTexture: HipBuffer, resources: TiledBackwardResources): void;
+  encodeGeometry(encoder: HipEncoder | null, cameraBuffer: HipBuffer,
+                 accumulate?: { sums: HipBuffer; visible: HipBuffer; tileCounts: HipBuffer; guard: HipBuffer; stats: HipBuffer; first: boolean } | null): void;
+  /** Whether Optimizer.stepWithGeometry also writes K17's packed gradient to getGradientsBuffer() (default true, as the reference's K17 does). */
+  setGradientOutput(enabled: boolean): void;
   setTrainingConfig(next: Partial<TrainingConfig>): void;
   getMetricMapTexture(): HipBuffer;
   computeLossOnly(encoder: HipEncoder | null, predicted: HipBuffer, target: HipBuffer): void;
@@ -122,6 +146,12 @@ export class Optimizer {
   setDeferredSH(pointCloud: PointCloud, enabled?: boolean): HipBuffer | null;
   flushSH(pointCloud: PointCloud): void;
   setGuard(flagBuffer: HipBuffer | null, offset?: number): void;
+  /** step() fused with K17 (wdgs_optimizer_step_with_geometry): after backwardPass.encodeRaster for the view. */
+  stepWithGeometry(encoder: HipEncoder | null, coefficients: PointCloud, backwardPass: TiledBackwardPass, cameraBuffer: HipBuffer, tileCountsBuffer: HipBuffer): void;
+  /** Data-parallel step (SURVEY 8(e)): Adam + re-pack on the owned slice; rowsOut receives the re-packed 32-byte rows. */
+  stepF32Range(encoder: HipEncoder | null, coefficients: PointCloud, gradF32: HipBuffer, visibleCounts: HipBuffer, first: number, count: number, rowsOut?: HipBuffer | null): void;
+  applyRepackedRows(rows: HipBuffer, skipFirst: number, skipCount: number, guard: HipBuffer | null, pointCloud: PointCloud): void;
+  stateChanged(): void;
   advanceIteration(count?: number): void;
   destroy(): void;
 }
@@ -152,3 +182,22 @@ export class DensifyPrunePass {
   destroy(): void;
 }
 export function downsampleRGBA8(device: HipDevice, src: HipBuffer, srcW: number, srcH: number, dst: HipBuffer, dstW: number, dstH: number): void;
+/** View-batched K1 / K17 (include/webdgs.h wdgs_tiled_forward_project_views, wdgs_tiled_backward_encode_geometry_views); no reference counterpart. */
+export function projectViews(forwardPasses: TiledForwardPass[], cameraBuffers: HipBuffer[], pointCloud: PointCloud): void;
+export function geometryViews(backwardPasses: TiledBackwardPass[], cameraBuffers: HipBuffer[], forwardPasses: TiledForwardPass[], sums: HipBuffer, visible: HipBuffer, guard: HipBuffer,
+                              pointCloud: PointCloud, writeGradients?: boolean, continues?: boolean): void;
+export function imageSSE(device: HipDevice, a: HipBuffer, b: HipBuffer, numPixels: number): number;
+export function imagePSNR(device: HipDevice, a: HipBuffer, b: HipBuffer, numPixels: number): number;
+/** The C-ABI communicator (wdgs_comm_*): RCCL on the device's stream, for the data-parallel step of a host without torch.distributed. */
+export class Communicator {
+  constructor(device: HipDevice, uniqueId: ArrayBuffer, worldSize: number, rank: number);
+  readonly worldSize: number; readonly rank: number;
+  static uniqueId(): ArrayBuffer;
+  exchangeGradients(grad: HipBuffer, visible: HipBuffer, flag: HipBuffer | null, slicePoints: number): void;
+  allgatherRows(rows: HipBuffer, slicePoints: number): void;
+  broadcast(ptr: bigint, bytes: number, root: number): void;
+  allreduceCounts(counts: HipBuffer, count: number): void;
+  allreduceGradients(grad: HipBuffer, visible: HipBuffer, numPoints: number): void;
+  static groupStart(): void; static groupEnd(): void;
+  destroy(): void;
+}

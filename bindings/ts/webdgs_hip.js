@@ -17,7 +17,14 @@ const addon = require(path.join(__dirname, '..', 'napi', 'webdgs_napi.node'));
 const dflt = (v, d) => (v === undefined || v === null ? d : v);
 
 class HipBuffer {                        // GPUBuffer
-  constructor(device, ptr, size, handle) { this.device = device; this.ptr = ptr; this.size = size; this.handle = handle; this.destroyed = false; }
+  constructor(device, ptr, size, handle) {
+    this.device = device; this.ptr = ptr; this.size = size; this.handle = handle; this.destroyed = false;
+    // called before the buffer's CONTENT is handed to the host (HipDevice.readBuffer / readBufferAsync) or copied by copyBufferToBuffer: a producer
+    // that keeps part of it elsewhere brings it up to date first (the optimizer's deferred SH writes and compact training copy)
+    this.beforeRead = null;
+  }
+  /** mapAsync + getMappedRange in one synchronous call: the buffer's bytes as an ArrayBuffer. */
+  read(byteLength) { return this.device.readBuffer(this, byteLength); }
   destroy() {
     if (this.destroyed) return;
     this.destroyed = true;
@@ -38,6 +45,12 @@ class HipEncoder {
     if (this.record) { addon.encoderBegin(device.handle); this.open = true; }
   }
   clearBuffer(buffer) { addon.bufferClear(this.device.handle, buffer.ptr, buffer.size); }
+  /** encoder.copyBufferToBuffer (trainer.ts:445): device to device, stream-ordered, recordable. */
+  copyBufferToBuffer(src, srcOffset, dst, dstOffset, size) {
+    if (srcOffset + size > src.size || dstOffset + size > dst.size) throw new RangeError('copyBufferToBuffer: range exceeds a buffer');
+    if (src.beforeRead) src.beforeRead();
+    addon.copyBufferToBuffer(this.device.handle, dst.ptr + BigInt(dstOffset), src.ptr + BigInt(srcOffset), size);
+  }
   finish() {
     if (!this.record) return new HipCommandBuffer(this.device, null);
     this.open = false;
@@ -65,12 +78,16 @@ class HipDevice {                        // GPUDevice + GPUQueue
   }
   createCommandEncoder(desc) { return new HipEncoder(this, desc && desc.label, desc && desc.record); }
   view(ptr, size) { return new HipBuffer(this, ptr, size, undefined); }
-  readBuffer(buffer, byteLength) { return addon.copyToHost(this.handle, buffer.ptr, byteLength === undefined ? buffer.size : byteLength); }
+  readBuffer(buffer, byteLength) {
+    if (buffer.beforeRead) buffer.beforeRead();
+    return addon.copyToHost(this.handle, buffer.ptr, byteLength === undefined ? buffer.size : byteLength);
+  }
   /** Pinned host memory (wdgs_host_alloc) as an ArrayBuffer: the destination of readBufferAsync. */
   createPinnedArrayBuffer(byteLength) { return addon.hostAlloc(byteLength); }
   /** mapAsync(READ) counterpart (trainer.ts:455-458): queues the copy and resolves once the stream reaches it. */
   readBufferAsync(buffer, offset, pinned, byteLength) {
     if (buffer.handle === undefined) throw new Error('readBufferAsync needs a buffer created by createBuffer');
+    if (buffer.beforeRead) buffer.beforeRead();
     addon.bufferReadAsync(this.handle, buffer.handle, offset, pinned, byteLength);
     return addon.queueOnSubmittedWorkDone(this.handle).then(() => pinned);
   }
@@ -78,6 +95,11 @@ class HipDevice {                        // GPUDevice + GPUQueue
   synchronize() { addon.deviceSynchronize(this.handle); }
   selectLane(lane) { addon.deviceSelectLane(this.handle, lane); }            // include/webdgs.h "Lanes"
   laneOrder(waiter, signal) { addon.deviceLaneOrder(this.handle, waiter, signal); }
+  laneMark(lane, mark) { addon.deviceLaneMark(this.handle, lane, mark); }          // remembers the current end of `lane` in mark `mark` ...
+  laneWaitMark(lane, mark) { addon.deviceLaneWaitMark(this.handle, lane, mark); }  // ... for lanes that wait for it later
+  /** Per-kernel hipEvent timing (wdgs_device_set_profiling): kernelTimes() -> { name: { launches, totalMs } } after a synchronize. */
+  setProfiling(enabled) { addon.deviceKernelTimes(this.handle, enabled ? 1 : 0); }
+  kernelTimes(reset) { const t = addon.deviceKernelTimes(this.handle, 3); if (reset) addon.deviceKernelTimes(this.handle, 2); return t; }
   destroy() { if (this.handle !== null) { addon.encoderAbort(this.handle); addon.deviceDestroy(this.handle); this.handle = null; } }
 }
 
@@ -131,9 +153,16 @@ class TiledForwardPass {                 // tiled-forward-pass.ts:62
   get nativeHandle() { return this.handle; }
   /** K1 takes the SH-DC halves from the optimizer's compact array (Optimizer.setDeferredSH) instead of the cloud's rows; null restores the rows. */
   setDcSource(dcWords) { this.dcSource = dcWords || null; addon.tiledForwardSetDcSource(this.handle, dcWords ? dcWords.ptr : null); }
+  /** A cloud that is being trained with deferred SH writes carries the optimizer's compact array (pointCloud.dcWords, Optimizer.setDeferredSH):
+   *  every forward pass built on that cloud -- the trainer's, a Viewer's -- takes the SH-DC halves from it without the host knowing. */
+  syncDcSource() { const want = this.pointCloud.dcWords || null; if (want !== (this.dcSource || null)) this.setDcSource(want); }
   encode(_encoder, options) {
+    this.syncDcSource();
     addon.tiledForwardEncode(this.handle, this.pointCloud.gaussian_3d_buffer.ptr, this.pointCloud.sh_buffer.ptr, this.cameraBuffer.ptr, options && options.skipSort ? 1 : 0);
   }
+  /** The rest of encode (scan, emit, sort) for a pass whose K1 ran through projectViews (view-batched step; no reference counterpart). */
+  encodeProjected(_encoder) { addon.tiledForwardEncodeProjected(this.handle); }
+  isProjected() { return addon.tiledForwardIsProjected(this.handle) !== 0; }
   setCameraBuffer(buffer) { this.cameraBuffer = buffer; }
   /** Adopts a point cloud of another size (wdgs_tiled_forward_resize) instead of destroy + construct; false if the SH degree differs. */
   setPointCloud(pointCloud) {
@@ -191,6 +220,17 @@ class TiledBackwardPass {                // tiled-backward-pass.ts:71
   encode(_encoder, predictedTexture, targetTexture, r, _options) {   // (TiledBackwardPassOptions is an empty interface in the reference)
     addon.tiledBackwardEncode(this.handle, predictedTexture.ptr, targetTexture.ptr, resourcePtrs(r), this.pointCloud.gaussian_3d_buffer.ptr);
   }
+  /** First half of encode (K15 loss gradient, clear, K16 backward raster): wdgs_tiled_backward_encode_raster. */
+  encodeRaster(_encoder, predictedTexture, targetTexture, r) { addon.tiledBackwardEncodeRaster(this.handle, predictedTexture.ptr, targetTexture.ptr, resourcePtrs(r)); }
+  /** Second half (K17).  `accumulate` (a batched step) = { sums, visible, tileCounts, guard, stats, first }: K17 also adds the view's gradient to the
+   *  step's fp32 block and folds the forward pass's overflow word (stats + 8 bytes) into the guard word. */
+  encodeGeometry(_encoder, cameraBuffer, accumulate) {
+    const a = accumulate ? { sums: accumulate.sums.ptr, visible: accumulate.visible.ptr, tileCounts: accumulate.tileCounts.ptr, guard: accumulate.guard.ptr,
+      overflowWord: accumulate.stats.ptr + 8n, first: accumulate.first ? 1 : 0 } : null;
+    addon.tiledBackwardEncodeGeometry(this.handle, cameraBuffer.ptr, this.pointCloud.gaussian_3d_buffer.ptr, a);
+  }
+  /** Whether Optimizer.stepWithGeometry also writes K17's packed gradient to getGradientsBuffer() (default: yes, as the reference's K17 does). */
+  setGradientOutput(enabled) { this.gradientOutput = !!enabled; addon.tiledBackwardSetGradientOutput(this.handle, enabled ? 1 : 0); }
   /** setTrainingConfig(next) (tiled-backward-pass.ts:812-830): loss weights of the next encode. */
   setTrainingConfig(next) {
     this.trainingConfig = Object.assign({ lambda_l1: 0.8, lambda_l2: 0.0, lambda_dssim: 0.2, c1: 0.0001, c2: 0.0009 }, this.trainingConfig || {}, next || {});
@@ -245,10 +285,16 @@ class Optimizer {                        // optimizer.ts:40
   /** Brings the SH-DC rows of paramSH / stateSH up to date before handing the arrays out (see include/webdgs.h). */
   getStateBuffers() {
     const s = addon.optimizerState(this.handle, 0);
-    if (this.buffers) return this.buffers;
-    const sizes = addon.optimizerStateSizes(Math.max(1, this.pointCloud.num_points));
-    const o = {};
-    STATE_KEYS.forEach((k, i) => { o[k] = this.device.view(s[k], sizes[i]); });
+    let o = this.buffers;
+    if (!o) {
+      const sizes = addon.optimizerStateSizes(Math.max(1, this.pointCloud.num_points));
+      o = {};
+      STATE_KEYS.forEach((k, i) => { o[k] = this.device.view(s[k], sizes[i]); });
+    }
+    // position, log-scale and SH-DC {param, m, v} are trained in a compact copy: a handle kept across steps is brought up to date whenever its
+    // content is read through the host (the reference's GPUBuffers are live)
+    const self = this;
+    for (const k of STATE_KEYS) if (!o[k].beforeRead) o[k].beforeRead = () => { if (!self.destroyed) addon.optimizerState(self.handle, 0); };
     return o;
   }
   step(_encoder, coefficients, gradientsBuffer, tileCountsBuffer) {
@@ -262,9 +308,27 @@ class Optimizer {                        // optimizer.ts:40
     const on = enabled !== false;
     const p = addon.optimizerDeferredSH(this.handle, pointCloud.sh_buffer.ptr, on ? 1 : 0);
     this.deferredCloud = on ? pointCloud : null;
-    return on && p !== null ? this.device.view(p, 8 * Math.max(1, this.pointCloud.num_points)) : null;
+    const words = on && p !== null ? this.device.view(p, 8 * Math.max(1, this.pointCloud.num_points)) : null;
+    const self = this;
+    pointCloud.sh_buffer.beforeRead = on ? () => self.flushSH(pointCloud) : null;   // host reads of the rows see the trained values
+    pointCloud.dcWords = words;                                                   // forward passes built on the cloud pick the halves up (syncDcSource)
+    return words;
   }
   flushSH(pointCloud) { if (!this.destroyed) addon.optimizerFlushSH(this.handle, pointCloud.sh_buffer.ptr); }
+  /** step() fused with K17 (wdgs_optimizer_step_with_geometry): call after backwardPass.encodeRaster for the view. */
+  stepWithGeometry(_encoder, coefficients, backwardPass, cameraBuffer, tileCountsBuffer) {
+    addon.optimizerStepWithGeometry(this.handle, backwardPass.handle, cameraBuffer.ptr, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, tileCountsBuffer.ptr);
+  }
+  /** Adam + re-pack on Gaussians [first, first + count) -- the slice a data-parallel rank owns; rowsOut also receives the re-packed 32-byte rows. */
+  stepF32Range(_encoder, coefficients, gradF32, visibleCounts, first, count, rowsOut) {
+    addon.optimizerStepF32Range(this.handle, coefficients.gaussian_3d_buffer.ptr, coefficients.sh_buffer.ptr, gradF32.ptr, visibleCounts.ptr, first, count, rowsOut ? rowsOut.ptr : null);
+  }
+  /** Writes the rows the other ranks published into this replica (with deferred SH writes the gathered halves go to the compact array). */
+  applyRepackedRows(rows, skipFirst, skipCount, guard, pointCloud) {
+    addon.optimizerApplyRepackedRows(this.handle, rows.ptr, skipFirst, skipCount, guard ? guard.ptr : null, pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr);
+  }
+  /** The state arrays were rewritten from outside (slices gathered from other ranks, a restored snapshot): refresh the internal copies. */
+  stateChanged() { addon.optimizerStateChanged(this.handle); }
   /** While the u32 at `flagBuffer + offset` is non-zero at execution time, step() leaves every buffer untouched (tile-entry overflow). */
   setGuard(flagBuffer, offset) { addon.optimizerSetGuard(this.handle, flagBuffer ? flagBuffer.ptr + BigInt(offset || 0) : null); }
   /** Host-side iteration counter: call when a recorded command buffer containing step() is re-submitted. */
@@ -326,6 +390,53 @@ class DensifyPrunePass {                 // densify-prune.ts:75
 /** Bilinear blit of an rgba8 image to another size (trainer.ts:303-328: the ground-truth down-sample of the metric views). */
 function downsampleRGBA8(device, src, srcW, srcH, dst, dstW, dstH) { addon.downsampleRGBA8(device.handle, src.ptr, srcW, srcH, dst.ptr, dstW, dstH); }
 
-module.exports = { addon, HipBuffer, HipCommandBuffer, HipEncoder, HipDevice, allocatePointCloudLike, PrefixScanner, get_prefix_scanner, DynamicSortStuff,
+/** K1 of ALL the views of a batched step in one launch (wdgs_tiled_forward_project_views); follow with forwardPasses[v].encodeProjected(encoder). */
+function projectViews(forwardPasses, cameraBuffers, pointCloud) {
+  for (const f of forwardPasses) f.syncDcSource();
+  addon.tiledForwardProjectViews(forwardPasses.map((f) => f.handle), cameraBuffers.map((c) => c.ptr), pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr);
+}
+/** K17 of ALL the views of a batched step in one launch (wdgs_tiled_backward_encode_geometry_views): the step's fp32 gradient block, visibility counts
+ *  and guard word, bit for bit what encodeGeometry(camera, { first: v === 0, ... }) per view produces. */
+function geometryViews(backwardPasses, cameraBuffers, forwardPasses, sums, visible, guard, pointCloud, writeGradients, continues) {
+  const res = forwardPasses.map((f) => addon.tiledForwardGetResources(f.handle));
+  addon.tiledBackwardGeometryViews(backwardPasses.map((b) => b.handle), cameraBuffers.map((c) => c.ptr), res.map((r) => r.tileCountsBuffer), res.map((r) => r.statsBuffer + 8n),
+    pointCloud.gaussian_3d_buffer.ptr, sums.ptr, visible.ptr, guard.ptr, writeGradients ? 1 : 0, continues ? 1 : 0);
+}
+/** Exact sum of squared rgb8 differences of two rgba8 images (synchronises); PSNR = 10 log10(255^2 3P / SSE). */
+function imageSSE(device, a, b, numPixels) {
+  const out = device.createBuffer({ size: 8 });
+  addon.imageSSE(device.handle, a.ptr, b.ptr, numPixels, out.ptr);
+  const v = new BigUint64Array(device.readBuffer(out, 8))[0];
+  out.destroy();
+  return Number(v);
+}
+function imagePSNR(device, a, b, numPixels) {
+  const sse = imageSSE(device, a, b, numPixels);
+  return sse === 0 ? Infinity : 10 * Math.log10(255 * 255 * 3 * numPixels / sse);
+}
+
+/** The C-ABI communicator (wdgs_comm_*, include/webdgs.h): RCCL queued on the device's stream by the library itself -- the transport of the
+ *  data-parallel step for a host without torch.distributed.  `uniqueId` (ArrayBuffer, 128 bytes) comes from Communicator.uniqueId() on rank 0 and
+ *  reaches the other ranks over any host channel (parallel.js ships it through a file). */
+class Communicator {
+  constructor(device, uniqueId, worldSize, rank) {
+    this.device = device; this.worldSize = worldSize; this.rank = rank;
+    this.handle = addon.commCreate(device.handle, uniqueId, worldSize, rank);
+  }
+  static uniqueId() { return addon.commUniqueId(); }
+  exchangeGradients(grad, visible, flag, slicePoints) { addon.commExchangeGradients(this.handle, grad.ptr, visible.ptr, flag ? flag.ptr : null, slicePoints); }
+  allgatherRows(rows, slicePoints) { addon.commAllgatherRows(this.handle, rows.ptr, slicePoints); }
+  broadcast(ptr, bytes, root) { addon.commBroadcast(this.handle, ptr, bytes, root); }
+  allreduceCounts(counts, count) { addon.commAllreduceCounts(this.handle, counts.ptr, count); }
+  allreduceGradients(grad, visible, numPoints) { addon.commAllreduceGradients(this.handle, grad.ptr, visible.ptr, numPoints); }
+  static groupStart() { addon.commGroup(0); }
+  static groupEnd() { addon.commGroup(1); }
+  destroy() { if (this.handle !== null) { addon.commDestroy(this.handle); this.handle = null; } }
+}
+
+const MAX_LANES = 4;         // WDGS_MAX_LANES
+const MAX_BATCH_VIEWS = 16;  // WDGS_MAX_BATCH_VIEWS
+
+module.exports = { addon, MAX_LANES, MAX_BATCH_VIEWS, projectViews, geometryViews, imageSSE, imagePSNR, Communicator, HipBuffer, HipCommandBuffer, HipEncoder, HipDevice, allocatePointCloudLike, PrefixScanner, get_prefix_scanner, DynamicSortStuff,
   get_dynamic_sorter, TiledForwardPass, TiledRasterizer, TiledBackwardPass, DEFAULT_ADAM_HYPERPARAMETERS, allocateOptimizerStateBuffers, Optimizer,
   DensifyPrunePass, downsampleRGBA8 };

@@ -134,6 +134,9 @@ int wdgs_queue_wait(wdgs_device* dev, uint64_t ticket);
 int wdgs_copy_to_host(wdgs_device* dev, void* dst_host, const void* src_dev, size_t bytes);
 int wdgs_copy_to_device(wdgs_device* dev, void* dst_dev, const void* src_host, size_t bytes);
 int wdgs_memset(wdgs_device* dev, void* dst_dev, int value, size_t bytes); /* encoder.clearBuffer */
+/* encoder.copyBufferToBuffer(src, srcOffset, dst, dstOffset, size) (the staging copy of trainer.ts:445): device to device on the
+ * current lane, stream-ordered; recordable.  The ranges must not overlap. */
+int wdgs_copy_buffer_to_buffer(wdgs_device* dev, void* dst_dev, const void* src_dev, size_t bytes);
 
 /* ---------------------------------------------------------------- buffers (for hosts without their own allocator)
  * Replaces device.createBuffer / GPUBuffer.destroy; contents are zero-filled like WebGPU buffers. */

@@ -5,7 +5,7 @@ members.  Used two ways:
     python scripts/ts_surface.py --reference /root/reference  > tests/golden/reference_surface.json
 
 extracts the surface of the reference's operator layer (src/renderers/*.ts, src/sort/sort_dynamic.ts, src/prefix/prefix.ts,
-src/utils/allocate-pointcloud.ts, src/trainer.ts) -- names and arities only, no source text -- into a committed fixture; and
+src/utils/allocate-pointcloud.ts, src/trainer.ts, and the loaders / camera / viewer files of SURVEY 8(f)) -- names and arities only, no source text -- into a committed fixture; and
 tests/test_ts_surface.py parses bindings/ts/*.js and *.d.ts with the same scanner and checks that they cover that fixture.
 
 The scanner is a brace-depth walk over comment- and string-stripped text, not a TypeScript parser: it understands what these files use
@@ -22,7 +22,9 @@ MODIFIERS = {"public", "private", "protected", "static", "async", "readonly", "o
 NOT_METHODS = {"if", "for", "while", "switch", "catch", "return", "function", "new", "typeof", "await", "super", "throw"}
 
 REFERENCE_FILES = ["src/renderers/tiled-forward-pass.ts", "src/renderers/tiled-rasterizer.ts", "src/renderers/tiled-backward-pass.ts", "src/renderers/optimizer.ts",
-                   "src/renderers/densify-prune.ts", "src/sort/sort_dynamic.ts", "src/prefix/prefix.ts", "src/utils/allocate-pointcloud.ts", "src/trainer.ts"]
+                   "src/renderers/densify-prune.ts", "src/sort/sort_dynamic.ts", "src/prefix/prefix.ts", "src/utils/allocate-pointcloud.ts", "src/trainer.ts",
+                   # the callers and data formats either side of the path: loaders, image ingest, camera block, viewer
+                   "src/viewer.ts", "src/camera/camera.ts", "src/utils/plyreader.ts", "src/utils/load-pointcloud.ts", "src/utils/load-camera.ts", "src/utils/load-images.ts"]
 
 
 def strip(text: str) -> str:

@@ -1,0 +1,186 @@
+"""GPU: the TypeScript-side host beyond the one-view step -- loaders, image ingest and Viewer driven by node
+(bindings/napi/viewer_run.js) against the Python host on the same files: a JS-loaded .ply renders ``==`` the Python-loaded one in both
+render modes and on a resized canvas; a viewer that shares its PointCloud with a running trainer shows the TRAINED colours without any
+hand-over call (deferred SH writes: ADVICE r3 medium), in both hosts; state handles kept across steps are current when read; and
+bindings/napi/bench.js prints its line."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from webdgs_amd import images, loaders, ops, synth
+from webdgs_amd.trainer import Trainer
+from webdgs_amd.viewer import Viewer, encodePNG
+
+import harness
+from harness import assert_bits_equal
+from test_gpu_trainer_oracle import _FixedViews
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "bindings", "napi", "webdgs_napi.node")
+
+
+def _need_node():
+    if not NODE or not os.path.exists(ADDON):
+        pytest.skip("node or the N-API addon is not available")
+
+
+def _camera_json(cfg, n):
+    out = []
+    for i, blk in enumerate(synth.circle_cameras(cfg, n)):
+        view = blk[0:16].reshape(4, 4).T.astype(np.float64)
+        rot_rows = view[:3, :3]
+        out.append(dict(id=i, img_name=f"gt_{i}.png", width=cfg.width, height=cfg.height, fx=cfg.fy, fy=cfg.fy, position=list(-rot_rows.T @ view[:3, 3]), rotation=rot_rows.tolist()))
+    return out
+
+
+def test_js_loaded_ply_renders_like_the_python_loaded_one_and_the_viewer_follows_training(hip_device, orc, tmp_path):
+    _need_node()
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=6000, width=144, height=96, s0=0.01)
+    g, sh, _ = harness.scene(cfg)
+    (tmp_path / "scene.ply").write_bytes(loaders.exportPly(g, sh, cfg.sh_deg))
+    cams_json = _camera_json(cfg, 3)
+    (tmp_path / "cams.json").write_text(json.dumps(cams_json))
+    cams = loaders.loadCameraJson((tmp_path / "cams.json").read_bytes())
+    tg, tsh = synth.make_target_scene(g, sh)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    os.mkdir(tmp_path / "gt")
+    for i, c in enumerate(cams):
+        (tmp_path / "gt" / f"gt_{i}.png").write_bytes(encodePNG(orc.forward(tg, tsh, loaders.cameraUniforms(c, cfg.width, cfg.height), st, ti)["rgba8"]))
+    steps, draws, resized = 7, [0, 2, 1, 1, 0, 2, 2, 0, 1], (100, 72)
+    (tmp_path / "meta.json").write_text(json.dumps(dict(width=cfg.width, height=cfg.height, resized=resized, view_camera=1, steps=steps, draws=draws)))
+    r = subprocess.run([NODE, os.path.join(ROOT, "bindings", "napi", "viewer_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "VIEWER_RUN_OK" in r.stdout, f"exit code {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    out = json.loads((tmp_path / "out.json").read_text())
+
+    def js_frame(name, w=cfg.width, h=cfg.height):
+        return np.fromfile(tmp_path / name, np.uint8).reshape(h, w, 4)
+
+    # ---- the Python host on the same files
+    data = loaders.loadPointCloud((tmp_path / "scene.ply").read_bytes())
+    assert (out["type"], out["num_points"], out["sh_deg"]) == (data.type, data.num_points, data.sh_deg) and np.array_equal(data.gaussians, g)
+    pc = ops.createPointCloud(dev, data.gaussians, data.sh, data.sh_deg)
+    v = Viewer(dev, cfg.width, cfg.height)
+    t = None
+    try:
+        v.setCamera(cams[1])
+        v.setPointCloud(pc)
+        v.render(None)
+        assert_bits_equal(js_frame("out_frame_points.rgba"), v.readFrame(), "point-cloud mode: JS-loaded .ply vs Python-loaded")
+        v.setRenderMode("gaussian")
+        v.render(None)
+        gauss = v.readFrame().copy()
+        assert_bits_equal(js_frame("out_frame_gaussian.rgba"), gauss, "gaussian mode: JS-loaded .ply vs Python-loaded")
+        assert_bits_equal(gauss, orc.forward(g, sh, loaders.cameraUniforms(cams[1], cfg.width, cfg.height), st, ti)["rgba8"], "... and both are the oracle's image")
+        assert_bits_equal(images.decodePNG((tmp_path / "out_frame.png").read_bytes()), gauss, "the PNG the JS viewer saved")
+        v.setPointSize(5.0)
+        v.setRenderMode("pointcloud")
+        v.render(None)
+        assert_bits_equal(js_frame("out_frame_points5.rgba"), v.readFrame(), "setPointSize + setRenderMode")
+        v.resize(*resized)
+        v.setRenderMode("gaussian")
+        v.render(None)
+        assert_bits_equal(js_frame("out_frame_resized.rgba", *resized), v.readFrame(), "resized canvas")
+        v.resize(cfg.width, cfg.height)
+
+        # ---- train the shared cloud; the viewer is never told (no flushPointCloud)
+        gt = images.loadImages([str(tmp_path / "gt" / f) for f in os.listdir(tmp_path / "gt")], dev)
+        assert out["images"] == [[im.name, im.width, im.height] for im in gt] and out["cameras"] == 3
+        t = Trainer(dev, seed=0)
+        assert t.deferred_sh, "deferred SH writes are the Trainer's default: that is the case under test"
+        t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+        t.setPointCloud(pc)
+        t.setDataset(cams, gt)
+        t.start()
+        t._rng = _FixedViews(draws)
+        for _ in range(steps):
+            t.step()
+        v.render(None)
+        trained = v.readFrame().copy()
+        assert_bits_equal(js_frame("out_frame_trained.rgba"), trained, "unflushed viewer beside a running trainer: node vs Python")
+        assert not np.array_equal(trained, gauss), "training changed the image"
+        import torch
+        from webdgs_amd import parallel
+        stale = parallel._tensor_at(dev, pc.sh_buffer.ptr, pc.num_points * 24, torch.int32).cpu().numpy().view(np.uint32)
+        rows = pc.sh_buffer.read(np.uint32)[: pc.num_points * 24]
+        assert out["stale_rows_seen"] and not np.array_equal(stale, rows), "the rows really are stale until a hand-over (otherwise this test shows nothing)"
+        assert_bits_equal(np.fromfile(tmp_path / "out_sh.bin", np.uint32), rows, "host read of the SH rows through the hook: node vs Python")
+        assert_bits_equal(np.fromfile(tmp_path / "out_gaussians.bin", np.uint32), pc.gaussian_3d_buffer.read(np.uint32)[: pc.num_points * 6], "trained Gaussians: node vs Python")
+        # what the unflushed viewer showed IS the trained cloud: a fresh pass on a flushed copy of the cloud, no dc source, renders the same image
+        flushed = ops.createPointCloud(dev, pc.gaussian_3d_buffer.read(np.uint32)[: pc.num_points * 6].reshape(-1, 6), rows.reshape(-1, 24), pc.sh_deg)
+        v2 = Viewer(dev, cfg.width, cfg.height)
+        v2.setCamera(cams[1])
+        v2.setPointCloud(flushed)
+        v2.setRenderMode("gaussian")
+        v2.render(None)
+        assert_bits_equal(v2.readFrame(), trained, "unflushed viewer == viewer of the flushed cloud")
+        v2.destroy()
+        # a state handle fetched before further steps is current when read
+        kept = t.optimizer.getStateBuffers()
+        for _ in range(2):
+            t.step()
+        pos_kept = kept["optPosBuffer"].read(np.uint32)[: pc.num_points * 12]
+        assert_bits_equal(pos_kept, t.optimizer.getStateBuffers()["optPosBuffer"].read(np.uint32)[: pc.num_points * 12], "kept state handle == fresh getStateBuffers()")
+        assert_bits_equal(np.fromfile(tmp_path / "out_state_pos_kept.bin", np.uint32), pos_kept, "kept state handle: node vs Python")
+        t.destroy()
+        t = None
+        assert pc.dc_words is None and out["dc_words_after_trainer"], "the optimizer's destruction hands the rows back"
+        v.render(None)
+        assert_bits_equal(js_frame("out_frame_after_trainer.rgba"), v.readFrame(), "viewer after the trainer is gone")
+    finally:
+        if t is not None:
+            t.destroy()
+        v.destroy()
+
+
+def test_keep_gradients_switch_is_obeyed_after_set_point_cloud(hip_device, orc):
+    """``keep_gradients`` flipped AFTER ``setPointCloud`` (the passes survive swaps) must not leave getGradientsBuffer() stale."""
+    dev = hip_device
+    cfg = harness.small_config("c1", num_points=3000, width=96, height=64)
+    g, sh, cam = harness.scene(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    target = orc.forward(tg, tsh, cam, st, ti)["rgba8"]
+    t = Trainer(dev, seed=0)
+    try:
+        t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+        t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+        t.setDataset([dict(camera=cam, width=cfg.width, height=cfg.height)], [dict(texture=dev.bufferFrom(target), width=cfg.width, height=cfg.height)])
+        t.start()
+        ref_g, ref_sh = g.copy(), sh.copy()
+        state = orc.unpack(ref_g, ref_sh)
+        for _ in range(3):   # eager, recording, replay -- gradient output off
+            t.step()
+            orc.train_step(ref_g, ref_sh, state, cam, st, ti, target)
+        assert not t.keep_gradients and len(t._cmd_cache) == 1
+        t.keep_gradients = True
+        t.step()
+        ref = orc.train_step(ref_g, ref_sh, state, cam, st, ti, target)
+        assert_bits_equal(t.backwardPass.getGradientsBuffer().read(np.uint32).reshape(-1, 8)[: cfg.num_points], ref["gradients"], "gradients of the step after the switch")
+        t.step()
+        t.step()   # recorded again, with the output on
+        for _ in range(2):
+            ref = orc.train_step(ref_g, ref_sh, state, cam, st, ti, target)
+        assert_bits_equal(t.backwardPass.getGradientsBuffer().read(np.uint32).reshape(-1, 8)[: cfg.num_points], ref["gradients"], "gradients of a replayed step after the switch")
+        assert_bits_equal(t.pointCloud.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6), ref_g, "the cloud")
+    finally:
+        t.destroy()
+
+
+def test_bench_js_prints_its_line(tmp_path):
+    _need_node()
+    for extra in ([], ["--views-per-step", "3", "--lanes", "2", "--views", "4"]):
+        r = subprocess.run([NODE, os.path.join(ROOT, "bindings", "napi", "bench.js"), "--config", "c1", "--steps", "6", "--warmup", "2", "--min-seconds", "0.05"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"exit code {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["unit"] == "iters/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 6 and line["ms_per_step"] > 0
+        assert line["ms_per_step_awaiting_every_step"] > 0 and line["timed_blocks"]["blocks"] >= 2 and "node" in line["host"]
+        assert line["config"]["global_batch_views"] == (3 if extra else 1) and line["config"]["tile_entries_E"] > 0
+        assert line["kernel_ms_per_step"] and any(k.startswith("backward_rasterize") for k in line["kernel_ms_per_step"])

@@ -400,5 +400,31 @@ def test_a_projection_is_consumed_once(hip_device, orc):
         with pytest.raises(ops.StateError):
             fw.encodeProjected(None)
         harness.assert_bits_equal(fw.getSortedIndicesBuffer().read(np.uint32)[:e], ref["sorted_values"][:e], "sorted indices after the plain encode")
+        # A RECORDED encodeProjected consumes a projection on every replay: the check travels with the command buffer to queue.submit (a replay
+        # makes no encode call; without the check a recording that starts at the scan runs on sums that were already scanned in place -- the
+        # device fault of round 3's project-ahead experiment)
+        dev = hip_device
+        with dev.createCommandEncoder("rest of a projected pass", record=True) as enc:
+            fw.encodeProjected(enc)   # recording needs no projection: nothing runs now
+            cmd = enc.finish()
+        try:
+            with pytest.raises(ops.StateError, match="holds no projection"):
+                dev.queue.submit([cmd])
+            ops.projectViews([fw], [pipe.camera], pipe.pc)
+            dev.queue.submit([cmd])
+            assert not fw.isProjected()
+            harness.assert_bits_equal(fw.getSortedIndicesBuffer().read(np.uint32)[:e], ref["sorted_values"][:e], "sorted indices of a replayed projected pass")
+            with pytest.raises(ops.StateError, match="holds no projection"):
+                dev.queue.submit([cmd])   # the same projection twice
+            ops.projectViews([fw], [pipe.camera], pipe.pc)
+            fw.encode(None)               # a foreign encode of the pass between the projection and the replay (what a host preview between steps does)
+            with pytest.raises(ops.StateError, match="holds no projection"):
+                dev.queue.submit([cmd])
+            ops.projectViews([fw], [pipe.camera], pipe.pc)
+            dev.queue.submit([cmd])
+            harness.assert_bits_equal(fw.getSortedIndicesBuffer().read(np.uint32)[:e], ref["sorted_values"][:e], "sorted indices after the refused submits")
+        finally:
+            dev.synchronize()
+            cmd.destroy()
     finally:
         pipe.destroy()

@@ -22,12 +22,15 @@ WAIVERS = {
 }
 
 
+JS_MODULES = ("webdgs_hip.js", "trainer.js", "viewer.js", "camera.js", "loaders.js", "images.js")
+
+
 def _ours():
     js, dts = dict(classes={}, functions={}), dict(classes={}, functions={})
-    for f in ("webdgs_hip.js", "trainer.js"):
+    for f in JS_MODULES:
         s = ts_surface.surface(open(os.path.join(ROOT, "bindings", "ts", f)).read())
         js["classes"].update(s["classes"]); js["functions"].update(s["functions"])
-    for f in ("webdgs_hip.d.ts", "trainer.d.ts"):
+    for f in [m[:-3] + ".d.ts" for m in JS_MODULES]:
         s = ts_surface.surface(open(os.path.join(ROOT, "bindings", "ts", f)).read())
         dts["classes"].update(s["classes"]); dts["functions"].update(s["functions"])
     return js, dts
@@ -63,7 +66,7 @@ def test_every_reference_class_method_exists_with_the_same_arity():
                     elif side_name == "d.ts" and (mem["params"], mem["required"]) != (info["params"], info["required"]):
                         missing.append(f"d.ts: {cname}.{m} declares {mem['params']} parameters ({mem['required']} required), the reference {info['params']} ({info['required']})")
     assert not missing, "\n".join(missing)
-    assert checked >= 80   # 6 classes, 81 public methods + constructors in the fixture
+    assert checked >= 93   # 8 classes (Viewer and Camera since round 4), 94 public methods + constructors in the fixture
 
 
 def test_exported_functions_and_returned_interfaces_are_covered():
@@ -103,10 +106,10 @@ def test_waivers_name_things_the_reference_really_has():
 
 
 def test_python_host_has_the_same_method_names():
-    from webdgs_amd import ops, trainer
+    from webdgs_amd import ops, trainer, viewer
     ref = _reference()
     py = dict(TiledForwardPass=ops.TiledForwardPass, TiledRasterizer=ops.TiledRasterizer, TiledBackwardPass=ops.TiledBackwardPass, Optimizer=ops.Optimizer,
-              DensifyPrunePass=ops.DensifyPrunePass, Trainer=trainer.Trainer)
+              DensifyPrunePass=ops.DensifyPrunePass, Trainer=trainer.Trainer, Viewer=viewer.Viewer, Camera=viewer.Camera)
     missing = []
     for f in ref["files"].values():
         for cname, methods in f["classes"].items():

@@ -155,6 +155,7 @@ SIGNATURES = {
     "wdgs_copy_to_host": (_I, [_P, _P, _P, _Z]),
     "wdgs_copy_to_device": (_I, [_P, _P, _P, _Z]),
     "wdgs_memset": (_I, [_P, _P, _I, _Z]),
+    "wdgs_copy_buffer_to_buffer": (_I, [_P, _P, _P, _Z]),
     "wdgs_buffer_create": (_I, [_P, _Z, C.POINTER(_P)]),
     "wdgs_buffer_destroy": (_I, [_P]),
     "wdgs_buffer_ptr": (_P, [_P]),

@@ -405,13 +405,22 @@ int wdgs_device_reset_kernel_times(wdgs_device* d) {
 }
 
 // ---------------------------------------------------------------- recorded command buffers
-struct wdgs_command_buffer_impl { hipGraph_t graph; hipGraphExec_t exec; };
+static bool forward_holds_projection(const wdgs_tiled_forward* f);
+static void forward_consume_projection(wdgs_tiled_forward* f);
+// `consumes`: the forward passes whose projection (wdgs_tiled_forward_project_views) a replay of this recording uses up -- its scan works in
+// place on K1's workgroup sums.  The validity flag of a pass is a HOST fact checked when an encode is made; a replay makes no encode call, so
+// the command buffer carries the check to wdgs_queue_submit.  Without it a recording that starts at the scan could be replayed on a pass whose
+// projection another encode had already consumed: offsets scanned twice, a tile-entry count far beyond the entries really written, stale keys
+// with a zero tile field among them, and sort_scatter's atomicMin(&ranges[(key >> 16) - 1]) landing 16 GB past the table -- the device fault
+// behind the abort of gpurun_out/r04o_tests.log.
+struct wdgs_command_buffer_impl { hipGraph_t graph; hipGraphExec_t exec; std::vector<wdgs_tiled_forward*> consumes; };
 
 int wdgs_encoder_begin(wdgs_device* d) {
     WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_encoder_begin: a recording is already open on this device");
     WDGS_CHECK_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed));
     d->capturing = true;
+    d->capture_consumes.clear();
     return WDGS_OK;
 }
 int wdgs_encoder_finish(wdgs_device* d, wdgs_command_buffer** out) {
@@ -422,8 +431,9 @@ int wdgs_encoder_finish(wdgs_device* d, wdgs_command_buffer** out) {
     WDGS_CHECK_HIP(hipStreamEndCapture(d->stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGraphDestroy(graph); wdgs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return WDGS_E_HIP; }
-    auto* c = new wdgs_command_buffer_impl{graph, exec};
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); d->capture_consumes.clear(); wdgs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return WDGS_E_HIP; }
+    auto* c = new wdgs_command_buffer_impl{graph, exec, std::move(d->capture_consumes)};
+    d->capture_consumes.clear();
     *out = reinterpret_cast<wdgs_command_buffer*>(c);
     return WDGS_OK;
 }
@@ -431,6 +441,7 @@ int wdgs_encoder_abort(wdgs_device* d) {
     WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
     if (!d->capturing) return WDGS_OK;  // nothing open: harmless, so error paths may call it unconditionally
     d->capturing = false;
+    d->capture_consumes.clear();
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(d->stream, &graph);  // an invalidated capture reports an error here and yields no graph
     if (graph) (void)hipGraphDestroy(graph);
@@ -442,6 +453,16 @@ int wdgs_queue_submit(wdgs_device* d, wdgs_command_buffer* cmd) {
     WDGS_REQUIRE(d && cmd, WDGS_E_INVALID, "null argument");
     WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_queue_submit while recording");
     auto* c = reinterpret_cast<wdgs_command_buffer_impl*>(cmd);
+    // a recording that contains wdgs_tiled_forward_encode_projected uses up the projection of its pass on EVERY replay: all must be there
+    // (checked before anything is consumed, so a refused submit changes nothing)
+    for (wdgs_tiled_forward* f : c->consumes) {
+        WDGS_REQUIRE(std::find(d->forwards.begin(), d->forwards.end(), f) != d->forwards.end(), WDGS_E_STATE,
+                     "wdgs_queue_submit: the command buffer was recorded against a forward pass that has been destroyed");
+        WDGS_REQUIRE(forward_holds_projection(f), WDGS_E_STATE,
+                     "wdgs_queue_submit: the command buffer starts at the scan of a projected forward pass (wdgs_tiled_forward_encode_projected), but the pass holds no "
+                     "projection: run wdgs_tiled_forward_project_views before every submit, and no other encode of the pass in between");
+    }
+    for (wdgs_tiled_forward* f : c->consumes) forward_consume_projection(f);
     WDGS_CHECK_HIP(hipGraphLaunch(c->exec, d->stream));
     return WDGS_OK;
 }
@@ -494,6 +515,14 @@ int wdgs_memset(wdgs_device* d, void* dst, int value, size_t bytes) {
     if (bytes == 0) return WDGS_OK;
     // allowed inside a recording: it becomes a memset node of the command buffer (encoder.clearBuffer is recorded in the reference too)
     WDGS_CHECK_HIP(hipMemsetAsync(dst, value, bytes, d->stream));
+    return WDGS_OK;
+}
+
+int wdgs_copy_buffer_to_buffer(wdgs_device* d, void* dst, const void* src, size_t bytes) {
+    WDGS_REQUIRE(d && (bytes == 0 || (dst && src)), WDGS_E_INVALID, "wdgs_copy_buffer_to_buffer: null argument");
+    if (bytes == 0) return WDGS_OK;
+    // device to device, stream-ordered; inside a recording it becomes a copy node (encoder.copyBufferToBuffer is recorded in the reference too)
+    WDGS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, d->stream));
     return WDGS_OK;
 }
 
@@ -829,11 +858,19 @@ int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void*
 }
 int wdgs_tiled_forward_encode_projected(wdgs_tiled_forward* op) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_encode_projected: null op");
+    if (op->dev->capturing) {
+        // recorded: nothing runs now, so nothing is consumed now -- every submit of the command buffer will need (and use up) a projection
+        // of this pass (wdgs_queue_submit).  Whether the columns were counted is a property of the pass's configuration, not of one projection.
+        op->dev->capture_consumes.push_back(op);
+        return forward_encode_rest(op, 0, forward_uses_columns(op, 0));
+    }
     WDGS_REQUIRE(op->projected, WDGS_E_STATE,
                  "wdgs_tiled_forward_encode_projected: the pass holds no projection (wdgs_tiled_forward_project_views), or a later encode has consumed or overwritten it");
     op->projected = false;  // the scan consumes K1's workgroup sums in place: the rest of the pass can run ONCE per projection
     return forward_encode_rest(op, 0, op->projected_columns);
 }
+static bool forward_holds_projection(const wdgs_tiled_forward* f) { return f->projected; }
+static void forward_consume_projection(wdgs_tiled_forward* f) { f->projected = false; }
 
 int wdgs_tiled_forward_is_projected(const wdgs_tiled_forward* op) { return (op && op->projected) ? 1 : 0; }
 

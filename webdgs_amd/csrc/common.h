@@ -62,6 +62,9 @@ struct wdgs_device {
     struct Total { u32 launches = 0; float ms = 0.f; };
     std::map<std::string, Total> totals;
     std::vector<wdgs_tiled_forward*> forwards;  // live forward passes, for deferred overflow checks
+    // forward passes whose PROJECTION the open recording consumes (wdgs_tiled_forward_encode_projected while capturing): handed to the
+    // command buffer by wdgs_encoder_finish, checked and consumed by every wdgs_queue_submit of it
+    std::vector<wdgs_tiled_forward*> capture_consumes;
     int num_cus = 256;
 };
 

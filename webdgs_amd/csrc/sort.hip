@@ -258,7 +258,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         // In the partition's sorted order the entries of one tile are neighbours (same digit, and the input of this pass is ordered by
         // the tile's low bits), so a tile's first entry here is the one whose predecessor belongs to another tile: about 130 per
         // partition.  The smallest of those positions over all partitions is where the tile starts.
-        if (ranges_mode == 2u && (e == 0u || (s_keys[e - 1u] >> 16u) != (key >> 16u))) atomicMin(&ranges[(key >> 16u) - 1u], pos);
+        // (a key whose tile field is 0 or beyond the grid cannot come out of emit; the bound keeps a corrupted list -- entries counted but never
+        // written -- from turning into an address 16 GB past the table)
+        if (ranges_mode == 2u && (e == 0u || (s_keys[e - 1u] >> 16u) != (key >> 16u)) && (key >> 16u) - 1u < total_tiles) atomicMin(&ranges[(key >> 16u) - 1u], pos);
     }
 }
 

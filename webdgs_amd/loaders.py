@@ -272,11 +272,15 @@ def cameraUniforms(cam: dict, width: Optional[int] = None, height: Optional[int]
         fov_y = 2.0 * math.atan(cam["height"] / (2.0 * cam["fy"]))
     focal = 0.5 * h / math.tan(fov_y * 0.5)
     fov_x = 2.0 * math.atan(w / (2.0 * focal))
-    rot = np.asarray(cam.get("rotation") if cam.get("rotation") is not None else np.eye(4).reshape(-1), np.float32).astype(np.float64).reshape(4, 4).T
+    rot = np.asarray(cam.get("rotation") if cam.get("rotation") is not None else np.eye(4).reshape(-1), np.float32).reshape(16)
     pos = _f32(cam.get("position") if cam.get("position") is not None else (0, 0, 5)).astype(np.float64)
-    trans = np.eye(4)
-    trans[:3, 3] = -pos
-    view = (rot @ trans).astype(np.float32).astype(np.float64)                    # mat4.translate(r, -t)
+    # mat4.translate(r, -t) as wgpu-matrix 3.2.0 evaluates it: the first three columns are copied as they are (a -0 stays a -0), the fourth is
+    # m[c0] * v0 + m[c1] * v1 + m[c2] * v2 + m[c3] in binary64, stored as f32
+    view_cm = rot.copy()
+    r64 = rot.astype(np.float64)
+    v0, v1, v2 = (float(x) for x in -pos)
+    for r in range(4):
+        view_cm[12 + r] = np.float32(r64[r] * v0 + r64[4 + r] * v1 + r64[8 + r] * v2 + r64[12 + r])
     tan_y, tan_x = math.tan(fov_y / 2.0), math.tan(fov_x / 2.0)
     top, right = tan_y * znear, tan_x * znear
     proj = np.zeros((4, 4))
@@ -287,7 +291,7 @@ def cameraUniforms(cam: dict, width: Optional[int] = None, height: Optional[int]
     proj[3, 2] = 1.0
     proj = proj.astype(np.float32).astype(np.float64)
     out = np.zeros(68, np.float32)
-    out[0:16] = view.T.reshape(-1)
+    out[0:16] = view_cm
     out[32:48] = proj.T.reshape(-1)
     out[16:32] = synth.mat4_inverse(out[0:16])
     out[48:64] = synth.mat4_inverse(out[32:48])

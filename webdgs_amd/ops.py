@@ -112,7 +112,12 @@ class HipEncoder:
         buf.clear()
 
     def copyBufferToBuffer(self, src: HipBuffer, src_off: int, dst: HipBuffer, dst_off: int, size: int) -> None:
-        dst.tensor().view(torch.uint8)[dst_off:dst_off + size].copy_(src.tensor().view(torch.uint8)[src_off:src_off + size])
+        """``encoder.copyBufferToBuffer`` (trainer.ts:445): device to device, stream-ordered, recordable."""
+        if src_off + size > src.size or dst_off + size > dst.size:
+            raise _lib.WdgsError(_lib.WDGS_E_INVALID, f"copyBufferToBuffer: {size} bytes at {src_off} -> {dst_off} exceed the buffers ({src.size}, {dst.size})")
+        if src.before_read is not None:
+            src.before_read()
+        check(self.device.lib.wdgs_copy_buffer_to_buffer(self.device.handle, dst.ptr + dst_off, src.ptr + src_off, int(size)))
 
     def finish(self):
         if not self.record:
@@ -251,6 +256,9 @@ class PointCloud:
     sh_deg: int
     gaussian_3d_buffer: HipBuffer
     sh_buffer: HipBuffer
+    # set while an Optimizer trains this cloud with deferred SH writes (``Optimizer.setDeferredSH``): the compact SH-DC array every forward pass
+    # built on the cloud reads in place of the rows' first six bytes -- the trainer's passes and a Viewer's alike, without the host knowing
+    dc_words: Optional[HipBuffer] = None
 
 
 def createPointCloud(device: HipDevice, gaussians: np.ndarray, sh: np.ndarray, sh_deg: int) -> PointCloud:
@@ -342,9 +350,19 @@ class TiledForwardPass:
         h = C.c_void_p()
         check(device.lib.wdgs_tiled_forward_create(device.handle, C.byref(cfg), C.byref(h)))
         self.handle = h
+        self._dc_source: Optional[HipBuffer] = None
+
+    def syncDcSource(self) -> None:
+        """Follows the cloud's ``dc_words`` (set by ``Optimizer.setDeferredSH``): a pass built on a cloud that is being trained renders the
+        trained colours even if its host never heard of deferred SH writes (the reference's Viewer shares the Trainer's PointCloud,
+        main.ts:389, 524)."""
+        want = getattr(self.pointCloud, "dc_words", None)
+        if want is not getattr(self, "_dc_source", None):
+            self.setDcSource(want)
 
     def encode(self, encoder: Optional[HipEncoder] = None, options: Optional[dict] = None) -> None:
         skip = 1 if (options or {}).get("skipSort") else 0
+        self.syncDcSource()
         check(self.device.lib.wdgs_tiled_forward_encode(self.handle, self.pointCloud.gaussian_3d_buffer.ptr, self.pointCloud.sh_buffer.ptr,
                                                         self.cameraBuffer.ptr, skip))
 
@@ -669,7 +687,17 @@ class Optimizer:
         kernels train is written back into ``paramSH`` / ``stateSH`` (stream-ordered) before anyone reads them."""
         st = _lib.OptimizerState()
         check(self.device.lib.wdgs_optimizer_get_state(self.handle, C.byref(st)))
+        # position, log-scale and SH-DC {param, m, v} are trained in a compact copy: a handle the host keeps across steps is brought up to date
+        # whenever its content is read (the reference's GPUBuffers are live; ADVICE r3)
+        for b in self.buffers.values():
+            if b.before_read is None:
+                b.before_read = self._flush_state
         return self.buffers
+
+    def _flush_state(self) -> None:
+        if not self.destroyed and self.handle:
+            st = _lib.OptimizerState()
+            check(self.device.lib.wdgs_optimizer_get_state(self.handle, C.byref(st)))
 
     # ---- deferred SH writes (include/webdgs.h: wdgs_optimizer_set_deferred_sh; no reference counterpart)
     def setDeferredSH(self, pointCloud: PointCloud, enabled: bool = True) -> Optional[HipBuffer]:
@@ -682,7 +710,9 @@ class Optimizer:
         self._deferred_cloud = pointCloud if enabled else None
         pointCloud.sh_buffer.before_read = (lambda: self.flushSH(pointCloud)) if enabled else None
         ptr = self.device.lib.wdgs_optimizer_dc_words(self.handle)
-        return self.device.view(ptr, 8 * max(1, self.numPoints), "sh-dc words") if (enabled and ptr) else None
+        words = self.device.view(ptr, 8 * max(1, self.numPoints), "sh-dc words") if (enabled and ptr) else None
+        pointCloud.dc_words = words
+        return words
 
     def flushSH(self, pointCloud: PointCloud) -> None:
         """Writes the deferred SH-DC halves into the cloud's rows (a no-op when nothing was trained since the last flush)."""
@@ -763,6 +793,8 @@ def projectViews(forwardPasses: list, cameraBuffers: list, pointCloud: PointClou
     """K1 of ALL the views of a batched step in one launch (``wdgs_tiled_forward_project_views``): Gaussian and SH row are read once and
     projected under every camera into that view's own forward pass.  Follow with ``forwardPasses[v].encodeProjected(encoder)``."""
     dev = forwardPasses[0].device
+    for f in forwardPasses:
+        f.syncDcSource()
     check(dev.lib.wdgs_tiled_forward_project_views(_ptr_array([f.handle for f in forwardPasses]), _ptr_array([c.ptr for c in cameraBuffers]), len(forwardPasses),
                                                    pointCloud.gaussian_3d_buffer.ptr, pointCloud.sh_buffer.ptr))
 

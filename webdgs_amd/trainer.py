@@ -79,6 +79,7 @@ class Trainer:
         # rows are flushed at hand-over points (Optimizer.setDeferredSH).  False: the reference's write pattern.  Results are identical.
         self.deferred_sh = os.environ.get("WDGS_DEFERRED_SH", "1") != "0"
         self._dc_words: Optional[ops.HipBuffer] = None
+        self._gradient_output_applied: Optional[bool] = None
         self._tickets: list = []
         self._more_op_sets: list = []  # [forwardPass, rasterizer, backwardPass] of lanes 1.. (set 0 is the three above)
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
@@ -310,9 +311,7 @@ class Trainer:
             self.rasterizer = ops.TiledRasterizer(dict(device=self.device, forwardPass=self.forwardPass, format="rgba8unorm"))
         if self.backwardPass is None:
             self.backwardPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
-            # the fused K17 + Adam step keeps the gradient in registers; nothing in the trainer reads the packed copy (trainer.ts hands it to
-            # optimizer.step() only), so the step does not write it unless asked to (``keep_gradients``)
-            self.backwardPass.setGradientOutput(self.keep_gradients or not self.fuse_geometry_adam)
+            self._gradient_output_applied = None  # (a fresh pass writes the packed gradient, the C ABI's default: _apply_gradient_output decides)
         else:
             self.backwardPass.setViewport(w, h)
         for more in self._more_op_sets:
@@ -479,8 +478,22 @@ class Trainer:
         self.device.queue.submit([cmd])
         return False
 
+    def _apply_gradient_output(self) -> None:
+        """The fused K17 + Adam step keeps the gradient in registers; nothing in the trainer reads the packed copy (trainer.ts hands it to
+        ``optimizer.step()`` only), so the step does not write it unless asked to.  ``keep_gradients`` and ``fuse_geometry_adam`` are read
+        HERE, at every step, so a host that flips them after ``setPointCloud`` is obeyed (a recorded fused step baked the old choice: the
+        recordings are dropped on a change) -- ``backwardPass.getGradientsBuffer()`` never silently holds stale data."""
+        want = bool(self.keep_gradients or not self.fuse_geometry_adam)
+        if self._gradient_output_applied is want:
+            return
+        if self._gradient_output_applied is not None:
+            self._invalidate_command_buffers()
+        self.backwardPass.setGradientOutput(want)
+        self._gradient_output_applied = want
+
     def _step_single_view(self, view: int) -> None:
         """The reference's step (trainer.ts:603-645): one view, Adam straight from the packed fp16 gradients."""
+        self._apply_gradient_output()
         tileCounts = self.forwardPass.getResources()["tileCountsBuffer"]
 
         def encode(encoder):

@@ -32,6 +32,40 @@ def encodePNG(rgba: np.ndarray) -> bytes:
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
 
 
+class Camera:
+    """``Camera`` (``src/camera/camera.ts:100-205``) without the browser: ``canvas`` is any object with ``width`` and ``height``.  Owns the
+    272-byte uniform buffer a forward pass reads and rewrites it, stream-ordered, on every ``update_buffer()``."""
+
+    def __init__(self, canvas, device: HipDevice):
+        self.canvas, self.device = canvas, device
+        self.uniform_buffer: HipBuffer = device.createBuffer(272, "camera uniform")
+        self.uniforms = np.zeros(68, np.float32)
+        self.reset()
+
+    def reset(self) -> None:
+        """camera.ts:113-119: position (0, 0, 5), identity rotation, fovY 45 degrees."""
+        self._preset = dict(position=(0.0, 0.0, 5.0))
+        self.on_update_canvas()
+
+    def on_update_canvas(self) -> None:
+        self.update_buffer()
+
+    def update_buffer(self) -> None:
+        self.uniforms = loaders.cameraUniforms(self._preset, int(self.canvas.width), int(self.canvas.height))
+        self.uniform_buffer.write(self.uniforms)
+
+    def set_preset(self, preset: dict) -> None:
+        """camera.ts:196-205: a CameraData dict (pose kept where the preset has none; fovY from height and fy when both are there)."""
+        merged = dict(self._preset)
+        for k in ("position", "rotation"):
+            if preset.get(k) is not None:
+                merged[k] = preset[k]
+        if preset.get("fx") and preset.get("fy") and preset.get("height"):
+            merged.update(fx=preset["fx"], fy=preset["fy"], height=preset["height"])
+        self._preset = merged
+        self.on_update_canvas()
+
+
 class Viewer:
     """``Viewer`` (``src/viewer.ts``): ``setPointCloud``, ``render(encoder)``, pass-through setters, resize handling."""
 
