@@ -150,6 +150,35 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: 
     return out
 
 
+def run_batched_step(dev, cfg, g, sh, tg, tsh, args, views_per_step: int = 8) -> dict:
+    """The like-for-like base of the 1 -> 8 GPU curve, carried by the N = 1 record too: the SAME batched step a rank
+    of an N > 1 job runs -- `views_per_step` views per step on the Trainer's default lanes, 64 circle cameras, recorded command buffers,
+    the headline's pipeline depth, Adam on all N Gaussians, no exchange -- timed exactly like the headline (blocks of K steps from one
+    restored training state, median block).  An N > 1 line divided by N x this rate is the scaling efficiency; dividing by the one-view
+    `value` instead would flatter the curve (the one-view step is slower per view)."""
+    from webdgs_amd import ops, parallel, synth
+    from webdgs_amd.trainer import Trainer
+    cams = synth.circle_cameras(cfg, 64)
+    cameras, images = make_dataset(dev, cfg, tg, tsh, cams)
+    t = Trainer(dev, seed=1234, world_size=1, rank=0, views_per_rank=views_per_step, overlap_views=args.lanes or None, pipeline_depth=args.pipeline_depth,
+                exchange=parallel.Exchange())
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset(cameras, images)
+    t.setMaxIterations(10 ** 9)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.start()
+    steps = max(4, args.steps // 3)
+    for _ in range(2):
+        t.step()
+    t.warmupCommandBuffers()
+    el, _dev_ms, blocks = timed_blocks(t, dev, steps, args.min_seconds, 1, barrier=lambda: None)
+    out = dict(views_per_step=views_per_step, lanes=t._lanes, views_per_s=round(views_per_step * steps / el, 3), ms_per_step=round(el / steps * 1e3, 4), steps_per_block=steps,
+               blocks=len(blocks), pipeline_depth=args.pipeline_depth, dataset_views=64,
+               note="the per-rank step of BASELINE c4 on this one GPU: Adam on all N Gaussians, no exchange; the like-for-like base of an N > 1 line's value / N")
+    t.destroy()
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +194,7 @@ def parse_args(argv=None):
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the K-step block is repeated until this much time has been timed; the MEDIAN block is reported (0 = one block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the eager per-kernel pass (roofline becomes null)")
+    ap.add_argument("--no-batched-step", action="store_true", help="N = 1: skip the `batched_step` leg (the 8-views-per-step step of config c4 on this one GPU)")
     ap.add_argument("--no-single-gpu-base", action="store_true", help="N > 1: skip the like-for-like leg (the same batched step on rank 0 alone, no exchange)")
     ap.add_argument("--cpu-baseline-points", type=int, default=0, help="0 = full workload")
     return ap.parse_args(argv)
@@ -344,6 +374,27 @@ def source_sha(kernel: str) -> str:
         return ""
 
 
+def measured_issue_rate():
+    """(wave-instructions per second, provenance) of the fastest plain fp32 VALU stream (v_fma / v_mul / v_add / v_sub_f32, one instruction kind per
+    loop) in the newest committed record of scripts/microbench/valu_issue.hip at the rasterization kernels' occupancy (`profiles/*_valu_issue_w7.txt`);
+    (None, reason) when there is none."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_issue_w7.txt")), key=os.path.basename, reverse=True)
+    for f in files:
+        best = 0.0
+        try:
+            for ln in open(f):
+                m = re.match(r"v_(?:fma|mul|add|sub)_f32\b.*?\s([\d.]+) G wave-instr/s", ln)
+                if m:
+                    best = max(best, float(m.group(1)))
+        except OSError:
+            continue
+        if best > 0:
+            return best * 1e9, f"profiles/{os.path.basename(f)}: fastest of the v_fma/v_mul/v_add/v_sub_f32 loops at 7 waves per SIMD (one box, one clock state)"
+    return None, "no profiles/*_valu_issue_w7.txt record"
+
+
 def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, tiles: int, k_coef: int, passes: int, config: str, pairs: int, raster_ms: float,
                    views: int = 1) -> dict:
     """The `roofline` object for the dominant kernel.  The two rasterization kernels (K14 / K16) are bound by fp32 VALU issue (SURVEY
@@ -393,15 +444,15 @@ def build_roofline(dom: str, dur_ms: float, n: int, v: int, e: int, p_pix: int, 
         if raster_ms > 0:
             roof["flop_frac_fwd_plus_bwd"] = round((f_fwd + f_bwd) / (raster_ms / 1e3) / 157.3e12, 4)
         peak_issue = 1024 * 2.4e9 / 2.0  # wave-instructions per second the chip can issue
-        # What a stream of independent or dependent v_fma_f32 really sustains at this kernel's occupancy (scripts/microbench/valu_issue.hip,
-        # profiles/r03s_valu_issue_w7.txt: 1022 G/s -- the clock the chip holds under a full vector load is below 2.4 GHz); conversions,
-        # compares, selects and DPP steps cost the same in a mix, v_rcp_f32 and v_permlane*_swap about five times as much.
-        attainable = 1022.0e9
+        # What a stream of plain fp32 VALU instructions really sustains on this chip (the clock it holds under a full vector load is below
+        # 2.4 GHz): read from the committed microbenchmark record, never a constant in this file -- null when the record is absent
+        attainable, attainable_src = measured_issue_rate()
         insts = pk[dom].get("SQ_INSTS_VALU") if pk is not None and dom in pk else None
-        roof.update(bound="valu_issue", unit="G wave-instr/s", peak=round(peak_issue / 1e9, 1), attainable_measured=round(attainable / 1e9, 1))
+        roof.update(bound="valu_issue", unit="G wave-instr/s", peak=round(peak_issue / 1e9, 1), attainable_measured=round(attainable / 1e9, 1) if attainable else None,
+                    attainable_source=attainable_src)
         if insts:
-            roof.update(achieved=round(insts / dur_s / 1e9, 1), frac=round(insts / dur_s / peak_issue, 4), frac_of_attainable=round(insts / dur_s / attainable, 4),
-                        valu_insts_per_launch=round(insts))
+            roof.update(achieved=round(insts / dur_s / 1e9, 1), frac=round(insts / dur_s / peak_issue, 4),
+                        frac_of_attainable=round(insts / dur_s / attainable, 4) if attainable else None, valu_insts_per_launch=round(insts))
         else:
             roof.update(achieved=None, frac=None, note="VALU instruction count needs a PMC profile of this kernel version (scripts/pmc.sh); hbm_frac and flop_frac are live")
     return roof
@@ -571,9 +622,11 @@ def main() -> None:
             solo.destroy()
         parallel.barrier()
 
-    sustained = cpu_baseline = None
+    sustained = cpu_baseline = batched = None
     if rank == 0 and world == 1:
         trainer.destroy()
+        if vpr == 1 and not args.no_batched_step and args.config in ("c3", "c3-small", "c2"):
+            batched = run_batched_step(dev, cfg, g, sh, tg, tsh, args)
         if args.sustained_steps > 0 and args.config in ("c3", "c3-small", "c2"):
             sustained = run_sustained(dev, cfg, g, sh, cameras, images, args.sustained_steps, args.pipeline_depth)
         if not args.no_cpu_baseline:
@@ -613,7 +666,11 @@ def main() -> None:
                                       "finish inside the timed region; `ms_per_step_awaiting_every_step` is the reference's own await-per-step"),
                        "densify_schedule": "reference defaults (warm-up 500): not reached in the timed region; see `sustained` / `c3_as_written_iters_per_s`" if views_per_step == 1 else "disabled in this leg",
                        "iter_definition": "value counts training VIEWS (fwd+bwd) per second; a step = views_per_rank x n_gpus views + 1 exchange + 1 Adam"},
-            "kernel_ms_per_view": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            # durations by the per-kernel events of the eager leg: kernels that run once per VIEW of a step, and kernels that run once per STEP
+            # (the view-batched K1 / K17 and the optimizer pass of a batched step) -- never mixed in one table
+            "kernel_ms_per_view": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]) if k in per_view_kernels},
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]) if k not in per_view_kernels},
+            "batched_step": batched,
             "roofline": roofline, "hbm_roofline_by_stage": hbm_by_stage, "exchange": exch, "sustained": sustained, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

@@ -729,6 +729,11 @@ static napi_value tiledBackwardEncodeGeometry(napi_env env, napi_callback_info i
     WDGS_OK_OR_THROW(wdgs_tiled_backward_encode_geometry((wdgs_tiled_backward*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_ptr(env, argv[2]), has ? &a : nullptr));
     return js_undefined(env);
 }
+static napi_value tiledBackwardSetMetricCountsTarget(napi_env env, napi_callback_info info) {  // (op, countsPtr | null)
+    ARGS(2);
+    WDGS_OK_OR_THROW(wdgs_tiled_backward_set_metric_counts_target((wdgs_tiled_backward*)get_ptr(env, argv[0]), get_ptr(env, argv[1])));
+    return js_undefined(env);
+}
 static napi_value tiledBackwardSetGradientOutput(napi_env env, napi_callback_info info) {  // (op, enabled)
     ARGS(2);
     WDGS_OK_OR_THROW(wdgs_tiled_backward_set_gradient_output((wdgs_tiled_backward*)get_ptr(env, argv[0]), (int)get_u32(env, argv[1])));
@@ -836,7 +841,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(deviceSelectLane); EXPORT_FN(deviceLaneOrder); EXPORT_FN(queueMark); EXPORT_FN(queueWait); EXPORT_FN(tiledForwardResize); EXPORT_FN(tiledBackwardResize);
     EXPORT_FN(applyRepackedRows); EXPORT_FN(commExchangeGradients); EXPORT_FN(commAllgatherRows); EXPORT_FN(commBroadcast); EXPORT_FN(commInfo);
     EXPORT_FN(optimizerStepWithGeometry); EXPORT_FN(optimizerApplyRepackedRows); EXPORT_FN(tiledBackwardEncodeRaster); EXPORT_FN(tiledBackwardEncodeGeometry);
-    EXPORT_FN(tiledBackwardSetGradientOutput); EXPORT_FN(tiledForwardProjectViews); EXPORT_FN(tiledForwardEncodeProjected); EXPORT_FN(tiledForwardIsProjected);
+    EXPORT_FN(tiledBackwardSetGradientOutput); EXPORT_FN(tiledBackwardSetMetricCountsTarget); EXPORT_FN(tiledForwardProjectViews); EXPORT_FN(tiledForwardEncodeProjected); EXPORT_FN(tiledForwardIsProjected);
     EXPORT_FN(tiledBackwardGeometryViews); EXPORT_FN(deviceLaneMark); EXPORT_FN(deviceLaneWaitMark); EXPORT_FN(deviceKernelTimes); EXPORT_FN(commGroup); EXPORT_FN(copyBufferToBuffer);
     return exports;
 }

@@ -21,6 +21,8 @@ export interface TrainerOptions {
   pipelineDepth?: number;
   /** views per rank per global step (a batched step: BASELINE config c4), device lanes they are dealt to (default 3), view-batched K1 / K17 (default on) */
   viewsPerStep?: number; lanes?: number; batchViews?: boolean;
+  /** device lanes the metric views of a densify event are dealt to (default 3; integer counts: any order gives the same bits) */
+  metricLanes?: number;
   /** view-sharded data parallelism (parallel.js) */
   worldSize?: number; rank?: number; exchange?: Exchange;
 }

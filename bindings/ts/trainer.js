@@ -64,6 +64,10 @@ class Trainer {
     this.batchViews = this.viewsPerRank > 1 && o.batchViews !== false;
     this.opSets = this.batchViews ? Math.min(this.viewsPerRank, hip.MAX_BATCH_VIEWS) : this.lanes;
     this.moreOpSets = [];   // [forwardPass, rasterizer, backwardPass] of op sets 1.. (set 0 is the three below)
+    // The metric views of a densify event are independent until normalizeMetricCounts (integer atomics: any order gives the same bits): they are
+    // dealt to `metricLanes` op sets, each on a device lane of its own, all adding into set 0's counts (TiledBackwardPass.setMetricCountsTarget).
+    this.metricLanes = Math.max(1, Math.min(Math.floor(o.metricLanes || Trainer.DEFAULT_LANES), hip.MAX_LANES));
+    this.moreMetricSets = [];   // [forwardPass, rasterizer, metricsPass, target, cameraBuffer] of metric lanes 1..
     this.dpGrad = null; this.dpVisible = null; this.dpRows = null; this.dpFlag = null; this.stateSliced = false;
     this.dcWords = null;
     this.forwardPass = null; this.rasterizer = null; this.backwardPass = null; this.optimizer = null; this.pointCloud = null;
@@ -93,7 +97,8 @@ class Trainer {
     this.requestPointCloudSwap(hip.allocatePointCloudLike(this.device, this.pointCloud, { numPoints }));
   }
   destroyMoreOpSets() { for (const set of this.moreOpSets) for (const op of set) op.destroy(); this.moreOpSets = []; }
-  forwardPasses() { return [this.forwardPass, this.metricsForwardPass].concat(this.moreOpSets.map((m) => m[0])).filter((p) => p); }
+  destroyMoreMetricSets() { for (const set of this.moreMetricSets) for (const op of set) op.destroy(); this.moreMetricSets = []; }
+  forwardPasses() { return [this.forwardPass, this.metricsForwardPass].concat(this.moreOpSets.map((m) => m[0]), this.moreMetricSets.map((m) => m[0])).filter((p) => p); }
   applyPointCloudSwap(request) {   // trainer.ts:201-237
     this.drain();
     this.device.synchronize();
@@ -105,7 +110,7 @@ class Trainer {
     // The reference destroys every pass and constructs new ones; the passes here can follow a cloud of another size
     // (setPointCloud: buffers reused, or re-allocated with headroom), so only the optimizer -- which adopts the rebuilt state -- is new.
     const passes = [this.forwardPass, this.backwardPass, this.metricsForwardPass, this.metricsPass];
-    for (const m of this.moreOpSets) passes.push(m[0], m[2]);
+    for (const m of this.moreOpSets.concat(this.moreMetricSets)) passes.push(m[0], m[2]);
     const kept = this.reusePasses && old && !this.recreateBackward && passes.filter((p) => p).every((p) => p.setPointCloud(this.pointCloud));
     if (!kept) {
       for (const name of ['forwardPass', 'rasterizer', 'backwardPass', 'metricsForwardPass', 'metricsRasterizer', 'metricsPass']) {
@@ -113,6 +118,7 @@ class Trainer {
         this[name] = null;
       }
       this.destroyMoreOpSets();
+      this.destroyMoreMetricSets();
       this.gradientOutputApplied = null;
     }
     this.optimizer = new hip.Optimizer(this.device, this.pointCloud, oldParams || this.optimizerHyperparameters, request.optimizerInitialState);
@@ -232,6 +238,7 @@ class Trainer {
     const w = Math.max(1, Math.floor(baseWidth / down)), h = Math.max(1, Math.floor(baseHeight / down));
     if (this.metricsForwardPass && this.metricsViewportWidth === w && this.metricsViewportHeight === h) return { width: w, height: h };
     for (const name of ['metricsForwardPass', 'metricsRasterizer', 'metricsPass']) { if (this[name]) this[name].destroy(); this[name] = null; }
+    this.destroyMoreMetricSets();
     if (this.metricsTarget) this.metricsTarget.destroy();
     this.metricsViewportWidth = w; this.metricsViewportHeight = h;
     this.metricsForwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, this.metricsCameraBuffer, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
@@ -240,6 +247,21 @@ class Trainer {
     this.metricsPass = new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig });
     this.metricsTarget = this.device.createBuffer({ size: 4 * w * h, label: 'metrics-gt-downsampled' });
     return { width: w, height: h };
+  }
+
+  /** [forwardPass, rasterizer, metricsPass, downsampled-GT buffer, camera buffer] of metric lane k; sets 1.. are built on first use. */
+  metricSet(k) {
+    if (k === 0) return [this.metricsForwardPass, this.metricsRasterizer, this.metricsPass, this.metricsTarget, this.metricsCameraBuffer];
+    const w = this.metricsViewportWidth, h = this.metricsViewportHeight;
+    while (this.moreMetricSets.length < k) {
+      const cam = this.device.createBuffer({ size: 272, label: 'metrics camera uniform' });
+      const fw = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+      fw.setDcSource(this.dcWords);
+      this.moreMetricSets.push([fw, new hip.TiledRasterizer({ device: this.device, forwardPass: fw, format: 'rgba8unorm' }),
+        new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig }),
+        this.device.createBuffer({ size: 4 * w * h, label: 'metrics-gt-downsampled' }), cam]);
+    }
+    return this.moreMetricSets[k - 1];
   }
 
   opsOf(opSet) { return opSet > 0 ? this.moreOpSets[opSet - 1] : [this.forwardPass, this.rasterizer, this.backwardPass]; }
@@ -480,25 +502,39 @@ class Trainer {
     const c = this.densifyPruneConfig;
     const viewsTarget = Math.max(1, Math.floor(c.metricViews));
     const encoder = this.device.createCommandEncoder({ label: 'densify-prune multiview metrics' });
-    encoder.clearBuffer(this.metricsPass.getMetricCountsBuffer());
-    let usedViews = 0;
-    for (let attempt = 0; attempt < viewsTarget * 4 && usedViews < viewsTarget; attempt++) {
-      const idx = Math.floor(this.random() * this.trainCameras.length);
-      const camData = this.trainCameras[idx], image = this.images[idx];
-      if (!camData || !image) continue;
-      if (image.width !== baseW || image.height !== baseH) continue;
-      // every rank walks the same view list; the work is sharded round-robin and the counts are all-reduced below
-      const take = (usedViews % this.worldSize) === this.rank;
-      usedViews++;
-      if (!take) continue;
-      this.device.queue.writeBuffer(this.metricsCameraBuffer, 0, cameraBlockFor(camData.camera, mW, mH));
-      this.metricsForwardPass.encode(encoder);
-      this.metricsRasterizer.encode(encoder, mW, mH);
-      hip.downsampleRGBA8(this.device, image.texture, baseW, baseH, this.metricsTarget, mW, mH);
-      this.metricsPass.computeMetricMap(encoder, this.metricsRasterizer.getOutputTextureView(), this.metricsTarget, { threshold: c.metricThreshold });
-      this.metricsPass.computeMetricCounts(encoder, { splatBuffer: this.metricsForwardPass.getResources().splatBuffer,
-        tileOffsetsBuffer: this.metricsRasterizer.getTileOffsetsBuffer(), tileIndicesBuffer: this.metricsForwardPass.getSortedIndicesBuffer(),
-        nContribTexture: this.metricsRasterizer.getNContribTextureView() }, { clear: false });
+    const counts = this.metricsPass.getMetricCountsBuffer();
+    encoder.clearBuffer(counts);
+    const dev = this.device, L = this.metricLanes;
+    let usedViews = 0, taken = 0;
+    try {
+      for (let attempt = 0; attempt < viewsTarget * 4 && usedViews < viewsTarget; attempt++) {
+        const idx = Math.floor(this.random() * this.trainCameras.length);
+        const camData = this.trainCameras[idx], image = this.images[idx];
+        if (!camData || !image) continue;
+        if (image.width !== baseW || image.height !== baseH) continue;
+        // every rank walks the same view list; the work is sharded round-robin and the counts are all-reduced below
+        const take = (usedViews % this.worldSize) === this.rank;
+        usedViews++;
+        if (!take) continue;
+        const k = taken % L;   // this rank's views in turn on its metric lanes; every lane's pass adds into set 0's counts
+        taken++;
+        const set = this.metricSet(k), fw = set[0], rast = set[1], mpass = set[2], target = set[3], cam = set[4];
+        if (k > 0) {
+          if (taken <= L) { mpass.setMetricCountsTarget(counts); dev.laneOrder(k, 0); }   // the lane's first view of this event: behind the clear
+          dev.selectLane(k);
+        }
+        dev.queue.writeBuffer(cam, 0, cameraBlockFor(camData.camera, mW, mH));
+        fw.encode(encoder);
+        rast.encode(encoder, mW, mH);
+        hip.downsampleRGBA8(dev, image.texture, baseW, baseH, target, mW, mH);
+        mpass.computeMetricMap(encoder, rast.getOutputTextureView(), target, { threshold: c.metricThreshold });
+        mpass.computeMetricCounts(encoder, { splatBuffer: fw.getResources().splatBuffer, tileOffsetsBuffer: rast.getTileOffsetsBuffer(),
+          tileIndicesBuffer: fw.getSortedIndicesBuffer(), nContribTexture: rast.getNContribTextureView() }, { clear: false });
+        if (k > 0) dev.selectLane(0);
+      }
+    } finally {
+      dev.selectLane(0);
+      for (let k = 1; k < Math.min(L, taken); k++) dev.laneOrder(0, k);   // join: normalize / prepare / the exchange follow every lane
     }
     if (usedViews === 0) return;
     if (this.worldSize > 1) this.exchange.allreduceCounts(this.metricsPass.getMetricCountsBuffer(), this.pointCloud.num_points);   // u32 sum, in place
@@ -537,6 +573,7 @@ class Trainer {
       this[name] = null;
     }
     this.destroyMoreOpSets();
+    this.destroyMoreMetricSets();
     for (const b of this.cameraBuffers) b.destroy();
     this.cameraBuffers = [];
     for (const name of ['dpGrad', 'dpVisible', 'dpRows', 'dpFlag', 'metricsTarget']) { if (this[name]) this[name].destroy(); this[name] = null; }

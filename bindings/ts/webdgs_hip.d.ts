@@ -118,6 +118,8 @@ export class TiledBackwardPass {
                  accumulate?: { sums: HipBuffer; visible: HipBuffer; tileCounts: HipBuffer; guard: HipBuffer; stats: HipBuffer; first: boolean } | null): void;
   /** Whether Optimizer.stepWithGeometry also writes K17's packed gradient to getGradientsBuffer() (default true, as the reference's K17 does). */
   setGradientOutput(enabled: boolean): void;
+  /** computeMetricCounts adds into `counts` (another pass's metric counts) instead of this pass's own array; null restores its own. */
+  setMetricCountsTarget(counts: HipBuffer | null): void;
   setTrainingConfig(next: Partial<TrainingConfig>): void;
   getMetricMapTexture(): HipBuffer;
   computeLossOnly(encoder: HipEncoder | null, predicted: HipBuffer, target: HipBuffer): void;

@@ -231,6 +231,9 @@ class TiledBackwardPass {                // tiled-backward-pass.ts:71
   }
   /** Whether Optimizer.stepWithGeometry also writes K17's packed gradient to getGradientsBuffer() (default: yes, as the reference's K17 does). */
   setGradientOutput(enabled) { this.gradientOutput = !!enabled; addon.tiledBackwardSetGradientOutput(this.handle, enabled ? 1 : 0); }
+  /** computeMetricCounts of this pass adds into `counts` (another pass's getMetricCountsBuffer()) instead of its own array; null restores its own.
+   *  Several passes can then take the metric views of one densify event on different lanes (integer atomics: any order gives the same bits). */
+  setMetricCountsTarget(counts) { this.metricTarget = counts || null; addon.tiledBackwardSetMetricCountsTarget(this.handle, counts ? counts.ptr : null); }
   /** setTrainingConfig(next) (tiled-backward-pass.ts:812-830): loss weights of the next encode. */
   setTrainingConfig(next) {
     this.trainingConfig = Object.assign({ lambda_l1: 0.8, lambda_l2: 0.0, lambda_dssim: 0.2, c1: 0.0001, c2: 0.0009 }, this.trainingConfig || {}, next || {});

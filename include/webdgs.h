@@ -295,6 +295,11 @@ int wdgs_tiled_backward_set_viewport(wdgs_tiled_backward* op, uint32_t width, ui
 int wdgs_tiled_backward_set_training_config(wdgs_tiled_backward* op, const wdgs_training_config* cfg);
 void* wdgs_tiled_backward_gradients(wdgs_tiled_backward* op);     /* getGradientsBuffer: GaussianGradient[N] */
 void* wdgs_tiled_backward_metric_counts(wdgs_tiled_backward* op); /* getMetricCountsBuffer: u32[N] */
+/* computeMetricCounts of this pass adds into `counts_dev` (u32[num_points], e.g. another pass's getMetricCountsBuffer) instead of its own
+ * array; NULL restores its own.  No reference counterpart: runDensifyPruneMultiView (trainer.ts:373-497) walks its metric views one after
+ * the other through ONE pass; with a shared target several passes can take the views of one densify event on different lanes -- the
+ * counts are integer atomics, so every order gives the same bits.  The target must outlive the calls and hold at least num_points words. */
+int wdgs_tiled_backward_set_metric_counts_target(wdgs_tiled_backward* op, void* counts_dev);
 void* wdgs_tiled_backward_loss_image(wdgs_tiled_backward* op);    /* getLossTextureView: rgba32float W*H */
 void* wdgs_tiled_backward_metric_map(wdgs_tiled_backward* op);    /* getMetricMapTextureView: u32[W*H] */
 /* Whether the fused step (wdgs_optimizer_step_with_geometry) also writes K17's packed GaussianGradient[N] to the pass's gradient buffer

@@ -26,7 +26,10 @@ for i in range(4):
     images.append(dict(texture=dev.bufferFrom(trs.getOutputTextureView().read(np.uint8)), width=cfg.width, height=cfg.height))
     cameras.append(dict(camera=cams[i], width=cfg.width, height=cfg.height))
 trs.destroy(); tfw.destroy()
-t = Trainer(dev, seed=1, use_command_buffers=False)
+vpr = int(os.environ.get("WDGS_PROFILE_VPR", "1"))  # views per step: > 1 profiles the batched step (view-batched K1 / K17, the fp32 Adam pass)
+t = Trainer(dev, seed=1, use_command_buffers=False, views_per_rank=vpr)
+if vpr > 1:
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
 t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg)); t.setDataset(cameras, images)
 if os.environ.get("WDGS_PROFILE_FROZEN"):  # every learning rate 0: the same scene in every step (and in every build that is compared)
     t.setOptimizerHyperparameters({k: 0.0 for k in t.getOptimizerHyperparameters() if k.startswith("lr_")})

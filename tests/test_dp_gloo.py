@@ -183,3 +183,19 @@ def test_two_ranks_two_views_each_sliced_adam_equals_the_oracle_trainer(tmp_path
         assert np.array_equal(r["pos"][f:f + c].view(np.uint32), o.state["opt_pos"][f:f + c].view(np.uint32))
     f1, c1 = (int(x) for x in r1["own"])
     assert not np.array_equal(r0["pos"][f1:f1 + c1].view(np.uint32), o.state["opt_pos"][f1:f1 + c1].view(np.uint32)), "rank 0 does not train rank 1's slice"
+
+
+def test_only_an_aliasing_refusal_switches_the_exchange_to_staging():
+    """the in-place collectives fall back to a staging tensor ONLY for an error that says the arguments alias; anything
+    else -- transport errors, timeouts, the unforeseen -- is re-raised, so no rank ever changes its call sequence alone."""
+    ex = object.__new__(parallel.TorchExchange)
+    for text in ("NCCL error: unhandled system error", "watchdog caught collective operation timeout", "something nobody has seen before", "CUDA error: invalid argument",
+                 "Socket closed", ""):
+        ex._in_place = True
+        with pytest.raises(RuntimeError):
+            ex._out_of_place(RuntimeError(text))
+        assert ex._in_place
+    for text in ("output tensor must not alias the input tensor", "Tensors overlap in memory", "in-place reduce_scatter is not supported"):
+        ex._in_place = True
+        ex._out_of_place(RuntimeError(text))
+        assert not ex._in_place

@@ -155,6 +155,29 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert out["exchange"]["ms_per_step"] > 0 and 0 < out["exchange"]["frac_of_step"] < 1.0  # (not double-counted: ADVICE r2)
     assert out["timed_blocks"]["blocks"] >= 1 and out["steps"] == 3
     assert out["roofline"]["kernel"] and out["roofline"]["hbm_frac"] is not None
+    # per-view and per-step kernels are reported apart: a batched run's view-batched K1 / K17 and its optimizer pass are per STEP
+    per_view, per_step = out["kernel_ms_per_view"], out["kernel_ms_per_step"]
+    assert "backward_rasterize" in per_view and "rasterize" in per_view and not (set(per_view) & set(per_step))
+    assert "project_count_views" in per_step and "geometry_backward_views" in per_step and "project_count_views" not in per_view
+    assert out["batched_step"] is None, "the N > 1 line's like-for-like base is `single_gpu_same_step`"
+
+
+def test_single_gpu_bench_line_carries_the_batched_step_base(tmp_path):
+    """the N = 1 record also holds the 8-views-per-step rate -- the like-for-like base of the 1 -> 8 GPU curve -- so a
+    ratio of two SCALE records cannot be taken against the (per view slower) one-view step by accident."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_BENCH_WATCHDOG="500")
+    root = os.path.dirname(HERE)
+    r = _run_child([sys.executable, os.path.join(root, "bench.py"), "--config", "c2", "--steps", "6", "--warmup", "2", "--min-seconds", "0.05", "--sustained-steps", "0",
+                    "--no-cpu-baseline"], env, 560)
+    assert r.returncode == 0, _verdict(r)
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    b = out["batched_step"]
+    assert out["n_gpus"] == 1 and out["config"]["global_batch_views"] == 1
+    assert b["views_per_step"] == 8 and b["lanes"] == 3 and b["views_per_s"] > 0 and b["ms_per_step"] > 0 and b["dataset_views"] == 64
+    assert abs(b["views_per_s"] - 8 / (b["ms_per_step"] / 1e3)) / b["views_per_s"] < 2e-3
+    assert "geometry_backward_adam" in out["kernel_ms_per_view"] and out["kernel_ms_per_step"] == {}, "the one-view step has no per-step kernels"
 
 
 def _visible_gpus() -> int:

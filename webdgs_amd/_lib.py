@@ -207,6 +207,7 @@ SIGNATURES = {
     "wdgs_tiled_backward_set_training_config": (_I, [_P, C.POINTER(TrainingConfig)]),
     "wdgs_tiled_backward_gradients": (_P, [_P]),
     "wdgs_tiled_backward_metric_counts": (_P, [_P]),
+    "wdgs_tiled_backward_set_metric_counts_target": (_I, [_P, _P]),
     "wdgs_tiled_backward_loss_image": (_P, [_P]),
     "wdgs_tiled_backward_metric_map": (_P, [_P]),
     "wdgs_tiled_backward_accumulators": (_P, [_P]),

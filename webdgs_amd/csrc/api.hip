@@ -154,6 +154,7 @@ struct wdgs_tiled_backward {
     bool gradient_output;  // the fused K17 + Adam step also writes the packed gradient (wdgs_tiled_backward_set_gradient_output; default on)
     float* loss_image;   // rgba32f
     u32* metric_counts;  // u32[N]
+    u32* metric_counts_into;  // nullable: computeMetricCounts adds into THIS array instead (wdgs_tiled_backward_set_metric_counts_target)
     u32* metric_err;     // u32[W*H]
     u32* metric_flags;   // u32[W*H]
     u32* metric_minmax;  // u32[2] + scratch
@@ -1153,9 +1154,10 @@ int wdgs_tiled_backward_compute_metric_counts(wdgs_tiled_backward* op, const wdg
     WDGS_REQUIRE(op && res && res->splat_buffer && res->tile_offsets_buffer && res->tile_indices_buffer && res->n_contrib_texture, WDGS_E_INVALID,
                  "wdgs_tiled_backward_compute_metric_counts: incomplete resources");
     const u32 n = op->cfg.num_points;
-    if (clear) WDGS_CHECK_HIP(hipMemsetAsync(op->metric_counts, 0, (size_t)std::max(n, 1u) * 4, op->dev->stream));
+    u32* const counts = op->metric_counts_into ? op->metric_counts_into : op->metric_counts;
+    if (clear) WDGS_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)std::max(n, 1u) * 4, op->dev->stream));
     return launch_metric_count(op->dev, op->settings, ceil_div(op->cfg.viewport_width, 16), ceil_div(op->cfg.viewport_height, 16), res->tile_offsets_buffer,
-                               res->tile_indices_buffer, num_instances, res->splat_buffer, n, op->metric_flags, res->n_contrib_texture, op->metric_counts, n);
+                               res->tile_indices_buffer, num_instances, res->splat_buffer, n, op->metric_flags, res->n_contrib_texture, counts, n);
 }
 int wdgs_tiled_backward_normalize_metric_counts(wdgs_tiled_backward* op, uint32_t divisor) {
     WDGS_REQUIRE(op, WDGS_E_INVALID, "null op");
@@ -1178,6 +1180,11 @@ int wdgs_tiled_backward_set_training_config(wdgs_tiled_backward* op, const wdgs_
 }
 void* wdgs_tiled_backward_gradients(wdgs_tiled_backward* op) { return op ? op->gradients : nullptr; }
 void* wdgs_tiled_backward_metric_counts(wdgs_tiled_backward* op) { return op ? op->metric_counts : nullptr; }
+int wdgs_tiled_backward_set_metric_counts_target(wdgs_tiled_backward* op, void* counts_dev) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_backward_set_metric_counts_target: null op");
+    op->metric_counts_into = (u32*)counts_dev;
+    return WDGS_OK;
+}
 void* wdgs_tiled_backward_loss_image(wdgs_tiled_backward* op) { return op ? op->loss_image : nullptr; }
 void* wdgs_tiled_backward_metric_map(wdgs_tiled_backward* op) { return op ? op->metric_flags : nullptr; }
 void* wdgs_tiled_backward_accumulators(wdgs_tiled_backward* op) { return op ? op->acc : nullptr; }

@@ -180,6 +180,7 @@ template <int MODE>
 __global__ __launch_bounds__(256, 6) void geometry_backward_kernel(u32 n, const float* __restrict__ camera_f, RenderSettings settings,
                                                                  const u32* gaussians, int* __restrict__ acc, u32* __restrict__ acc_dirty,
                                                                  u32* __restrict__ gradients, ViewAccumulate va, ViewAdam ad) {
+    WD_STREAM_PRIO();
     constexpr bool ACC = MODE == 1;
     // The Trainer's forms (MODE 1, 2) CONSUME the accumulators: a row that held sums is put back to zero by the thread that read it and
     // the state word says "clean", so the next view's clear has nothing to do (backward_raster.hip: acc_clear_if_dirty).  The plain
@@ -258,6 +259,7 @@ struct GeometryViews {
 __global__ __launch_bounds__(256, 3) void geometry_backward_views_kernel(u32 n, RenderSettings settings, const u32* __restrict__ gaussians, GeometryViews gv,
                                                                         float* __restrict__ sums, u32* __restrict__ visible, u32* __restrict__ guard,
                                                                         u32 continues /*0: these are the step's first views; 1: the block already holds earlier views*/) {
+    WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0u) {
         u32 g = continues ? *guard : 0u;

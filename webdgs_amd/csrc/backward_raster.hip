@@ -327,6 +327,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
 // c3: 8-19 us).  After the plain K17 (TiledBackwardPass.encode, which leaves the sums readable) or a resize the word says dirty and the
 // whole buffer is cleared here.  The word is device state, so a recorded command buffer takes the right branch at every replay.
 __global__ __launch_bounds__(256) void acc_clear_if_dirty_kernel(int4* __restrict__ acc, u32 quads, const u32* __restrict__ acc_dirty) {
+    WD_STREAM_PRIO();
     if (*acc_dirty == 0u) return;
     const int4 z = make_int4(0, 0, 0, 0);
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += gridDim.x * blockDim.x) acc[i] = z;
@@ -350,8 +351,10 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
     static const bool one_wave = !(std::getenv("WDGS_BWR_WPW") && std::getenv("WDGS_BWR_WPW")[0] == '4');
     // WDGS_BWR_SUMS=butterfly: round 2's register-only reduction (same-box A/B; the LDS form is 6 KB of LDS per wave instead of 4)
     static const bool lds_sums = !(std::getenv("WDGS_BWR_SUMS") && std::getenv("WDGS_BWR_SUMS")[0] == 'b');
+    // WDGS_BWR_PAD_LDS=<bytes>: unused dynamic LDS per workgroup -- an occupancy experiment (fewer resident waves of this kernel per CU)
+    static const u32 pad_lds = std::getenv("WDGS_BWR_PAD_LDS") ? (u32)std::atoi(std::getenv("WDGS_BWR_PAD_LDS")) : 0u;
 #define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
-    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), 0, st, num_tiles_x, tiles, (const u32*)ranges, \
+    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), pad_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
                 (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs

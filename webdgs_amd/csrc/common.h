@@ -101,6 +101,18 @@ struct KernelScope {
     }
 };
 
+// Wave priority of the bandwidth- / latency-bound kernels (0..3; the rasterization kernels stay at the default 0): where a lane's streaming
+// kernel shares a SIMD with another lane's rasterization waves, its few instructions are issued ahead of theirs, so it gets its memory
+// requests out and leaves sooner.  Issue order only -- results cannot depend on it.  A build-time choice (make STREAM_PRIO=n) so that two
+// builds can be compared on one box (WDGS_LIB_PATH).
+#ifndef WDGS_STREAM_PRIO
+#define WDGS_STREAM_PRIO 0
+#endif
+#define WD_STREAM_PRIO()                                                     \
+    do {                                                                     \
+        if (WDGS_STREAM_PRIO > 0) __builtin_amdgcn_s_setprio(WDGS_STREAM_PRIO); \
+    } while (0)
+
 #define WDGS_LAUNCH(dev, kname, kernel, grid, block, shmem, ...)                           \
     do {                                                                                   \
         KernelScope _ks((dev), (kname));                                                   \

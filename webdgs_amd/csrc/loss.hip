@@ -23,6 +23,7 @@ constexpr u32 PPT = 4;       // vertically adjacent pixels per thread
 __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32* __restrict__ pred, const u32* __restrict__ targ,
                                                          wdgs_training_config cfg, float4* __restrict__ out, int4* __restrict__ acc, u32 acc_quads,
                                                          const u32* __restrict__ acc_dirty) {
+    WD_STREAM_PRIO();
     // clearBuffer x4 of the gradient accumulators (tiled-backward-pass.ts:624-627) rides on this kernel, which precedes the backward
     // rasterization anyway: the accumulators' state word (backward_raster.hip) says whether anything has to be cleared at all -- after a
     // consuming K17 nothing has -- so the clear is one scalar load here instead of a launch of its own.

@@ -25,6 +25,7 @@ namespace {
 __global__ __launch_bounds__(256) void adam_repack_kernel(u32 n, wdgs_adam_hyperparameters h, const u32* __restrict__ tile_counts,
                                                            const u32* __restrict__ gradients, float4* opt_rot, float* opt_opacity, CsView cs, u32* gaussians,
                                                            u32* sh_buffer, const u32* __restrict__ guard, u32* dc_words) {
+    WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     if (guard && *guard != 0u) return;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 cou
                                                                u32* gaussians, u32* sh_buffer,
                                                                const u32* __restrict__ guard, u32* __restrict__ guard_seen_host, u32* __restrict__ rows_out,
                                                                u32* dc_words) {
+    WD_STREAM_PRIO();
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     if (guard && *guard != 0u) {
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256) void adam_repack_f32_kernel(u32 first, u32 cou
 // [skip_first, skip_first + skip_count), which this rank re-packed itself.
 __global__ __launch_bounds__(256) void apply_rows_kernel(u32 n, const u32* __restrict__ rows, u32 skip_first, u32 skip_count, const u32* __restrict__ guard, u32* __restrict__ guard_seen_host,
                                                           u32* __restrict__ gaussians, u32* __restrict__ sh_buffer, u32* __restrict__ dc_words) {
+    WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0u && guard && guard_seen_host && *guard != 0u) *guard_seen_host = 1u;  // (a rank whose owned slice is empty runs no Adam kernel)
     if (idx >= n || (idx >= skip_first && idx - skip_first < skip_count)) return;

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
                                                              u32* __restrict__ tile_counts, u32* __restrict__ visible_shards,
                                                              u32* __restrict__ block_counts, u32* __restrict__ column_counts /*[num_tiles_x][gridDim.x]*/,
                                                              const u32* __restrict__ dc_words /*nullable: u32[N][2], the trained SH-DC halves (adam.h)*/) {
+    WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool visible = false;
     u32 num_tiles_out = 0u;
@@ -244,6 +245,7 @@ struct ProjectViews {
 };
 __global__ __launch_bounds__(256) void project_count_views_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer, RenderSettings settings,
                                                                    TileInfo ti, ProjectViews pv, const u32* __restrict__ dc_words) {
+    WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ u32 s_col[256];
     __shared__ u32 s_vis[4], s_cnt[4];
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256) void project_count_views_kernel(u32 n, const u
 // stats[0] = total tile entries (update_stats, src/shaders/update-stats.wgsl:19-35); stats[2] = overflow flag.
 __global__ void update_stats_kernel(u32 n, const u32* __restrict__ offsets, const u32* __restrict__ counts, u32 capacity, u32* __restrict__ stats,
                                     u32* __restrict__ visible_shards, u32* __restrict__ host_mirror) {
+    WD_STREAM_PRIO();
     // 64 threads: fold the visible-count shards (and clear them for the next encode)
     u32 v = visible_shards[threadIdx.x];
     visible_shards[threadIdx.x] = 0u;
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(256) void emit_kernel(u32 n, const u32* __restrict_
                                                     const u32* __restrict__ tile_counts, u32* __restrict__ tile_offsets,
                                                     const u32* __restrict__ block_offsets, RenderSettings settings, TileInfo ti,
                                                     u32* __restrict__ keys, u32* __restrict__ values, u32 capacity) {
+    WD_STREAM_PRIO();
     __shared__ u32 s_pre[4][64], s_org[4][64], s_w[4][64], s_inv[4][64], s_dep[4][64];
     __shared__ u32 s_wtot[4];
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
                                                             const u32* __restrict__ column_offsets /*[num_tiles_x][gridDim.x], scanned*/,
                                                             const u32* __restrict__ column_totals, u32 inv_ntx /*2^32 / num_tiles_x, rounded up*/,
                                                             u32* __restrict__ keys, u32* __restrict__ values, u32 capacity) {
+    WD_STREAM_PRIO();
     __shared__ u32 s_pre[256];                     // exclusive prefix of the entry counts over the workgroup's Gaussians
     __shared__ u32 s_box[256];                     // min_x | min_y << 8 | width << 16  (all < 256 on this path)
     __shared__ u32 s_inv[256], s_dep[256];

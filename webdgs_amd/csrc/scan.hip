@@ -112,6 +112,7 @@ __device__ __forceinline__ void stats_epilogue(u32 carry, const ScanStatsEpilogu
 // them: one round up to 1 M Gaussians).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ total_out,
                                                                        ScanStatsEpilogue ep) {
+    WD_STREAM_PRIO();
     __shared__ u32 lds[4];
     const u32 carry = scan_inplace_by_block(block_sums, num_blocks, lds);
     if (threadIdx.x == 0 && total_out) *total_out = carry;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(u32* __re
 // its histogram and row-scan kernels, here without reading a key.
 __global__ __launch_bounds__(SCAN_THREADS) void forward_scan_kernel(u32* __restrict__ block_sums, u32 num_blocks, u32* __restrict__ column_counts,
                                                                     u32* __restrict__ column_totals, ScanStatsEpilogue ep) {
+    WD_STREAM_PRIO();
     __shared__ u32 lds[4];
     if (blockIdx.x == 0u) {
         const u32 carry = scan_inplace_by_block(block_sums, num_blocks, lds);

@@ -42,6 +42,7 @@ struct DigitOf {
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, DigitOf digit_of,
                                                                  u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/, u32* __restrict__ ranges_init,
                                                                  u32 total_tiles) {
+    WD_STREAM_PRIO();
     __shared__ u32 lh[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
 // One workgroup per digit: in-place exclusive scan of counts[digit][0 .. active_parts), row total -> totals[digit].
 __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ counts, const u32* __restrict__ count_ptr, u32 num_parts,
                                                               u32* __restrict__ totals) {
+    WD_STREAM_PRIO();
     __shared__ u32 s_w[4];
     const u32 active = (*count_ptr + SORT_TILE - 1u) / SORT_TILE;
     u32* row = counts + (size_t)blockIdx.x * num_parts;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
                                                                     const u32* __restrict__ count_ptr, DigitOf digit_of, u32 num_parts,
                                                                     const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals,
                                                                     u32* __restrict__ ranges, u32 ranges_mode, u32 total_tiles) {
+    WD_STREAM_PRIO();
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
     const u32 dmask = digit_of.dmask;
     const u32 count = *count_ptr;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
 // instead of 23) -- one launch over T+1 waves instead of an init launch plus a pass over all E keys.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, u32 total_tiles,
                                                            u32* __restrict__ ranges) {
+    WD_STREAM_PRIO();
     const u32 t = blockIdx.x * 4u + (threadIdx.x >> 6);  // wave index = tile
     const u32 lane = threadIdx.x & 63u;
     if (t > total_tiles) return;
@@ -459,6 +463,7 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 // the result); `alt` is the other ping-pong pair, used as scratch by oversized segments only.
 __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
                                                                     u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles) {
+    WD_STREAM_PRIO();
     __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP];  // one pair: every pass reads its input into registers before anyone scatters
     __shared__ seg_hist_t whist[SEG_THREADS / 64][SEG_BINS];
     __shared__ u32 s_base[RADIX];

@@ -586,6 +586,13 @@ class TiledBackwardPass:
     def getGradientsBuffer(self) -> HipBuffer:
         return self.device.view(self.device.lib.wdgs_tiled_backward_gradients(self.handle), 32 * max(1, self.pointCloud.num_points))
 
+    def setMetricCountsTarget(self, counts: Optional[HipBuffer]) -> None:
+        """``computeMetricCounts`` of this pass adds into ``counts`` (another pass's ``getMetricCountsBuffer()``) instead of its own array;
+        ``None`` restores its own.  Lets several passes take the metric views of one densify event on different lanes (integer atomics:
+        any order gives the same bits).  No reference counterpart."""
+        self._metric_target = counts  # (kept alive)
+        check(self.device.lib.wdgs_tiled_backward_set_metric_counts_target(self.handle, counts.ptr if counts is not None else None))
+
     def getMetricCountsBuffer(self) -> HipBuffer:
         return self.device.view(self.device.lib.wdgs_tiled_backward_metric_counts(self.handle), 4 * max(1, self.pointCloud.num_points))
 

@@ -85,6 +85,11 @@ class Trainer:
         self.metricsForwardPass = self.metricsRasterizer = self.metricsPass = None
         self.metricsViewportWidth = self.metricsViewportHeight = 0
         self.metricsTarget: Optional[ops.HipBuffer] = None
+        # The metric views of a densify event are independent until normalizeMetricCounts (counts are integer atomics: any order gives the
+        # same bits): they are dealt to `metric_lanes` op sets, each on a device lane of its own, all adding into set 0's counts
+        # (TiledBackwardPass.setMetricCountsTarget).  The reference walks them one after the other through one pass (trainer.ts:391-430).
+        self.metric_lanes = max(1, min(int(os.environ.get("WDGS_METRIC_LANES", self.DEFAULT_LANES)), ops.MAX_LANES))
+        self._more_metric_sets: list = []  # [forwardPass, rasterizer, metricsPass, target, cameraBuffer] of metric lanes 1..
         self.pointCloud: Optional[ops.PointCloud] = None
         self.cameraBuffer = device.createBuffer(272, "camera uniform")
         self.metricsCameraBuffer = device.createBuffer(272, "metrics camera uniform")
@@ -116,6 +121,12 @@ class Trainer:
 
     DEFAULT_LANES = 3
     _OP_NAMES = ("forwardPass", "rasterizer", "backwardPass", "metricsForwardPass", "metricsRasterizer", "metricsPass", "optimizer")
+
+    def _destroy_more_metric_sets(self) -> None:
+        for more in self._more_metric_sets:
+            for op in more[:3]:
+                op.destroy()
+        self._more_metric_sets = []
 
     def _destroy_more_op_sets(self) -> None:
         for ops_of_lane in self._more_op_sets:
@@ -158,7 +169,7 @@ class Trainer:
         old = self.pointCloud
         self.pointCloud = request["pointCloud"]
         self._invalidate_command_buffers()
-        passes = [self.forwardPass, self.backwardPass, self.metricsForwardPass, self.metricsPass] + [op for more in self._more_op_sets for op in (more[0], more[2])]
+        passes = [self.forwardPass, self.backwardPass, self.metricsForwardPass, self.metricsPass] + [op for more in self._more_op_sets + self._more_metric_sets for op in (more[0], more[2])]
         kept = self.reuse_passes and old is not None and all(p.setPointCloud(self.pointCloud) for p in passes if p is not None)
         if not kept:
             for name in self._OP_NAMES:
@@ -167,6 +178,7 @@ class Trainer:
                     op.destroy()
                 setattr(self, name, None)
             self._destroy_more_op_sets()
+            self._destroy_more_metric_sets()
         self.optimizer = ops.Optimizer(self.device, self.pointCloud, oldParams or self.optimizerHyperparameters, request.get("optimizerInitialState"))
         self.optimizerHyperparameters = dict(self.optimizer.getHyperparameters())
         self._dc_words = self.optimizer.setDeferredSH(self.pointCloud, True) if self.deferred_sh else None
@@ -180,7 +192,7 @@ class Trainer:
         self.ensurePipelines(self.lastViewportWidth, self.lastViewportHeight)
 
     def _forward_passes(self) -> list:
-        return [p for p in [self.forwardPass, self.metricsForwardPass] + [more[0] for more in self._more_op_sets] if p is not None]
+        return [p for p in [self.forwardPass, self.metricsForwardPass] + [more[0] for more in self._more_op_sets + self._more_metric_sets] if p is not None]
 
     def flushPointCloud(self) -> None:
         """Brings the point cloud's SH rows up to date with what has been trained (``Optimizer.flushSH``): call before a device-side reader
@@ -226,7 +238,7 @@ class Trainer:
     def setTrainingConfig(self, next_cfg: dict) -> None:
         self.trainingConfig.update({k: v for k, v in next_cfg.items() if v is not None})
         self._invalidate_command_buffers()
-        for p in [self.backwardPass, self.metricsPass] + [more[2] for more in self._more_op_sets]:
+        for p in [self.backwardPass, self.metricsPass] + [more[2] for more in self._more_op_sets + self._more_metric_sets]:
             if p is not None:
                 p.setTrainingConfig(next_cfg)
 
@@ -337,6 +349,7 @@ class Trainer:
             if op is not None:
                 op.destroy()
             setattr(self, name, None)
+        self._destroy_more_metric_sets()
         self.metricsViewportWidth, self.metricsViewportHeight = w, h
         self.metricsForwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.metricsCameraBuffer,
                                                        dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
@@ -345,6 +358,20 @@ class Trainer:
         self.metricsPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
         self.metricsTarget = self.device.createBuffer(4 * w * h, "metrics-gt-downsampled")
         return w, h
+
+    def _metric_set(self, k: int) -> tuple:
+        """(forwardPass, rasterizer, metricsPass, downsampled-GT buffer, camera buffer) of metric lane ``k``; sets 1.. are built on first use."""
+        if k == 0:
+            return self.metricsForwardPass, self.metricsRasterizer, self.metricsPass, self.metricsTarget, self.metricsCameraBuffer
+        w, h = self.metricsViewportWidth, self.metricsViewportHeight
+        while len(self._more_metric_sets) < k:
+            cam = self.device.createBuffer(272, "metrics camera uniform")
+            fw = ops.TiledForwardPass(self.device, self.pointCloud, cam, dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+            fw.setDcSource(self._dc_words)
+            self._more_metric_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
+                                           ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig)),
+                                           self.device.createBuffer(4 * w * h, "metrics-gt-downsampled"), cam])
+        return tuple(self._more_metric_sets[k - 1])
 
     @staticmethod
     def metrics_camera(camera: np.ndarray, width: int, height: int) -> np.ndarray:
@@ -672,6 +699,7 @@ class Trainer:
                 op.destroy()
             setattr(self, name, None)
         self._destroy_more_op_sets()
+        self._destroy_more_metric_sets()
         self._dp_grad = self._dp_visible = self._dp_rows = self._dp_flag = self.metricsTarget = None
         self._camera_buffers = []
         self.pointCloud = None
@@ -686,28 +714,43 @@ class Trainer:
         c = self.densifyPruneConfig
         viewsTarget = max(1, int(c["metricViews"]))
         encoder = self.device.createCommandEncoder("densify-prune multiview metrics")
-        encoder.clearBuffer(self.metricsPass.getMetricCountsBuffer())
-        usedViews, attempts = 0, 0
-        while attempts < viewsTarget * 4 and usedViews < viewsTarget:
-            attempts += 1
-            idx = self._rng.randrange(len(self.trainCameras))
-            camData, image = self.trainCameras[idx], self.images[idx]
-            if image["width"] != baseW or image["height"] != baseH:
-                continue
-            # every rank walks the same view list; the work is sharded round-robin and the counts are all-reduced below
-            take = (usedViews % self.world_size) == self.rank
-            usedViews += 1
-            if not take:
-                continue
-            self.metricsCameraBuffer.write(self.metrics_camera(camData["camera"], mW, mH))
-            self.metricsForwardPass.encode(encoder)
-            self.metricsRasterizer.encode(encoder, mW, mH)
-            ops.downsampleRGBA8(self.device, image["texture"], baseW, baseH, self.metricsTarget, mW, mH)
-            self.metricsPass.computeMetricMap(encoder, self.metricsRasterizer.getOutputTextureView(), self.metricsTarget, dict(threshold=c["metricThreshold"]))
-            self.metricsPass.computeMetricCounts(encoder, dict(splatBuffer=self.metricsForwardPass.getResources()["splatBuffer"],
-                                                               tileOffsetsBuffer=self.metricsRasterizer.getTileOffsetsBuffer(),
-                                                               tileIndicesBuffer=self.metricsForwardPass.getSortedIndicesBuffer(),
-                                                               nContribTexture=self.metricsRasterizer.getNContribTextureView()), dict(clear=False))
+        counts = self.metricsPass.getMetricCountsBuffer()
+        encoder.clearBuffer(counts)
+        dev, L = self.device, self.metric_lanes
+        usedViews, attempts, taken = 0, 0, 0
+        try:
+            while attempts < viewsTarget * 4 and usedViews < viewsTarget:
+                attempts += 1
+                idx = self._rng.randrange(len(self.trainCameras))
+                camData, image = self.trainCameras[idx], self.images[idx]
+                if image["width"] != baseW or image["height"] != baseH:
+                    continue
+                # every rank walks the same view list; the work is sharded round-robin and the counts are all-reduced below
+                take = (usedViews % self.world_size) == self.rank
+                usedViews += 1
+                if not take:
+                    continue
+                k = taken % L   # this rank's views in turn on its metric lanes; every lane's pass adds into set 0's counts
+                taken += 1
+                fw, rast, mpass, target, cam = self._metric_set(k)
+                if k > 0:
+                    if taken <= L:   # the lane's first view of this event: behind the clear (and whatever else lane 0 holds)
+                        mpass.setMetricCountsTarget(counts)
+                        dev.laneOrder(k, 0)
+                    dev.selectLane(k)
+                cam.write(self.metrics_camera(camData["camera"], mW, mH))
+                fw.encode(encoder)
+                rast.encode(encoder, mW, mH)
+                ops.downsampleRGBA8(dev, image["texture"], baseW, baseH, target, mW, mH)
+                mpass.computeMetricMap(encoder, rast.getOutputTextureView(), target, dict(threshold=c["metricThreshold"]))
+                mpass.computeMetricCounts(encoder, dict(splatBuffer=fw.getResources()["splatBuffer"], tileOffsetsBuffer=rast.getTileOffsetsBuffer(),
+                                                       tileIndicesBuffer=fw.getSortedIndicesBuffer(), nContribTexture=rast.getNContribTextureView()), dict(clear=False))
+                if k > 0:
+                    dev.selectLane(0)
+        finally:
+            dev.selectLane(0)
+            for k in range(1, min(L, taken)):
+                dev.laneOrder(0, k)   # join: normalize / prepare / the exchange follow every lane
         if usedViews == 0:
             return
         if self.world_size > 1:  # u32 sum on the device, in place in the pass's own buffer (SURVEY 8(e) "Determinism")
