@@ -13,6 +13,9 @@ echo "== bench c3 (headline, full)"; timeout -k 10 600 python3 bench.py > $O/${T
 echo "== bench c2"; timeout -k 10 300 python3 bench.py --config c2 > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
 echo "== bench c5"; timeout -k 10 400 python3 bench.py --config c5 --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c5.json 2> $O/${TAG}_bench_c5.err
 echo "== bench c3, 8 views per step"; for L in 3 1; do timeout -k 10 500 python3 bench.py --views-per-rank 8 --lanes $L --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c3_vpr8_lanes${L}.json 2> $O/${TAG}_bench_vpr8.err; done
+echo "== the same measurement through the TypeScript-side host (node + N-API addon)"
+timeout -k 10 400 node bindings/napi/bench.js --config c3 > $O/${TAG}_benchjs_c3.json 2> $O/${TAG}_benchjs_c3.err
+timeout -k 10 500 node bindings/napi/bench.js --config c3 --views-per-step 8 --steps 10 --warmup 2 > $O/${TAG}_benchjs_c3_vpr8.json 2> $O/${TAG}_benchjs_c3_vpr8.err
 echo "== kernel trace of the c3 bench"
 rm -rf $O/prof_${TAG}
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --sustained-steps 0 --no-cpu-baseline --min-seconds 0.3 > $O/${TAG}_bench_c3_under_rocprof.json 2> $O/${TAG}_rocprof.err
@@ -25,5 +28,7 @@ cat $O/${TAG}_hbm_by_kernel.md
 python3 -c "
 import json
 for f in ('bench_c3','bench_c2','bench_c5','bench_c3_vpr8_lanes3','bench_c3_vpr8_lanes1'):
-    d=json.load(open('$O/${TAG}_'+f+'.json')); print(f, d['value'], d['ms_per_step'], d.get('c3_as_written_iters_per_s'), d['roofline']['kernel'], d['roofline'].get('frac'), d['roofline'].get('hbm_frac'))
+    d=json.load(open('$O/${TAG}_'+f+'.json')); print(f, d['value'], d['ms_per_step'], d.get('c3_as_written_iters_per_s'), d['roofline']['kernel'], d['roofline'].get('frac'), d['roofline'].get('hbm_frac'), d.get('batched_step'))
+for f in ('benchjs_c3','benchjs_c3_vpr8'):
+    d=json.load(open('$O/${TAG}_'+f+'.json')); print(f, d['value'], d['ms_per_step'], d['ms_per_step_awaiting_every_step'])
 "
