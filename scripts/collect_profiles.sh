@@ -18,7 +18,7 @@ timeout -k 10 400 node bindings/napi/bench.js --config c3 > $O/${TAG}_benchjs_c3
 timeout -k 10 500 node bindings/napi/bench.js --config c3 --views-per-step 8 --steps 10 --warmup 2 > $O/${TAG}_benchjs_c3_vpr8.json 2> $O/${TAG}_benchjs_c3_vpr8.err
 echo "== kernel trace of the c3 bench"
 rm -rf $O/prof_${TAG}
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --sustained-steps 0 --no-cpu-baseline --min-seconds 0.3 > $O/${TAG}_bench_c3_under_rocprof.json 2> $O/${TAG}_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --sustained-steps 0 --no-cpu-baseline --no-batched-step --min-seconds 0.3 > $O/${TAG}_bench_c3_under_rocprof.json 2> $O/${TAG}_rocprof.err
 cp $(find $O/prof_${TAG} -name "*kernel_stats.csv" | head -1) $O/${TAG}_c3_kernel_stats.csv
 echo "== PMC passes"
 timeout -k 10 900 bash scripts/pmc.sh ${TAG} c3 3 > $O/${TAG}_pmc.log 2>&1 || { tail -5 $O/${TAG}_pmc.log; exit 1; }

@@ -43,30 +43,23 @@ def _f16_words(a64: np.ndarray, halves_per_row: int) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- PLY
 def decodeHeader(data: bytes):
-    """``decodeHeader`` (``utils/plyreader.ts:1-54``): returns (vertexCount, propertyTypes in declaration order, vertex byte offset)."""
-    header_text, off = "", 0
-    while True:
-        chunk = data[off:off + 50]
-        if not chunk:
-            raise ValueError("PLY header: 'end_header' not found")
-        header_text += chunk.decode("utf-8", "replace")
-        off += 50
-        if "end_header" in header_text:
-            break
+    """``decodeHeader`` (``utils/plyreader.ts:1-54``): returns (vertexCount, propertyTypes in declaration order, vertex byte offset).  The header
+    is the text in front of the word ``end_header``; the payload starts one byte after that word (the reference's own offset rule).  A
+    ``property`` line is taken as ``property <type> <name>`` -- so ``property list uchar int vertex_indices`` declares a property named
+    ``uchar`` of type ``list``, exactly as the reference's three-word match reads it; only ``float`` and ``uchar`` TYPES are ever read."""
+    end = data.find(b"end_header")
+    if end < 0:
+        raise ValueError("PLY header: 'end_header' not found")
     vertex_count, props = 0, {}
-    for raw in header_text.split("\n"):
-        line = raw.strip()
-        if line.startswith("element vertex"):
-            m = re.search(r"\d+", line)
-            if m:
-                vertex_count = int(m.group(0))
-        elif line.startswith("property"):
-            m = re.search(r"(\w+)\s+(\w+)\s+(\w+)", line)
-            if m:
-                props[m.group(3)] = m.group(2)
-        elif line == "end_header":
-            break
-    return vertex_count, props, header_text.index("end_header") + len("end_header") + 1
+    for raw in data[:end].decode("utf-8", "replace").split("\n"):
+        words = raw.split()
+        if words[:2] == ["element", "vertex"]:
+            digits = re.search(r"\d+", raw)
+            if digits:
+                vertex_count = int(digits.group(0))
+        elif words and words[0] == "property" and len(words) >= 3:
+            props[words[2]] = words[1]
+    return vertex_count, props, end + len(b"end_header") + 1
 
 
 def nShCoeffs(deg: float) -> int:
