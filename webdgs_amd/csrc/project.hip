@@ -243,7 +243,11 @@ struct ProjectViews {
     u32* block_counts[WDGS_MAX_BATCH_VIEWS];
     u32* column_counts[WDGS_MAX_BATCH_VIEWS];   // all null or none null
 };
-__global__ __launch_bounds__(256) void project_count_views_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer, RenderSettings settings,
+// resident waves per SIMD the register allocation of the view-batched K1 aims at (make K1V_WAVES=n: a build-time choice, for same-box comparisons)
+#ifndef WDGS_K1V_WAVES
+#define WDGS_K1V_WAVES 4
+#endif
+__global__ __launch_bounds__(256, WDGS_K1V_WAVES) void project_count_views_kernel(u32 n, const u32* __restrict__ gaussians, const u32* __restrict__ sh_buffer, RenderSettings settings,
                                                                    TileInfo ti, ProjectViews pv, const u32* __restrict__ dc_words) {
     WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
