@@ -5,6 +5,7 @@ export interface LoadedImage {              // utils/load-images.ts:1-8
   name: string; file: string | { name: string; data: Buffer }; bitmap: Bitmap; width: number; height: number; texture: HipBuffer | null;
 }
 export function decodePNG(bytes: Buffer | Uint8Array): Bitmap;
+export function decodeJPEG(bytes: Buffer | Uint8Array): Bitmap;
 export function encodePNG(rgba: Uint8Array, width: number, height: number): Buffer;
 export function decodeImage(bytes: Buffer | Uint8Array, name?: string): Bitmap;
 export function compareNames(a: string, b: string): number;

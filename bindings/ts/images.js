@@ -11,6 +11,7 @@
 const fs = require('fs');
 const path = require('path');
 const zlib = require('zlib');
+const { decodeJPEG } = require('./jpeg.js');
 
 const PNG_MAGIC = Buffer.from([0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a]);
 
@@ -92,7 +93,8 @@ function encodePNG(rgba, width, height) {
 function decodeImage(bytes, name) {
   const buf = Buffer.isBuffer(bytes) ? bytes : Buffer.from(bytes);
   if (buf.length >= 8 && buf.compare(PNG_MAGIC, 0, 8, 0, 8) === 0) return decodePNG(buf);
-  throw new Error(`${name || 'image'}: only PNG can be decoded without a browser (createImageBitmap); convert JPEG ground truth to PNG`);
+  if (buf.length >= 3 && buf[0] === 0xff && buf[1] === 0xd8) return decodeJPEG(buf);
+  throw new Error(`${name || 'image'}: neither a PNG nor a JPEG file`);
 }
 
 /** Ordering of a.localeCompare(b, undefined, { numeric: true, sensitivity: 'base' }) (load-images.ts:17). */
@@ -123,4 +125,4 @@ function loadImages(files, device) {
   return out;
 }
 
-module.exports = { decodePNG, encodePNG, decodeImage, compareNames, createTextureFromImage, loadImages };
+module.exports = { decodePNG, decodeJPEG, encodePNG, decodeImage, compareNames, createTextureFromImage, loadImages };

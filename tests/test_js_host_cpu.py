@@ -82,6 +82,29 @@ def run(tmp_path_factory):
         buf = io.BytesIO()
         Image.fromarray(a[..., :3], "RGB").quantize(16).save(buf, format="PNG")
         (d / "images" / "pil_P.png").write_bytes(buf.getvalue())
+        # JPEG ground truth (what COLMAP datasets hold): samplings, qualities, progressive, restart markers, greyscale, sizes that are no multiple
+        # of the MCU -- the JS decoder (bindings/ts/jpeg.js) must give the texels Pillow's libjpeg-turbo gives
+        yy, xx = np.mgrid[0:45, 0:70]
+        smooth = np.stack([xx * 255 // 69, yy * 255 // 44, (xx + yy) * 7 % 256], -1).astype(np.uint8)
+        smooth[12:30, 20:50] = rng.integers(0, 256, (18, 30, 3), dtype=np.uint8)
+        k = 0
+        for sub in (0, 1, 2):
+            for prog in (False, True):
+                for q, pic in ((35, smooth), (92, smooth[:37, :53]), (75, smooth[:16, :17])):
+                    buf = io.BytesIO()
+                    Image.fromarray(np.ascontiguousarray(pic), "RGB").save(buf, format="JPEG", quality=q, subsampling=sub, progressive=prog, optimize=bool(k & 1))
+                    (d / "images" / f"jpg_{k:02d}.jpg").write_bytes(buf.getvalue())
+                    k += 1
+        for kw in (dict(restart_marker_blocks=3), dict(restart_marker_rows=1, progressive=True)):
+            buf = io.BytesIO()
+            Image.fromarray(smooth, "RGB").save(buf, format="JPEG", quality=85, subsampling=2, **kw)
+            (d / "images" / f"jpg_{k:02d}.jpeg").write_bytes(buf.getvalue())
+            k += 1
+        for prog in (False, True):
+            buf = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(smooth[:33, :47, 0]), "L").save(buf, format="JPEG", quality=80, progressive=prog)
+            (d / "images" / f"jpg_{k:02d}.JPG").write_bytes(buf.getvalue())
+            k += 1
     except ImportError:
         pass
     (d / "images" / "notes.txt").write_bytes(b"hello")
@@ -156,6 +179,11 @@ def test_images_are_filtered_ordered_decoded_and_dropped_alike(run):
         assert (out["images"][i]["width"], out["images"][i]["height"]) == (w.width, w.height)
         assert np.array_equal(np.fromfile(d / f"out_image_{i}.rgba", np.uint8).reshape(w.height, w.width, 4), w.bitmap), w.name
     names = [i["name"] for i in out["images"]]
+    try:
+        import PIL  # noqa: F401
+        assert sum(n.lower().endswith((".jpg", ".jpeg")) for n in names) == 22, "every JPEG written above was decoded by both hosts (and compared above)"
+    except ImportError:
+        pass
     assert names.index("Frame_2.png") < names.index("frame_9.PNG") < names.index("frame_10.png") and "broken.png" not in names and "photo.jpg" not in names
     assert "Failed to load image broken.png" in stderr and "Failed to load image photo.jpg" in stderr and out["png_round_trip"]
 
