@@ -59,6 +59,23 @@ function seededRandom(seed) {
 async function main() {
   const argv = process.argv.slice(2), args = parseArgs(argv);
   if (args.gpus > 1 && !process.env.WORLD_SIZE) { selfLaunch(args, argv); return; }
+  // WDGS_BENCH_SELFTEST=1: what a rank does in the launcher's CPU test (tests/test_bench_launcher.py) -- no addon, no GPU: the ranks meet through
+  // files beside the rendezvous path, rank 0 prints one line.  WDGS_BENCH_SELFTEST=fail makes the last rank exit non-zero.
+  if (process.env.WDGS_BENCH_SELFTEST) {
+    const world = parseInt(process.env.WORLD_SIZE || '1', 10), rank = parseInt(process.env.RANK || '0', 10);
+    if (process.env.WDGS_BENCH_SELFTEST === 'fail' && rank === world - 1) { console.error('selftest: this rank fails on purpose'); process.exit(7); }
+    const base = process.env.WDGS_RENDEZVOUS || path.join(os.tmpdir(), 'wdgs-selftest');
+    fs.writeFileSync(`${base}.rank${rank}`, String(process.pid));
+    const deadline = Date.now() + 20000;
+    let seen = 0;
+    while (Date.now() < deadline) {
+      seen = 0; for (let r = 0; r < world; r++) if (fs.existsSync(`${base}.rank${r}`)) seen++;
+      if (seen === world) break;
+      Atomics.wait(new Int32Array(new SharedArrayBuffer(4)), 0, 0, 20);
+    }
+    if (rank === 0) console.log(JSON.stringify({ selftest: true, n_gpus: world, n_ranks_seen: seen, self_launched: process.env.WDGS_BENCH_SELF_LAUNCHED === '1', argv }));
+    process.exit(seen === world ? 0 : 3);
+  }
 
   const hip = require(path.join(__dirname, '..', 'ts', 'webdgs_hip.js'));
   const parallel = require(path.join(__dirname, '..', 'ts', 'parallel.js'));

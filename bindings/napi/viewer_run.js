@@ -14,8 +14,9 @@ const meta = JSON.parse(fs.readFileSync(path.join(dir, 'meta.json'), 'utf8'));
 
 async function main() {
   const dev = new hip.HipDevice(0);
-  const pc = loaders.loadPointCloud(fs.readFileSync(path.join(dir, 'scene.ply')), dev);
-  const cams = loaders.loadCamera([{ name: 'cams.json', data: fs.readFileSync(path.join(dir, 'cams.json')) }]);
+  // meta.cloud_file: a .ply or COLMAP's points3D.bin; meta.camera_files: a camera JSON, or COLMAP's images.bin + cameras.bin (merged by loadCamera)
+  const pc = loaders.loadPointCloud(fs.readFileSync(path.join(dir, meta.cloud_file || 'scene.ply')), dev);
+  const cams = loaders.loadCamera((meta.camera_files || ['cams.json']).map((f) => ({ name: f, data: fs.readFileSync(path.join(dir, f)) })));
   const canvas = { width: meta.width, height: meta.height };
   const viewer = new Viewer(dev, null, canvas, 'rgba8unorm');
   viewer.setPointCloud(pc);

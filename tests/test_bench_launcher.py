@@ -67,3 +67,23 @@ def test_the_newest_counter_profile_describes_the_kernel_sources_in_the_tree():
         assert (newest.get("source_sha") or {}).get(kernel) == bench.source_sha(kernel), \
             f"{os.path.basename(files[0])} was collected for another version of {kernel}'s source: run scripts/collect_profiles.sh on the GPU and commit its profiles"
         assert newest["kernels"][kernel].get("SQ_INSTS_VALU", 0) > 0
+
+
+def test_node_bench_starts_its_own_ranks_and_relays_rank_zero():
+    """`node bindings/napi/bench.js --gpus N` from a bare shell: N child processes (RANK / WORLD_SIZE / LOCAL_RANK, one rendezvous path), rank 0's line
+    relayed, the worst child's exit code returned -- before the parent has loaded the addon (the CPU selftest body stands in for the GPU workload)."""
+    import shutil
+    node = shutil.which("node")
+    if not node:
+        import pytest
+        pytest.skip("node is not installed")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "WDGS_RENDEZVOUS")}
+    bench = os.path.join(ROOT, "bindings", "napi", "bench.js")
+    r = subprocess.run([node, bench, "--gpus", "3", "--config", "c2"], env=dict(env, WDGS_BENCH_SELFTEST="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["selftest"] and out["n_gpus"] == 3 and out["n_ranks_seen"] == 3 and out["self_launched"] is True and out["argv"] == ["--gpus", "3", "--config", "c2"]
+    r = subprocess.run([node, bench, "--gpus", "2"], env=dict(env, WDGS_BENCH_SELFTEST="fail"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rank 1 exited with 7" in r.stderr, (r.returncode, r.stderr[-1000:])

@@ -139,6 +139,97 @@ def test_js_loaded_ply_renders_like_the_python_loaded_one_and_the_viewer_follows
         v.destroy()
 
 
+def _quat_wxyz(R):
+    """Unit quaternion (w, x, y, z) of a proper rotation matrix (COLMAP's images.bin stores the world -> camera rotation that way)."""
+    t = np.trace(R)
+    if t > 0:
+        s = 2.0 * np.sqrt(t + 1.0)
+        return np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    i = int(np.argmax(np.diag(R)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = 2.0 * np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k])
+    q = np.zeros(4)
+    q[0], q[1 + i], q[1 + j], q[1 + k] = (R[k, j] - R[j, k]) / s, 0.25 * s, (R[j, i] + R[i, j]) / s, (R[k, i] + R[i, k]) / s
+    return q
+
+
+def test_a_colmap_dataset_with_jpeg_ground_truth_trains_alike_in_both_hosts(hip_device, orc, tmp_path):
+    """north_star: "outputs match ... on identical COLMAP/PLY inputs".  A COLMAP reconstruction as it lies on disk -- points3D.bin, images.bin,
+    cameras.bin and JPEG images -- goes through each host's OWN loaders (node: loaders.js + jpeg.js; Python: loaders.py + Pillow), each host trains the
+    cloud on it, and the trained clouds and the viewer frames must be equal byte for byte."""
+    _need_node()
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    import struct
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=7000, width=160, height=112, s0=0.01)
+    g, sh, _ = harness.scene(cfg)
+    g16 = g.view(np.float16).reshape(-1, 12).astype(np.float64)
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (cfg.num_points, 3), dtype=np.uint8)
+    pts = struct.pack("<Q", cfg.num_points)
+    for i in range(cfg.num_points):   # id, xyz, rgb, error, track length + track
+        track = [(1, 2)] * (i % 3)
+        pts += struct.pack("<Q3d3BdQ", i + 1, *g16[i, :3], *rgb[i], 0.5, len(track)) + b"".join(struct.pack("<II", *t) for t in track)
+    (tmp_path / "points3D.bin").write_bytes(pts)
+    blocks = synth.circle_cameras(cfg, 3)
+    imgs_bin = struct.pack("<Q", 3)
+    for i, blk in enumerate(blocks):
+        view = blk[0:16].reshape(4, 4).T.astype(np.float64)
+        R, t = view[:3, :3], view[:3, 3]
+        imgs_bin += struct.pack("<I7dI", 10 + i, *_quat_wxyz(R), *t, 1) + f"frame_{i:02d}.jpg".encode() + b"\0" + struct.pack("<Q", i) + b"\0" * (24 * i)
+    (tmp_path / "images.bin").write_bytes(imgs_bin)
+    (tmp_path / "cameras.bin").write_bytes(struct.pack("<Q", 1) + struct.pack("<IiQQ4d", 1, 1, cfg.width, cfg.height, cfg.fy, cfg.fy, cfg.width / 2, cfg.height / 2))
+    cams = loaders.mergeColmap(loaders.loadColmapImagesBin(imgs_bin), loaders.loadColmapCamerasBin((tmp_path / "cameras.bin").read_bytes()))
+    data = loaders.loadPointCloud(pts)
+    assert data.type == "normal" and data.sh_deg == 0
+    # ground truth: the same cloud with brighter colours, rendered by the oracle under the LOADED cameras, stored as JPEG (4:2:0, one progressive)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    st[1] = 0.0
+    tg, tsh = synth.make_target_scene(data.gaussians, data.sh)
+    os.mkdir(tmp_path / "gt")
+    for i, c in enumerate(cams):
+        ref = orc.forward(tg, tsh, loaders.cameraUniforms(c, cfg.width, cfg.height), st, ti)["rgba8"]
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(ref[..., :3]), "RGB").save(buf, format="JPEG", quality=90, subsampling=2, progressive=(i == 1))
+        (tmp_path / "gt" / f"frame_{i:02d}.jpg").write_bytes(buf.getvalue())
+    steps, draws, resized = 6, [1, 0, 2, 2, 1, 0, 0, 1], (96, 64)
+    (tmp_path / "meta.json").write_text(json.dumps(dict(width=cfg.width, height=cfg.height, resized=resized, view_camera=2, steps=steps, draws=draws,
+                                                        cloud_file="points3D.bin", camera_files=["images.bin", "cameras.bin"])))
+    r = subprocess.run([NODE, os.path.join(ROOT, "bindings", "napi", "viewer_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "VIEWER_RUN_OK" in r.stdout, f"exit code {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    out = json.loads((tmp_path / "out.json").read_text())
+    assert (out["type"], out["num_points"], out["sh_deg"], out["cameras"]) == ("normal", cfg.num_points, 0, 3)
+
+    pc = ops.createPointCloud(dev, data.gaussians, data.sh, data.sh_deg)
+    gt = images.loadImages([str(tmp_path / "gt" / f) for f in os.listdir(tmp_path / "gt")], dev)
+    assert out["images"] == [[im.name, im.width, im.height] for im in gt]
+    v = Viewer(dev, cfg.width, cfg.height)
+    t = Trainer(dev, seed=0)
+    try:
+        v.setCamera(cams[2])
+        v.setPointCloud(pc)
+        v.setRenderMode("gaussian")
+        v.render(None)
+        assert_bits_equal(np.fromfile(tmp_path / "out_frame_gaussian.rgba", np.uint8).reshape(cfg.height, cfg.width, 4), v.readFrame(), "COLMAP cloud under a COLMAP camera: node vs Python")
+        t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+        t.setPointCloud(pc)
+        t.setDataset(cams, gt)
+        t.start()
+        t._rng = _FixedViews(draws)
+        for _ in range(steps):
+            t.step()
+        v.render(None)
+        assert_bits_equal(np.fromfile(tmp_path / "out_frame_trained.rgba", np.uint8).reshape(cfg.height, cfg.width, 4), v.readFrame(), "after training on the JPEG ground truth: node vs Python")
+        n = pc.num_points
+        assert_bits_equal(np.fromfile(tmp_path / "out_gaussians.bin", np.uint32), pc.gaussian_3d_buffer.read(np.uint32)[: n * 6], "trained Gaussians: node vs Python")
+        assert_bits_equal(np.fromfile(tmp_path / "out_sh.bin", np.uint32), pc.sh_buffer.read(np.uint32)[: n * 24], "trained SH rows: node vs Python")
+        assert not np.array_equal(pc.gaussian_3d_buffer.read(np.uint32)[: n * 6], data.gaussians.reshape(-1)), "training moved the cloud"
+    finally:
+        t.destroy()
+        v.destroy()
+
+
 def test_keep_gradients_switch_is_obeyed_after_set_point_cloud(hip_device, orc):
     """``keep_gradients`` flipped AFTER ``setPointCloud`` (the passes survive swaps) must not leave getGradientsBuffer() stale."""
     dev = hip_device
