@@ -83,7 +83,32 @@ async function main() {
   let sortOk = true; for (let i = 0; i < count; i++) { if (sk[i] !== keys[sv[i]] || back[i] !== sk[i] || (i && (sk[i - 1] > sk[i] || (sk[i - 1] === sk[i] && sv[i - 1] > sv[i])))) sortOk = false; }
   sorter.destroy(); scanner.destroy(); stats.destroy(); keyBuf.destroy();
 
-  fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
+  // ---- a step whose tile-entry list overflows maxTileEntries is reported (an Error with code WDGS_E_CAPACITY out of step(): the deferred check of
+  // onSubmittedWorkDone / the ticket wait) and changes nothing; the device stays usable.  Same form of the step as the run above.
+  const overflow = { code: null, steps_until_error: 0, untouched: false, usable_after: false };
+  {
+    const fresh = () => ({ type: 'full', num_points: meta.num_points, sh_deg: meta.sh_deg, gaussian_3d_buffer: upload(u8('gaussians.bin')), sh_buffer: upload(u8('sh.bin')) });
+    const make = (maxTileEntries) => {
+      const tr = new Trainer(dev, undefined, { random: () => 0.1, viewsPerStep: meta.views_per_step || 1, lanes: meta.lanes || 0, pipelineDepth: meta.pipeline_depth || 1, maxTileEntries });
+      tr.setDensifyPruneConfig({ schedule: { enabled: false } });
+      tr.setPointCloud(fresh()); tr.setDataset(cameras, images); tr.start();
+      return tr;
+    };
+    const small = make(4096);   // the scene needs several times that
+    const before = Buffer.from(dev.readBuffer(small.pointCloud.gaussian_3d_buffer, meta.num_points * 24));
+    try {
+      for (let i = 0; i < 3; i++) { await small.step(); overflow.steps_until_error++; }
+    } catch (e) { overflow.code = e.code || String(e); }
+    try { dev.synchronize(); } catch (_e) { /* the step that was still in flight overflowed too */ }
+    overflow.untouched = before.equals(Buffer.from(dev.readBuffer(small.pointCloud.gaussian_3d_buffer, meta.num_points * 24)));
+    const sp = small.pointCloud; small.destroy(); sp.gaussian_3d_buffer.destroy(); sp.sh_buffer.destroy();
+    const roomy = make(0);
+    await roomy.step(); await roomy.step(); await roomy.step(); roomy.drain(); dev.synchronize();
+    overflow.usable_after = roomy.getIteration() === 3 && !before.equals(Buffer.from(dev.readBuffer(roomy.pointCloud.gaussian_3d_buffer, meta.num_points * 24)));
+    const rp = roomy.pointCloud; roomy.destroy(); rp.gaussian_3d_buffer.destroy(); rp.sh_buffer.destroy();
+  }
+
+  fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ overflow, num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
     last_densify: t.getLastDensifyPruneIteration(), next_densify: t.getNextDensifyPruneIteration(), iters_per_s: t.getItersPerSec(), scan_ok: scanOk, sort_ok: sortOk,
     recorded_views: t.commandBuffers.size, recorded_keys: Array.from(t.commandBuffers.keys()), lanes: t.lanes, op_sets: t.opSets, stale_rows_seen: staleRowsSeen,
     exchange: exchange.name }));

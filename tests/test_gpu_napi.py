@@ -71,6 +71,9 @@ def test_node_trainer_equals_python_trainer(hip_device, orc, tmp_path, form):
     assert out["scan_ok"] and out["sort_ok"], "get_prefix_scanner / get_dynamic_sorter through the addon"
     assert out["recorded_views"] >= 2, "the JS trainer replays recorded command buffers"
     assert out["stale_rows_seen"], "deferred SH writes: the rows are stale between hand-overs and a host read through the buffer brings them up to date"
+    ov = out["overflow"]   # a step whose tile-entry list does not fit: same report, same guarantees as the Python host (test_gpu_pipeline.py)
+    assert ov["code"] == "WDGS_E_CAPACITY" and ov["untouched"] and ov["usable_after"], ov
+    assert ov["steps_until_error"] == (0 if opts.get("pipeline_depth", 1) == 1 else 1), "depth 1: the step itself throws; depth 2: the next one does"
     if vps == 2:
         assert out["lanes"] == 2 and out["op_sets"] == 2 and any(k.startswith("viewp/") for k in out["recorded_keys"]) and "adam" in out["recorded_keys"]
     if opts.get("comm") == "capi":
