@@ -23,7 +23,9 @@
 // nine fixed-point conversions (18), the per-pixel gradient arithmetic (about 45), the reduction (17) and the tests and bookkeeping
 // around them, at 0.96-0.99 of the rate this chip sustains for a pure FMA stream; DESIGN.md section 4 has the counters.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "dmath.h"
@@ -81,11 +83,25 @@ WD_DEV int cvt_fixed(float scaled) {
 // to back on one XCD and share its L2 lines of the entry list) or 4 (workgroup = tile, round 2's form).
 // LDS_SUMS: the wave sums of eight of the nine contributions go through a transposition in wave-private LDS (below) instead of the
 // register butterfly.
-template <u32 WPW, bool LDS_SUMS>
+// TIMELINE (measurement tool, WDGS_BWR_TIMELINE=<file>; one-wave workgroups only): every wave leaves {start, end} of the 100 MHz wall clock, where it
+// ran (XCC, SE, CU, SIMD from the hardware id registers) and how many splats it iterated over -- scripts/bwr_timeline.py reads the file.
+template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false>
 __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty) {
+                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty,
+                                                                 unsigned long long* __restrict__ timeline) {
+    const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
+    u32 iterations = 0u;
+    auto leave_timeline = [&]() {
+        if (TIMELINE && (threadIdx.x & 63u) == 0u) {
+            u32 hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw_id));    // HW_REG_HW_ID: wave, SIMD, CU, SH, SE
+            asm volatile("s_getreg_b32 %0, hwreg(20, 0, 32)" : "=s"(xcc_id));  // HW_REG_XCC_ID
+            unsigned long long* const rec = timeline + (size_t)blockIdx.x * 4u;
+            rec[0] = t_start; rec[1] = wall_clock64(); rec[2] = ((unsigned long long)xcc_id << 32) | hw_id; rec[3] = iterations;
+        }
+    };
     // the accumulators hold sums from here on (acc_clear_if_dirty below, and the consuming forms of geometry_backward, backward.hip)
     if (blockIdx.x == 0u && threadIdx.x == 0u) *acc_dirty = 1u;
     __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     u32 wmax = pix_n;  // wave maximum (uniform)
 #pragma unroll
     for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
-    if (wmax == 0u) return;
+    if (wmax == 0u) { leave_timeline(); return; }
 
     float T = 0.0f;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             const float alpha = (og < 0.99f) ? og : 0.99f;  // WGSL min(0.99, opacity*G)
             const bool act = cand && !(alpha < (1.0f / 255.0f));
             if (!__any(act)) continue;
+            if (TIMELINE) iterations++;
             // No branch around the per-pixel arithmetic: a pixel that does not contribute runs it with alpha = 0 and dL/dalpha = 0,
             // which leaves its state exactly as it was (T / 1 = T, accum_rec = 0 * colour + 1 * accum_rec) and makes every one of its
             // nine fixed-point contributions 0 (products with a zero factor; an inf * 0 = NaN converts to 0 as well) -- two selects
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         __builtin_amdgcn_wave_barrier();  // all lanes are done reading the records before the next chunk overwrites them
         hi = lo;
     }
+    leave_timeline();
 }
 
 // clearBuffer x4 (tiled-backward-pass.ts:624-627) as a kernel that first looks at the accumulators' state word: the Trainer's forms of
@@ -355,9 +373,27 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
     static const u32 pad_lds = std::getenv("WDGS_BWR_PAD_LDS") ? (u32)std::atoi(std::getenv("WDGS_BWR_PAD_LDS")) : 0u;
 #define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
     WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), pad_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
-                (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty)
+                (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, \
+                (unsigned long long*)nullptr)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
+        // WDGS_BWR_TIMELINE=<file> (measurement tool; eager launches only): per-wave records of this launch are appended to the file
+        static const char* const timeline_file = std::getenv("WDGS_BWR_TIMELINE");
+        if (timeline_file && lds_sums && !dev->capturing) {
+            unsigned long long* tl = nullptr;
+            const size_t bytes = (size_t)slots * 4u * sizeof(unsigned long long);
+            WDGS_CHECK_HIP(hipMalloc((void**)&tl, bytes));
+            WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
+            hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
+                               (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl);
+            std::vector<unsigned long long> host((size_t)slots * 4u);
+            WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
+            WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
+            (void)hipFree(tl);
+            if (FILE* f = std::fopen(timeline_file, "ab")) { const u32 head[2] = {slots, tiles}; std::fwrite(head, 4, 2, f); std::fwrite(host.data(), 8, host.size(), f); std::fclose(f); }
+            WDGS_CHECK_HIP(hipGetLastError());
+            return WDGS_OK;
+        }
         if (lds_sums) { WDGS_BWR_LAUNCH(1u, true, slots, 64); } else { WDGS_BWR_LAUNCH(1u, false, slots, 64); }
     } else {
         if (lds_sums) { WDGS_BWR_LAUNCH(4u, true, tiles, 256); } else { WDGS_BWR_LAUNCH(4u, false, tiles, 256); }
