@@ -32,7 +32,8 @@ def main():
     t0 = rec[ran, 0].astype(np.int64)
     t1 = rec[ran, 1].astype(np.int64)
     ids = rec[ran, 2]
-    it = rec[ran, 3].astype(np.int64)
+    it = (rec[ran, 3] & np.uint64(0xFFFF)).astype(np.int64)
+    ff = (rec[ran, 3] >> np.uint64(16)).astype(np.int64)  # SPLIT form: iterations of the state recurrence alone, over the chunks behind the wave's segment
     base = t0.min()
     t0 -= base
     t1 -= base
@@ -48,6 +49,8 @@ def main():
     print(f"slots={slots} tiles={tiles} waves that recorded={ran.sum()} (the others had no work: empty tile or surplus slot)")
     print(f"span first start -> last end: {span * tick_us:.2f} us;  last wave start at {t0.max() * tick_us:.2f} us;  iterated splats total={it.sum()}")
     dur = t1 - t0
+    if ff.any():
+        print(f"state-only iterations total={ff.sum()} (per wave that has any: mean={ff[ff > 0].mean():.1f} max={ff.max()})")
     print(f"wave life us: mean={dur.mean() * tick_us:.2f} p50={np.percentile(dur, 50) * tick_us:.2f} p90={np.percentile(dur, 90) * tick_us:.2f} "
           f"p99={np.percentile(dur, 99) * tick_us:.2f} max={dur.max() * tick_us:.2f}")
     work = it > 0
