@@ -85,12 +85,17 @@ WD_DEV int cvt_fixed(float scaled) {
 // register butterfly.
 // TIMELINE (measurement tool, WDGS_BWR_TIMELINE=<file>; one-wave workgroups only): every wave leaves {start, end} of the 100 MHz wall clock, where it
 // ran (XCC, SE, CU, SIMD from the hardware id registers) and how many splats it iterated over -- scripts/bwr_timeline.py reads the file.
-template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false>
+// PRIO: a launch whose waves are all resident from the start (c2: 4 800 waves, 8 192 slots) takes as long as its LONGEST wave -- the waves of a
+// SIMD start together and leave one by one, profiles/r05r_bwr_timeline_c2.txt -- and a wave iterates faster the fewer waves compete for its
+// SIMD's issue slots (446 ns per iteration alone, 617 ns among four: profiles/r05v_bwr_wave_rate.txt).  The wave therefore sets its issue
+// priority from the entries it still has to walk, once per chunk: longest remaining chain first.  c2 187.0 -> 176.9 us per step, c3 unchanged
+// (profiles/r05x_bwr_issue_priority_sweep.txt; thresholds swept there).  Arbitration only: results cannot depend on it.
+template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false, bool PRIO = true>
 __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty,
-                                                                 unsigned long long* __restrict__ timeline) {
+                                                                 unsigned long long* __restrict__ timeline, const u32* __restrict__ tile_order) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
     auto leave_timeline = [&]() {
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         // k, k + 8, k + 16, ... (any tile count: the grid is rounded up and surplus slots leave)
         const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
         tile_id = k + 8u * (j >> 2);
+        if (TIMELINE && tile_order) tile_id = tile_order[tile_id];  // experiment (WDGS_BWR_ORDER): the launcher's order instead of the raster order
         sub = j & 3u;
         if (tile_id >= num_tiles) return;
     }
@@ -183,6 +189,15 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     }
     for (u32 hi = wmax; hi > 0u;) {
         const u32 lo = chunk_lo(hi);
+        if (PRIO) {
+            // (hi is the same in every lane, which the compiler cannot see: as a scalar, or the four s_setprio end up in exec-masked regions
+            // that are not branched around and the last one always wins)
+            const u32 left = (u32)__builtin_amdgcn_readfirstlane((int)hi);
+            if (left >= 128u) __builtin_amdgcn_s_setprio(3);
+            else if (left >= 64u) __builtin_amdgcn_s_setprio(2);
+            else if (left >= 32u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // ---- this lane's entry: overlap test against the wave's block, order-preserving compaction into LDS
         const bool have = gidx_c != 0xFFFFFFFFu;
         const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
@@ -381,9 +396,12 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
 #define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
     WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), pad_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
                 (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, \
-                (unsigned long long*)nullptr)
+                (unsigned long long*)nullptr, (const u32*)nullptr)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
+        // WDGS_BWR_PRIO=0: the form without issue priorities (same-box A/B)
+        static const bool no_prio = std::getenv("WDGS_BWR_PRIO") && std::getenv("WDGS_BWR_PRIO")[0] == '0';
+        const bool prio = !no_prio && slots <= 8192u;  // (a launch that does not fit the chip's 8 192 wave slots gains nothing: c3 +-0)
         // WDGS_BWR_TIMELINE=<file> (measurement tool; eager launches only): per-wave records of this launch are appended to the file
         static const char* const timeline_file = std::getenv("WDGS_BWR_TIMELINE");
         if (timeline_file && lds_sums && !dev->capturing) {
@@ -391,17 +409,45 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
             const size_t bytes = (size_t)slots * 4u * sizeof(unsigned long long);
             WDGS_CHECK_HIP(hipMalloc((void**)&tl, bytes));
             WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
-            hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
-                               (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl);
+            // WDGS_BWR_ORDER=1 (experiment): tiles in descending order of the entries their waves walk (deepest n_contrib, capped by the list length)
+            u32* order_dev = nullptr;
+            if (std::getenv("WDGS_BWR_ORDER")) {
+                const u32 W = (u32)st.viewport_x, H = (u32)st.viewport_y, padded = slots / 4u;
+                std::vector<u32> h_ranges(tiles + 1u), h_n((size_t)W * H), work(tiles, 0u), order(padded);
+                WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
+                WDGS_CHECK_HIP(hipMemcpy(h_ranges.data(), ranges, sizeof(u32) * (tiles + 1u), hipMemcpyDeviceToHost));
+                WDGS_CHECK_HIP(hipMemcpy(h_n.data(), n_contrib, sizeof(u32) * h_n.size(), hipMemcpyDeviceToHost));
+                for (u32 y = 0; y < H; y++)
+                    for (u32 x = 0; x < W; x++) {
+                        const u32 t = (y / 16u) * num_tiles_x + x / 16u;
+                        const u32 len = (h_ranges[t + 1u] > h_ranges[t]) ? h_ranges[t + 1u] - h_ranges[t] : 0u;
+                        work[t] = std::max(work[t], std::min(h_n[(size_t)y * W + x], len));
+                    }
+                for (u32 t = 0; t < padded; t++) order[t] = t;
+                std::stable_sort(order.begin(), order.begin() + tiles, [&](u32 a, u32 b) { return work[a] > work[b]; });
+                WDGS_CHECK_HIP(hipMalloc((void**)&order_dev, sizeof(u32) * padded));
+                WDGS_CHECK_HIP(hipMemcpy(order_dev, order.data(), sizeof(u32) * padded, hipMemcpyHostToDevice));
+            }
+            if (prio)
+                hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, true>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
+                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl, order_dev);
+            else
+                hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, false>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
+                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl, order_dev);
             std::vector<unsigned long long> host((size_t)slots * 4u);
             WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
             WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
             (void)hipFree(tl);
+            if (order_dev) (void)hipFree(order_dev);
             if (FILE* f = std::fopen(timeline_file, "ab")) { const u32 head[2] = {slots, tiles}; std::fwrite(head, 4, 2, f); std::fwrite(host.data(), 8, host.size(), f); std::fclose(f); }
             WDGS_CHECK_HIP(hipGetLastError());
             return WDGS_OK;
         }
-        if (lds_sums) { WDGS_BWR_LAUNCH(1u, true, slots, 64); } else { WDGS_BWR_LAUNCH(1u, false, slots, 64); }
+        if (lds_sums && !prio) {
+            WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false>), dim3(slots), dim3(64), pad_lds, st, num_tiles_x, tiles,
+                        (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc,
+                        (u32*)acc_dirty, (unsigned long long*)nullptr, (const u32*)nullptr);
+        } else if (lds_sums) { WDGS_BWR_LAUNCH(1u, true, slots, 64); } else { WDGS_BWR_LAUNCH(1u, false, slots, 64); }
     } else {
         if (lds_sums) { WDGS_BWR_LAUNCH(4u, true, tiles, 256); } else { WDGS_BWR_LAUNCH(4u, false, tiles, 256); }
     }

@@ -31,7 +31,7 @@ template <bool GAUSSIAN_MODE, u32 WPW>
 __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
                                                         const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                                                         const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
-                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib) {
+                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority) {
     // (one record more than a chunk holds: the loop below reads one record ahead)
     __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
     __shared__ float4 s_con_all[WPW][65];  // -0.5*conic.x, -conic.y, -0.5*conic.z, opacity (Gaussian mode: see the record build below)
@@ -87,10 +87,22 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
             const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)val_c * 6);
             w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
         }
+        // issue priority from the entries the wave may still have to walk: longest remaining list first (backward_raster.hip, PRIO).  The
+        // next tile's start bounds this tile's list (the end of all entries if that tile is empty); arbitration only, results cannot depend on it.
+        const u32 next_start = ranges[tile_id + 1u];
+        const u32 list_len = ((next_start > start && next_start < total) ? next_start : total) - start;
         for (u32 chunk = 0;; chunk++) {
             // entries of a tile are contiguous, so the valid lanes are a prefix of the chunk
             const unsigned long long vmask = __ballot(valid);
             if (vmask == 0ull) break;
+            if (issue_priority) {
+                // (as a scalar: exec-masked s_setprio would all execute, backward_raster.hip)
+                const u32 done = chunk * 64u, left = (u32)__builtin_amdgcn_readfirstlane((int)((list_len > done) ? list_len - done : 0u));
+                if (left >= 128u) __builtin_amdgcn_s_setprio(3);
+                else if (left >= 64u) __builtin_amdgcn_s_setprio(2);
+                else if (left >= 32u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             // ---- this lane's entry: overlap test against the wave's block (conservative and exact per axis: a splat is dropped
             //      only if the nearest block pixel already fails the per-pixel test |p - c| > extent, which is monotone in p)
             const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
@@ -203,8 +215,11 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
     // (one-wave workgroups help backward_rasterize -- 303 -> 295.5 us -- but not this kernel: 119.2 vs 119.8 us, r03m; workgroup = tile stays)
     static const bool one_wave = std::getenv("WDGS_RASTER_WPW") && std::getenv("WDGS_RASTER_WPW")[0] == '1';
     const u32 slots = ceil_div(ti.total_tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
+    // WDGS_FWR_PRIO=0: no issue priorities (same-box A/B)
+    static const u32 issue_priority = (std::getenv("WDGS_FWR_PRIO") && std::getenv("WDGS_FWR_PRIO")[0] == '0') ? 0u : 1u;
+    const u32 issue_priority_now = (issue_priority && (!one_wave || slots <= 8192u)) ? 1u : 0u;  // launches whose waves are all resident from the start
 #define RASTER_ARGS st, ti, (const u32*)splats, num_splats, (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, \
-                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib
+                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now
     if (st.gaussian_mode >= 0.5f) {
         if (one_wave) WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);
         else WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 4u>), dim3(ti.total_tiles), dim3(256), 0, RASTER_ARGS);
