@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty,
-                                                                 unsigned long long* __restrict__ timeline, const u32* __restrict__ tile_order) {
+                                                                 unsigned long long* __restrict__ timeline) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
     auto leave_timeline = [&]() {
@@ -124,7 +124,6 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         // k, k + 8, k + 16, ... (any tile count: the grid is rounded up and surplus slots leave)
         const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
         tile_id = k + 8u * (j >> 2);
-        if (TIMELINE && tile_order) tile_id = tile_order[tile_id];  // experiment (WDGS_BWR_ORDER): the launcher's order instead of the raster order
         sub = j & 3u;
         if (tile_id >= num_tiles) return;
     }
@@ -396,7 +395,7 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
 #define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
     WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), pad_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
                 (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, \
-                (unsigned long long*)nullptr, (const u32*)nullptr)
+                (unsigned long long*)nullptr)
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
         // WDGS_BWR_PRIO=0: the form without issue priorities (same-box A/B)
@@ -409,36 +408,16 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
             const size_t bytes = (size_t)slots * 4u * sizeof(unsigned long long);
             WDGS_CHECK_HIP(hipMalloc((void**)&tl, bytes));
             WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
-            // WDGS_BWR_ORDER=1 (experiment): tiles in descending order of the entries their waves walk (deepest n_contrib, capped by the list length)
-            u32* order_dev = nullptr;
-            if (std::getenv("WDGS_BWR_ORDER")) {
-                const u32 W = (u32)st.viewport_x, H = (u32)st.viewport_y, padded = slots / 4u;
-                std::vector<u32> h_ranges(tiles + 1u), h_n((size_t)W * H), work(tiles, 0u), order(padded);
-                WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
-                WDGS_CHECK_HIP(hipMemcpy(h_ranges.data(), ranges, sizeof(u32) * (tiles + 1u), hipMemcpyDeviceToHost));
-                WDGS_CHECK_HIP(hipMemcpy(h_n.data(), n_contrib, sizeof(u32) * h_n.size(), hipMemcpyDeviceToHost));
-                for (u32 y = 0; y < H; y++)
-                    for (u32 x = 0; x < W; x++) {
-                        const u32 t = (y / 16u) * num_tiles_x + x / 16u;
-                        const u32 len = (h_ranges[t + 1u] > h_ranges[t]) ? h_ranges[t + 1u] - h_ranges[t] : 0u;
-                        work[t] = std::max(work[t], std::min(h_n[(size_t)y * W + x], len));
-                    }
-                for (u32 t = 0; t < padded; t++) order[t] = t;
-                std::stable_sort(order.begin(), order.begin() + tiles, [&](u32 a, u32 b) { return work[a] > work[b]; });
-                WDGS_CHECK_HIP(hipMalloc((void**)&order_dev, sizeof(u32) * padded));
-                WDGS_CHECK_HIP(hipMemcpy(order_dev, order.data(), sizeof(u32) * padded, hipMemcpyHostToDevice));
-            }
             if (prio)
                 hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, true>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
-                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl, order_dev);
+                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl);
             else
                 hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, false>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
-                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl, order_dev);
+                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl);
             std::vector<unsigned long long> host((size_t)slots * 4u);
             WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
             WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
             (void)hipFree(tl);
-            if (order_dev) (void)hipFree(order_dev);
             if (FILE* f = std::fopen(timeline_file, "ab")) { const u32 head[2] = {slots, tiles}; std::fwrite(head, 4, 2, f); std::fwrite(host.data(), 8, host.size(), f); std::fclose(f); }
             WDGS_CHECK_HIP(hipGetLastError());
             return WDGS_OK;
@@ -446,7 +425,7 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
         if (lds_sums && !prio) {
             WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false>), dim3(slots), dim3(64), pad_lds, st, num_tiles_x, tiles,
                         (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc,
-                        (u32*)acc_dirty, (unsigned long long*)nullptr, (const u32*)nullptr);
+                        (u32*)acc_dirty, (unsigned long long*)nullptr);
         } else if (lds_sums) { WDGS_BWR_LAUNCH(1u, true, slots, 64); } else { WDGS_BWR_LAUNCH(1u, false, slots, 64); }
     } else {
         if (lds_sums) { WDGS_BWR_LAUNCH(4u, true, tiles, 256); } else { WDGS_BWR_LAUNCH(4u, false, tiles, 256); }
