@@ -307,6 +307,30 @@ def test_c5_from_a_loaded_ply_with_the_50k_densify_equals_the_oracle_trainer(hip
         t.destroy()
 
 
+def test_c5_ply_goes_through_the_typescript_side_loaders_like_the_python_ones(tmp_path):
+    """c5's cloud arrives as a .ply: the 1.2 GB file of 5 M Gaussians (SH degree 3) parsed by ``bindings/ts/loaders.js`` (node, no GPU) gives the
+    packed Gaussians / SH the Python host's ``loadPly`` gives, and its ``exportPly`` writes the same file back -- compared by sha256."""
+    import json
+    import shutil
+    from webdgs_amd import loaders
+    if shutil.which("node") is None:
+        pytest.skip("node is not on this box")
+    cfg = synth.CONFIGS["c5"]
+    g0, sh0 = synth.make_gaussians(cfg)
+    data = loaders.exportPly(g0, sh0, cfg.sh_deg)
+    path = tmp_path / "c5.ply"
+    path.write_bytes(data)
+    assert path.stat().st_size > 1_000_000_000
+    want = dict(type="full", num_points=cfg.num_points, sh_deg=cfg.sh_deg, gaussians=hashlib.sha256(g0.tobytes()).hexdigest(), sh=hashlib.sha256(sh0.tobytes()).hexdigest(),
+                exported=hashlib.sha256(data).hexdigest(), exported_bytes=len(data))
+    del data
+    r = subprocess.run(["node", "--max-old-space-size=8192", os.path.join(ROOT, "bindings", "napi", "ply_roundtrip_run.js"), str(path)], capture_output=True, text=True, timeout=900)
+    path.unlink()
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert {k: got[k] for k in want} == want, (got, want)
+
+
 def test_c2_long_run_is_the_same_whichever_way_it_is_driven(hip_device):
     """BASELINE c2 (100 k Gaussians, 640x480) for 1 250 iterations at the reference's densify schedule -- eight densify events,
     the cloud shrinking from 100 k -- driven two ways: as the reference drives it (every step awaited, passes destroyed and rebuilt
