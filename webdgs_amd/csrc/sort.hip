@@ -507,7 +507,11 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
         __syncthreads();
         lo16 = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
         hi16 = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        if (hi16 - lo16 < SEG_BINS) {   // uniform per workgroup
+        if (hi16 - lo16 < (1u << 8)) {   // (every branch is uniform per workgroup; a narrower digit = fewer bins to clear and scan, fewer ballots per round)
+            seg_pass_regs<8>(kk, vv, a_k, a_v, n, per_wave, lo16, 0u, whist, s_wsum);
+        } else if (hi16 - lo16 < (1u << 9)) {
+            seg_pass_regs<9>(kk, vv, a_k, a_v, n, per_wave, lo16, 0u, whist, s_wsum);
+        } else if (hi16 - lo16 < SEG_BINS) {
             seg_pass_regs<SEG_WIDE_BITS>(kk, vv, a_k, a_v, n, per_wave, lo16, 0u, whist, s_wsum);
         } else {
             seg_pass_regs<8>(kk, vv, a_k, a_v, n, per_wave, 0u, 0u, whist, s_wsum);   // low depth byte
