@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of backward_rasterize (dev tool).
+"""Per-wave timeline of backward_rasterize -- and of rasterize, whose TIMELINE form writes the same records (WDGS_FWR_TIMELINE) -- (dev tool).
 
     WDGS_BWR_TIMELINE=/tmp/tl.bin WDGS_PROFILE_FROZEN=1 python scripts/profile_step.py c2 4     # eager steps; every launch appends its records
     python scripts/bwr_timeline.py /tmp/tl.bin                                                  # reads the LAST launch in the file

@@ -19,7 +19,9 @@
 // sustains for a pure FMA stream -- not HBM.
 // Arithmetic is the pinned contraction of DESIGN.md "raster math", bit-identical to the parity oracle.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "dmath.h"
 
@@ -27,11 +29,16 @@ namespace {
 
 // WPW = waves per workgroup: 1 (one 8x8 block per workgroup, a tile's four blocks dispatched back to back on one XCD) or 4 (workgroup = tile);
 // see backward_raster.hip.
-template <bool GAUSSIAN_MODE, u32 WPW>
+// TIMELINE (measurement tool, WDGS_FWR_TIMELINE=<file>, eager launches): every wave leaves {start, end} of the 100 MHz wall clock, where it ran and how
+// many records it composited -- the format of backward_raster.hip's, read by scripts/bwr_timeline.py.
+template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE = false>
 __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
                                                         const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                                                         const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
-                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority) {
+                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
+                                                        unsigned long long* __restrict__ timeline) {
+    const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
+    u32 iterations = 0u;
     // (one record more than a chunk holds: the loop below reads one record ahead)
     __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
     __shared__ float4 s_con_all[WPW][65];  // -0.5*conic.x, -conic.y, -0.5*conic.z, opacity (Gaussian mode: see the record build below)
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
             const bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
             const unsigned long long m = __ballot(ok);
             const u32 cnt = (u32)__popcll(m);
+            if (TIMELINE) iterations += cnt;
             if (ok) {
                 const u32 slot = (u32)__popcll(m & lt_mask);
                 s_geo[slot] = make_float4(cx, cy, ex, ey);
@@ -203,6 +211,13 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
         out_alpha[p] = 1.0f - A;
         out_ncontrib[p] = last_contributor;
     }
+    if (TIMELINE && lane == 0u) {
+        u32 hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw_id));    // HW_REG_HW_ID
+        asm volatile("s_getreg_b32 %0, hwreg(20, 0, 32)" : "=s"(xcc_id));  // HW_REG_XCC_ID
+        unsigned long long* const rec = timeline + ((size_t)blockIdx.x * WPW + (threadIdx.x >> 6)) * 4u;
+        rec[0] = t_start; rec[1] = wall_clock64(); rec[2] = ((unsigned long long)xcc_id << 32) | hw_id; rec[3] = iterations;
+    }
 }
 
 }  // namespace
@@ -217,9 +232,27 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
     const u32 slots = ceil_div(ti.total_tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
     // WDGS_FWR_PRIO=0: no issue priorities (same-box A/B)
     static const u32 issue_priority = (std::getenv("WDGS_FWR_PRIO") && std::getenv("WDGS_FWR_PRIO")[0] == '0') ? 0u : 1u;
-    const u32 issue_priority_now = (issue_priority && (!one_wave || slots <= 8192u)) ? 1u : 0u;  // launches whose waves are all resident from the start
+    const u32 issue_priority_now = (issue_priority && slots <= 8192u) ? 1u : 0u;  // launches whose waves (4 per tile in either workgroup shape) are all resident from the start
 #define RASTER_ARGS st, ti, (const u32*)splats, num_splats, (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, \
-                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now
+                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now, (unsigned long long*)nullptr
+    // WDGS_FWR_TIMELINE=<file> (measurement tool; eager launches of the Gaussian mode in its default workgroup shape): per-wave records appended to the file
+    static const char* const timeline_file = std::getenv("WDGS_FWR_TIMELINE");
+    if (timeline_file && st.gaussian_mode >= 0.5f && !one_wave && !dev->capturing) {
+        unsigned long long* tl = nullptr;
+        const size_t bytes = (size_t)ti.total_tiles * 4u * 4u * sizeof(unsigned long long);
+        WDGS_CHECK_HIP(hipMalloc((void**)&tl, bytes));
+        WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
+        hipLaunchKernelGGL((rasterize_kernel<true, 4u, true>), dim3(ti.total_tiles), dim3(256), 0, dev->stream, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
+                           (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib,
+                           issue_priority_now, tl);
+        std::vector<unsigned long long> host((size_t)ti.total_tiles * 16u);
+        WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
+        WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
+        (void)hipFree(tl);
+        if (FILE* f = std::fopen(timeline_file, "ab")) { const u32 head[2] = {ti.total_tiles * 4u, ti.total_tiles}; std::fwrite(head, 4, 2, f); std::fwrite(host.data(), 8, host.size(), f); std::fclose(f); }
+        WDGS_CHECK_HIP(hipGetLastError());
+        return WDGS_OK;
+    }
     if (st.gaussian_mode >= 0.5f) {
         if (one_wave) WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);
         else WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 4u>), dim3(ti.total_tiles), dim3(256), 0, RASTER_ARGS);
