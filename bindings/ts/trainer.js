@@ -138,10 +138,13 @@ class Trainer {
    *  image size as Camera.set_preset + update_buffer do, trainer.ts:583-586) and LoadedImage (images.js: { bitmap, width, height }). */
   setDataset(cameras, images) {
     this.drain();
+    for (const t of this.ownedTextures || []) t.destroy();   // (the ones a previous call uploaded itself; a caller's textures stay the caller's)
+    this.ownedTextures = [];
     const imgs = images.map((im) => {
       if (im.texture) return im;
       const tex = this.device.createBuffer({ size: 4 * im.width * im.height, label: 'gt image' });
       this.device.queue.writeBuffer(tex, 0, im.bitmap);
+      this.ownedTextures.push(tex);
       return Object.assign({}, im, { texture: tex });
     });
     const cams = cameras.map((c, i) => (c.camera ? c : Object.assign({}, c, { camera: require('./loaders.js').cameraUniforms(c, imgs[i].width, imgs[i].height) })));
@@ -576,6 +579,8 @@ class Trainer {
     this.destroyMoreMetricSets();
     for (const b of this.cameraBuffers) b.destroy();
     this.cameraBuffers = [];
+    for (const t of this.ownedTextures || []) t.destroy();
+    this.ownedTextures = [];
     for (const name of ['dpGrad', 'dpVisible', 'dpRows', 'dpFlag', 'metricsTarget']) { if (this[name]) this[name].destroy(); this[name] = null; }
     this.metricsCameraBuffer.destroy();
     this.isTraining = false;
