@@ -53,12 +53,31 @@ async function main() {
     const viaHook = new Uint32Array(dev.readBuffer(t.pointCloud.sh_buffer, n * 96));
     for (let i = 0; i < raw.length && !staleRowsSeen; i++) if (raw[i] !== viaHook[i]) staleRowsSeen = true;
   }
-  fs.writeFileSync(path.join(dir, 'out_gaussians.bin'), Buffer.from(dev.readBuffer(t.pointCloud.gaussian_3d_buffer, n * 24)));
-  fs.writeFileSync(path.join(dir, 'out_sh.bin'), Buffer.from(dev.readBuffer(t.pointCloud.sh_buffer, n * 96)));
+  // results: raw files, or (meta.hash_only: full-size runs) their sha256 in out_meta.json
+  const hashes = {};
+  const emit = (name, buffer, bytes) => {
+    const data = Buffer.from(dev.readBuffer(buffer, bytes));
+    if (meta.hash_only) hashes[name] = require('crypto').createHash('sha256').update(data).digest('hex');
+    else fs.writeFileSync(path.join(dir, `out_${name}.bin`), data);
+  };
+  emit('gaussians', t.pointCloud.gaussian_3d_buffer, n * 24);
+  emit('sh', t.pointCloud.sh_buffer, n * 96);
   const st = t.optimizer.getStateBuffers();
   const rowBytes = { optPosBuffer: 48, optRotBuffer: 48, optScaleBuffer: 48, optOpacityBuffer: 12, paramSH: 192, stateSH: 384 };
-  for (const k of Object.keys(rowBytes)) fs.writeFileSync(path.join(dir, `out_state_${k}.bin`), Buffer.from(dev.readBuffer(st[k], n * rowBytes[k])));
-  if (meta.keep_gradients) fs.writeFileSync(path.join(dir, 'out_gradients.bin'), Buffer.from(dev.readBuffer(t.backwardPass.getGradientsBuffer(), n * 32)));
+  for (const k of Object.keys(rowBytes)) emit(`state_${k}`, st[k], n * rowBytes[k]);
+  if (meta.keep_gradients) emit('gradients', t.backwardPass.getGradientsBuffer(), n * 32);
+  if (meta.skip_probes) {   // (full-size runs: the scanner / sorter / overflow probes below belong to the small cases)
+    fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ hashes, num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
+      last_densify: t.getLastDensifyPruneIteration(), next_densify: t.getNextDensifyPruneIteration(), iters_per_s: t.getItersPerSec(), recorded_views: t.commandBuffers.size,
+      stale_rows_seen: staleRowsSeen, exchange: exchange.name }));
+    const lastCloud = t.pointCloud;
+    t.destroy(); exchange.destroy();
+    lastCloud.gaussian_3d_buffer.destroy(); lastCloud.sh_buffer.destroy();
+    for (const im of images) im.texture.destroy();
+    dev.destroy();
+    console.log('TRAINER_RUN_OK');
+    return;
+  }
 
   // ---- get_prefix_scanner / get_dynamic_sorter (prefix.ts:140, sort_dynamic.ts:252) and the pinned asynchronous read-back
   const count = 5000;
@@ -108,7 +127,7 @@ async function main() {
     const rp = roomy.pointCloud; roomy.destroy(); rp.gaussian_3d_buffer.destroy(); rp.sh_buffer.destroy();
   }
 
-  fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ overflow, num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
+  fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ overflow, hashes, num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
     last_densify: t.getLastDensifyPruneIteration(), next_densify: t.getNextDensifyPruneIteration(), iters_per_s: t.getItersPerSec(), scan_ok: scanOk, sort_ok: sortOk,
     recorded_views: t.commandBuffers.size, recorded_keys: Array.from(t.commandBuffers.keys()), lanes: t.lanes, op_sets: t.opSets, stale_rows_seen: staleRowsSeen,
     exchange: exchange.name }));
