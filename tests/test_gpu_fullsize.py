@@ -331,21 +331,25 @@ def test_c5_ply_goes_through_the_typescript_side_loaders_like_the_python_ones(tm
     assert {k: got[k] for k in want} == want, (got, want)
 
 
-def test_c3_as_written_through_the_typescript_side_host_equals_the_python_host(hip_device, tmp_path):
+@pytest.mark.parametrize("form", ["c3_as_written", "c4_rank_step"])
+def test_c3_as_written_through_the_typescript_side_host_equals_the_python_host(hip_device, tmp_path, form):
     """BASELINE config c3 as written -- 1 M Gaussians, 1920x1080, SH degree 3, the full train loop with the reference's default densify/prune
     schedule (warm-up 500, interval 100: two rebuilds in 620 iterations, ten half-resolution metric views each) -- driven by
     ``bindings/ts/trainer.js`` under node and by ``webdgs_amd.trainer`` on the same view draws: final cloud and all six optimizer-state arrays
-    sha256-equal, the same point counts after every step."""
+    sha256-equal, the same point counts after every step.  Second form: the per-rank step of BASELINE c4 at the same size -- 8 views per step on 3
+    lanes, view-batched K1 / K17, the sliced exchange through the library's RCCL communicator in a world of one -- for 12 steps."""
     import json
     import shutil
+    from webdgs_amd import parallel
     from webdgs_amd.trainer import Trainer
     from test_gpu_trainer_oracle import _FixedViews
+    batched = form == "c4_rank_step"
     node = shutil.which("node")
     if not node or not os.path.exists(os.path.join(ROOT, "bindings", "napi", "webdgs_napi.node")):
         pytest.skip("node or the N-API addon is not available")
     dev = hip_device
     cfg = synth.CONFIGS["c3"]
-    views, steps = 8, 620
+    views, steps = 8, (12 if batched else 620)
     g, sh = synth.make_gaussians(cfg)
     tg, tsh = synth.make_target_scene(g, sh)
     cams = synth.circle_cameras(cfg, views)
@@ -359,22 +363,24 @@ def test_c3_as_written_through_the_typescript_side_host_equals_the_python_host(h
     rng = np.random.default_rng(7)
     draws = []
     for i in range(steps):
-        draws.append(int(rng.integers(views)))
+        draws += [int(v) for v in rng.integers(views, size=8 if batched else 1)]
         if i + 1 in (500, 600):
             draws += [int(v) for v in rng.integers(views, size=10)]
+    opts = dict(views_per_step=8, lanes=3, comm="capi", pipeline_depth=2) if batched else dict(pipeline_depth=2)
     g.tofile(tmp_path / "gaussians.bin")
     sh.tofile(tmp_path / "sh.bin")
     np.ascontiguousarray(cams, np.float32).tofile(tmp_path / "cameras.bin")
     np.stack(imgs).tofile(tmp_path / "images.bin")
     (tmp_path / "meta.json").write_text(json.dumps(dict(num_points=cfg.num_points, sh_deg=cfg.sh_deg, width=cfg.width, height=cfg.height, views=views, steps=steps,
-                                                        draws=draws, densify={}, pipeline_depth=2, hash_only=True, skip_probes=True)))
+                                                        draws=draws, densify={}, hash_only=True, skip_probes=True, **opts)))
     r = subprocess.run([node, os.path.join(ROOT, "bindings", "napi", "trainer_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "TRAINER_RUN_OK" in r.stdout, f"exit code {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
     out = json.loads((tmp_path / "out_meta.json").read_text())
     for f in ("gaussians.bin", "sh.bin", "images.bin"):
         (tmp_path / f).unlink()
 
-    t = Trainer(dev, seed=0, pipeline_depth=2)
+    exchange = parallel.CapiExchange(dev) if batched else None
+    t = Trainer(dev, seed=0, pipeline_depth=2, views_per_rank=8 if batched else 1, overlap_views=3 if batched else None, exchange=exchange)
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset([dict(camera=cams[i], width=cfg.width, height=cfg.height) for i in range(views)],
                  [dict(texture=dev.bufferFrom(imgs[i]), width=cfg.width, height=cfg.height) for i in range(views)])
@@ -387,8 +393,10 @@ def test_c3_as_written_through_the_typescript_side_host_equals_the_python_host(h
             sizes.append(t.getPointCount())
         dev.synchronize()
         n = t.getPointCount()
-        assert out["sizes"] == sizes and out["num_points"] == n and len(set(sizes)) == 3, (sorted(set(out["sizes"])), sorted(set(sizes)))
-        assert out["iteration"] == t.getIteration() == steps and out["last_densify"] == t.getLastDensifyPruneIteration() == 600
+        assert out["sizes"] == sizes and out["num_points"] == n and len(set(sizes)) == (1 if batched else 3), (sorted(set(out["sizes"])), sorted(set(sizes)))
+        assert out["iteration"] == t.getIteration() == steps and out["last_densify"] == t.getLastDensifyPruneIteration() == (None if batched else 600)
+        if batched:
+            assert "RCCL" in out["exchange"], "the sliced step ran through the library's communicator"
         sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
         assert out["hashes"]["gaussians"] == sha(t.pointCloud.gaussian_3d_buffer.read(np.uint32)[: n * 6]), "node vs python: gaussians"
         assert out["hashes"]["sh"] == sha(t.pointCloud.sh_buffer.read(np.uint32)[: n * 24]), "node vs python: sh"
@@ -397,6 +405,8 @@ def test_c3_as_written_through_the_typescript_side_host_equals_the_python_host(h
             assert out["hashes"][f"state_{k}"] == sha(b.read(np.uint32)[: n * words[k]]), f"node vs python: state {k}"
     finally:
         t.destroy()
+        if exchange is not None:
+            exchange.destroy()
 
 
 def test_c2_long_run_is_the_same_whichever_way_it_is_driven(hip_device):
