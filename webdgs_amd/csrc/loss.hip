@@ -7,6 +7,7 @@
 // compulsory 8 B read + 16 B write per pixel; window taps are a conflict-free ds_read_b128 + ds_read_b64, shared by four pixels per thread.
 // The window sums keep the reference's order (dy outer, dx inner); the second-moment accumulations are FMAs, the contraction the
 // parity oracle pins (WGSL leaves it open).
+#include <cstdlib>
 #include "common.h"
 #include "dmath.h"
 
@@ -16,10 +17,15 @@ typedef wd_pair f2;  // component-wise scalar arithmetic (dmath.h)
 
 WD_DEV float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
-constexpr u32 LT = 32;       // tile edge in pixels
-constexpr u32 LH = LT + 4;   // halo edge in texels
-constexpr u32 PPT = 4;       // vertically adjacent pixels per thread
+constexpr u32 LT = 32;       // tile width in pixels
+constexpr u32 LH = LT + 4;   // halo width in texels
 
+// PPT = vertically adjacent pixels per thread: the workgroup's tile is 32 x 8 PPT pixels.  More pixels per thread share more window texels
+// (fewer LDS reads per pixel) but make fewer and longer waves.  Measured (profiles/r06j_loss_grad_pixels_per_thread_ab.txt): at c3 40.6 us
+// with 2, 43.2 with 4 (rounds 2-3), 42.4 with 1; at c2, where 32 x 32 tiles leave one or two waves per SIMD and the kernel lasts as long as one
+// wave's 3 000 instructions, 11.7 us with 1, 12.4 with 2, 14.8 with 4.  The launcher picks 1 up to 640 x 480 and 2 above; the arithmetic per
+// pixel is the same in every form.
+template <u32 PPT>
 __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32* __restrict__ pred, const u32* __restrict__ targ,
                                                          wdgs_training_config cfg, float4* __restrict__ out, int4* __restrict__ acc, u32 acc_quads,
                                                          const u32* __restrict__ acc_dirty) {
@@ -38,12 +44,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
     // Texel pair = 24 bytes: {pred.r, pred.g, pred.b, targ.r} + {targ.g, targ.b} (two float4 would carry 8 bytes of padding per texel:
     // 41.5 KB per workgroup = 3 per CU; at 31 KB five fit, the halo loads of one overlap the window sums of the others and the tail of
     // the 2040-workgroup grid is shorter).
-    __shared__ float4 sp[LH][LH];
-    __shared__ float2 st[LH][LH];
+    constexpr u32 TH = 8u * PPT, HH = TH + 4u;   // tile and halo height
+    __shared__ float4 sp[HH][LH];
+    __shared__ float2 st[HH][LH];
     s_lut[threadIdx.x] = wd_div((float)threadIdx.x, 255.0f);
     __syncthreads();
-    const int bx = blockIdx.x * LT, by = blockIdx.y * LT;
-    for (u32 t = threadIdx.x; t < LH * LH; t += 256u) {
+    const int bx = blockIdx.x * LT, by = blockIdx.y * TH;
+    for (u32 t = threadIdx.x; t < HH * LH; t += 256u) {
         const int hy = (int)(t / LH), hx = (int)(t % LH);
         int gx = bx + hx - 2, gy = by + hy - 2;
         gx = gx < 0 ? 0 : (gx > (int)W - 1 ? (int)W - 1 : gx);
@@ -167,8 +174,14 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(u32 W, u32 H, const u32*
 int launch_loss_grad(wdgs_device* dev, u32 W, u32 H, const void* pred, const void* targ, const wdgs_training_config& cfg, void* out, void* acc, u32 acc_rows,
                      const void* acc_dirty) {
     if (W == 0 || H == 0) return WDGS_OK;
-    WDGS_LAUNCH(dev, "loss_grad", loss_grad_kernel, dim3(ceil_div(W, LT), ceil_div(H, LT)), dim3(256), 0, W, H, (const u32*)pred, (const u32*)targ, cfg,
-                (float4*)out, (int4*)acc, acc_rows * 3u /*12 i32 per row*/, (const u32*)acc_dirty);
+    // WDGS_LOSS_PPT=1|2|4 forces the pixels per thread (same-box A/B)
+    static const int ppt_env = std::getenv("WDGS_LOSS_PPT") ? std::atoi(std::getenv("WDGS_LOSS_PPT")) : 0;
+    const u32 ppt = ppt_env == 1 || ppt_env == 2 || ppt_env == 4 ? (u32)ppt_env : ((size_t)W * H <= 640u * 480u ? 1u : 2u);
+#define WDGS_LOSS_LAUNCH(PPT_)                                                                                                                                       \
+    WDGS_LAUNCH(dev, "loss_grad", loss_grad_kernel<PPT_>, dim3(ceil_div(W, LT), ceil_div(H, 8u * PPT_)), dim3(256), 0, W, H, (const u32*)pred, (const u32*)targ, cfg, \
+                (float4*)out, (int4*)acc, acc_rows * 3u /*12 i32 per row*/, (const u32*)acc_dirty)
+    if (ppt == 1u) { WDGS_LOSS_LAUNCH(1u); } else if (ppt == 2u) { WDGS_LOSS_LAUNCH(2u); } else { WDGS_LOSS_LAUNCH(4u); }
+#undef WDGS_LOSS_LAUNCH
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
