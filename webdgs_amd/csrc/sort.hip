@@ -27,8 +27,12 @@
 namespace {
 
 constexpr u32 SORT_THREADS = 256;
-constexpr u32 SORT_ITEMS = 16;
-constexpr u32 SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per partition
+// Keys per thread of a partition (ITEMS below): 16 -- partitions of 4096 keys -- or, for a sorter of small capacity, 4: c2's row pass has 88
+// workgroups of 4096 keys for 256 CUs, and each lasts as long as one wave's serial ranking of ITEMS rounds; with 1024 keys it has 352.
+// Same box (profiles/r06k_sort_partition_size_ab.txt, r06l_*): c2 sort 37.2 -> 32.4 us, 5 800 -> 6 010 it/s.  Large sorters keep 16: with 8, c3 is
+// unchanged and c5 (41 M entries) loses 20 % of its sort (more partitions: a longer count table and row scan, shorter runs per write).
+constexpr u32 SORT_ITEMS_MAX = 16;
+constexpr u32 SORT_TILE_MAX = SORT_THREADS * SORT_ITEMS_MAX;  // keys per partition of the default form; capacities are multiples of it
 constexpr u32 RADIX = 256;
 
 // The digit a pass sorts on: bits [shift, shift + width) of the key ((key >> shift) & dmask) or, for the second pass of a forward-pass
@@ -39,19 +43,21 @@ struct DigitOf {
     __device__ __forceinline__ u32 operator()(u32 key) const { return row_inv ? __umulhi((key >> 16u) - 1u, row_inv) : ((key >> shift) & dmask); }
 };
 
+template <u32 ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, DigitOf digit_of,
                                                                  u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/, u32* __restrict__ ranges_init,
                                                                  u32 total_tiles) {
     WD_STREAM_PRIO();
+    constexpr u32 TILE = SORT_THREADS * ITEMS;  // keys per partition
     __shared__ u32 lh[SORT_THREADS / 64][RADIX];
     const u32 count = *count_ptr;
     const u32 part = blockIdx.x;
-    const u32 base = part * SORT_TILE;
+    const u32 base = part * TILE;
     const u32 dmask = digit_of.dmask;
     // ranges_init (nullable): the per-tile range table the scatter of this pass lowers (sort_scatter, ranges_mode 2) starts out "empty"
     // with its terminator ranges[T] = E -- set here, by the kernel that runs before that scatter (partition 0 runs even for an empty list)
     if (ranges_init) {
-        const u32 active = max((count + SORT_TILE - 1u) / SORT_TILE, 1u);
+        const u32 active = max((count + TILE - 1u) / TILE, 1u);
         if (part < active)
             for (u32 t = part * SORT_THREADS + threadIdx.x; t <= total_tiles; t += active * SORT_THREADS) ranges_init[t] = (t == total_tiles) ? count : 0xFFFFFFFFu;
     }
@@ -60,9 +66,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
 #pragma unroll
     for (u32 w = 0; w < SORT_THREADS / 64; w++) lh[w][threadIdx.x] = 0;
     __syncthreads();
-    if (base + SORT_TILE <= count) {
+    if (base + TILE <= count) {
 #pragma unroll
-        for (u32 j = 0; j < SORT_ITEMS / 4; j++) {
+        for (u32 j = 0; j < ITEMS / 4; j++) {
             const uint4 q = *reinterpret_cast<const uint4*>(keys + base + (j * SORT_THREADS + threadIdx.x) * 4u);
             // the four keys of a lane are neighbours in memory and, in tile-ordered data, usually share their digit: merge equal
             // digits inside the lane first (same-address LDS atomics of one wave-instruction serialise; they were 86 % of this
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
             }
         }
     } else {
-        for (u32 j = 0; j < SORT_ITEMS; j++) {
+        for (u32 j = 0; j < ITEMS; j++) {
             const u32 i = base + j * SORT_THREADS + threadIdx.x;
             if (i < count) atomicAdd(&lh[wave][digit_of(keys[i])], 1u);
         }
@@ -89,11 +95,13 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
 }
 
 // One workgroup per digit: in-place exclusive scan of counts[digit][0 .. active_parts), row total -> totals[digit].
+template <u32 ITEMS>
 __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ counts, const u32* __restrict__ count_ptr, u32 num_parts,
                                                               u32* __restrict__ totals) {
     WD_STREAM_PRIO();
+    constexpr u32 TILE = SORT_THREADS * ITEMS;  // keys per partition
     __shared__ u32 s_w[4];
-    const u32 active = (*count_ptr + SORT_TILE - 1u) / SORT_TILE;
+    const u32 active = (*count_ptr + TILE - 1u) / TILE;
     u32* row = counts + (size_t)blockIdx.x * num_parts;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u32 carry = 0;
@@ -126,26 +134,28 @@ __global__ __launch_bounds__(256) void sort_scan_rows_kernel(u32* __restrict__ c
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <u32 ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                     u32* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                                     const u32* __restrict__ count_ptr, DigitOf digit_of, u32 num_parts,
                                                                     const u32* __restrict__ offsets /*scanned rows*/, const u32* __restrict__ digit_totals,
                                                                     u32* __restrict__ ranges, u32 ranges_mode, u32 total_tiles) {
     WD_STREAM_PRIO();
+    constexpr u32 TILE = SORT_THREADS * ITEMS;  // keys per partition
     __shared__ u32 whist[SORT_THREADS / 64][RADIX];
     const u32 dmask = digit_of.dmask;
     const u32 count = *count_ptr;
     // neighbouring partitions write neighbouring slices of every digit run: the ACTIVE ones (the grid is sized for the capacity) are
     // numbered so that neighbours share an XCD (common.h)
-    const u32 active_parts = max((count + SORT_TILE - 1u) / SORT_TILE, 1u);  // partition 0 runs even for an empty list
+    const u32 active_parts = max((count + TILE - 1u) / TILE, 1u);  // partition 0 runs even for an empty list
     if (blockIdx.x >= active_parts) return;
     const u32 part = xcd_contiguous(blockIdx.x, active_parts);
-    const u32 base = part * SORT_TILE;
+    const u32 base = part * TILE;
     // The per-tile range table of a tile-structured sort (sort_segmented) is built by the two scatter passes themselves: the first one
     // sets every entry to "empty" (and the terminator ranges[T] = E), the second one -- whose output is in tile order -- lowers
     // ranges[tile] to the first position it writes for that tile (below).  ranges_mode: 0 none, 1 initialise, 2 lower.
     if (ranges_mode == 1u) {
-        const u32 active = max((count + SORT_TILE - 1u) / SORT_TILE, 1u);  // partition 0 runs even for an empty list
+        const u32 active = max((count + TILE - 1u) / TILE, 1u);  // partition 0 runs even for an empty list
         if (part < active)
             for (u32 t = part * SORT_THREADS + threadIdx.x; t <= total_tiles; t += active * SORT_THREADS) ranges[t] = (t == total_tiles) ? count : 0xFFFFFFFFu;
     }
@@ -161,18 +171,18 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
 
     // Wave w owns keys [base + w*1024, base + (w+1)*1024) in 16 rounds of 64 consecutive keys: the order
     // (wave, round, lane) is the input order, which is what makes the pass stable.
-    u32 k[SORT_ITEMS], v[SORT_ITEMS], rk[SORT_ITEMS];
+    u32 k[ITEMS], v[ITEMS], rk[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (u32 j = 0; j < SORT_ITEMS; j++) {
-        const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
+    for (u32 j = 0; j < ITEMS; j++) {
+        const u32 i = base + wave * (ITEMS * 64u) + j * 64u + lane;
         const bool valid = i < count;
         k[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
         v[j] = valid ? vals_in[i] : 0u;
     }
 #pragma unroll
-    for (u32 j = 0; j < SORT_ITEMS; j++) {
-        const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
+    for (u32 j = 0; j < ITEMS; j++) {
+        const u32 i = base + wave * (ITEMS * 64u) + j * 64u + lane;
         const bool valid = i < count;
         const u32 digit = valid ? digit_of(k[j]) : 0u;
         unsigned long long m = __ballot(valid);
@@ -193,8 +203,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     // Reorder the partition in LDS so that it leaves in digit runs: position in the partition's sorted order =
     // (digits below) + (same digit in earlier waves) + rank in own wave.  A direct scatter writes each run 4 B at a time from 16
     // different wave-instructions (write amplification 1.9x measured); from LDS consecutive lanes write consecutive addresses.
-    __shared__ u32 s_keys[SORT_TILE];
-    __shared__ u32 s_vals[SORT_TILE];
+    __shared__ u32 s_keys[TILE];
+    __shared__ u32 s_vals[TILE];
     __shared__ u32 s_gdelta[RADIX];   // global base of digit d minus its start in the partition's sorted order
     __shared__ u32 s_wsum[SORT_THREADS / 64];
     {
@@ -241,8 +251,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
     }
     __syncthreads();
 #pragma unroll
-    for (u32 j = 0; j < SORT_ITEMS; j++) {
-        const u32 i = base + wave * (SORT_ITEMS * 64u) + j * 64u + lane;
+    for (u32 j = 0; j < ITEMS; j++) {
+        const u32 i = base + wave * (ITEMS * 64u) + j * 64u + lane;
         if (i < count) {
             const u32 digit = digit_of(k[j]);
             const u32 lpos = whist[wave][digit] + rk[j];
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u32* _
         }
     }
     __syncthreads();
-    const u32 n_here = min(SORT_TILE, count - base);
+    const u32 n_here = min(TILE, count - base);
 #pragma unroll 4
     for (u32 e = threadIdx.x; e < n_here; e += SORT_THREADS) {
         const u32 key = s_keys[e];
@@ -537,7 +547,8 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
 
 struct wdgs_sorter {
     wdgs_device* dev;
-    u32 capacity;       // elements (multiple of SORT_TILE)
+    u32 capacity;       // elements (multiple of SORT_TILE_MAX)
+    u32 items;          // keys per thread of a partition: SORT_ITEMS_MAX, or 4 for a small sorter
     u32 num_parts;
     const u32* count_ptr;
     u32* keys[2];
@@ -554,8 +565,9 @@ int wdgs_sorter_create(wdgs_device* dev, uint32_t max_capacity, const void* stat
     WDGS_REQUIRE(max_capacity <= 0xFFFFF000u, WDGS_E_CAPACITY, "sorter capacity %u too large", max_capacity);
     wdgs_sorter* s = new wdgs_sorter();
     s->dev = dev;
-    s->capacity = (u32)align_up(max_capacity > 0 ? max_capacity : 1, SORT_TILE);
-    s->num_parts = s->capacity / SORT_TILE;
+    s->capacity = (u32)align_up(max_capacity > 0 ? max_capacity : 1, SORT_TILE_MAX);
+    s->items = s->capacity <= (8u << 20) ? 4u : SORT_ITEMS_MAX;  // (c2's passes: 3.75 M entries of capacity, 0.36 M used; c3's: 37.5 M)
+    s->num_parts = s->capacity / (SORT_THREADS * s->items);
     s->count_ptr = (const u32*)stats_dev;
     s->final_out_index = 0;
     for (int i = 0; i < 2; i++) { s->keys[i] = nullptr; s->vals[i] = nullptr; }
@@ -608,13 +620,27 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
         const u32 width = left / (passes - p);
         left -= width;
         const u32 dmask = (1u << width) - 1u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts,
-                    s->counts, (u32*)nullptr, 0u);
-        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(dmask + 1u), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        if (s->items == 4u) {
+            WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts,
+                        s->counts, (u32*)nullptr, 0u);
+        } else {
+            WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts,
+                        s->counts, (u32*)nullptr, 0u);
+        }
+        if (s->items == 4u) {
+            WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<4u>, dim3(dmask + 1u), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        } else {
+            WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<SORT_ITEMS_MAX>, dim3(dmask + 1u), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        }
         // (two passes: the first initialises the range table, the second fills it; any other pass count keeps the search kernel)
         const u32 ranges_mode = (passes == 2u) ? p + 1u : 0u;
-        WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts, s->counts, s->totals, ranges, ranges_mode, num_segments);
+        if (s->items == 4u) {
+            WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                        s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts, s->counts, s->totals, ranges, ranges_mode, num_segments);
+        } else {
+            WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                        s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts, s->counts, s->totals, ranges, ranges_mode, num_segments);
+        }
         src ^= 1;
         shift += width;
     }
@@ -636,10 +662,23 @@ int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* rang
     wdgs_device* dev = s->dev;
     const u32 tiles = num_tiles_x * num_tiles_y;
     const DigitOf rows{0u, num_tiles_y - 1u, 0xFFFFFFFFu / num_tiles_x + 1u};  // (num_tiles_x >= 2)
-    WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles);
-    WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(num_tiles_y), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
-    WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->vals[0], s->keys[1], s->vals[1], s->count_ptr, rows,
-                s->num_parts, s->counts, s->totals, ranges, 2u, tiles);
+    if (s->items == 4u) {
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles);
+    } else {
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles);
+    }
+    if (s->items == 4u) {
+        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<4u>, dim3(num_tiles_y), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+    } else {
+        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<SORT_ITEMS_MAX>, dim3(num_tiles_y), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+    }
+    if (s->items == 4u) {
+        WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->vals[0], s->keys[1], s->vals[1], s->count_ptr, rows,
+                    s->num_parts, s->counts, s->totals, ranges, 2u, tiles);
+    } else {
+        WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->vals[0], s->keys[1], s->vals[1], s->count_ptr, rows,
+                    s->num_parts, s->counts, s->totals, ranges, 2u, tiles);
+    }
     WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(tiles), dim3(SEG_THREADS), 0, s->keys[1], s->vals[1], s->keys[0], s->vals[0], ranges, tiles);
     WDGS_CHECK_HIP(hipGetLastError());
     s->final_out_index = 1;
@@ -656,11 +695,25 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
     int src = 0;
     for (u32 p = 0; p < passes; p++) {
         const u32 shift = p * 8u;
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts,
-                    s->counts, (u32*)nullptr, 0u);
-        WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
-        WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts, s->counts, s->totals, (u32*)nullptr, 0u, 0u);
+        if (s->items == 4u) {
+            WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts,
+                        s->counts, (u32*)nullptr, 0u);
+        } else {
+            WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts,
+                        s->counts, (u32*)nullptr, 0u);
+        }
+        if (s->items == 4u) {
+            WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<4u>, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        } else {
+            WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<SORT_ITEMS_MAX>, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
+        }
+        if (s->items == 4u) {
+            WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                        s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts, s->counts, s->totals, (u32*)nullptr, 0u, 0u);
+        } else {
+            WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
+                        s->vals[src ^ 1], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts, s->counts, s->totals, (u32*)nullptr, 0u, 0u);
+        }
         src ^= 1;
     }
     WDGS_CHECK_HIP(hipGetLastError());
