@@ -32,6 +32,10 @@ export class Trainer {
   flushPointCloud(): void;
   /** step() on a given global batch of views (worldSize * viewsPerStep indices); no reference counterpart. */
   stepViews(viewIds?: number[]): Promise<void>;
+  /** maxTileEntries for a new forward pass: the caller's, or what an overflow has grown the library-sized lists to (0 = the library's sizing). */
+  tileEntries(): number;
+  /** Doubles the library-sized tile-entry lists after a WDGS_E_CAPACITY report and rebuilds the passes; false when the caller pinned maxTileEntries. */
+  growTileEntryCapacity(error: Error): boolean;
   /** Records every view's command buffers up front; the number of steps taken depends on the dataset size only. */
   warmupCommandBuffers(): Promise<number>;
   /** Awaits every step still in flight (pipelineDepth > 1). */

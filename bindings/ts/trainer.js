@@ -42,6 +42,7 @@ class Trainer {
     this.random = o.random || Math.random;
     this.useCommandBuffers = o.useCommandBuffers !== false;
     this.maxTileEntries = o.maxTileEntries || 0;
+    this.grownTileEntries = 0;   // (sizing left to the library only: what an overflow has made of the lists, stepViews)
     this.reusePasses = o.reusePasses !== false;   // applyPointCloudSwap resizes the passes instead of rebuilding them
     // Adam writes the trained SH-DC halves to a compact array that K1 reads instead of 6 bytes into every 96-byte SH row (Optimizer.setDeferredSH);
     // the rows are flushed at hand-over points (flushPointCloud; host reads and forward passes built on the cloud follow by themselves).
@@ -208,7 +209,7 @@ class Trainer {
 
   newOpSet(w, h) {
     const fw = new hip.TiledForwardPass(this.device, this.pointCloud, this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer,
-      { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+      { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
     fw.setDcSource(this.dcWords);
     return [fw, new hip.TiledRasterizer({ device: this.device, forwardPass: fw, format: 'rgba8unorm' }),
       new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig })];
@@ -220,7 +221,7 @@ class Trainer {
     this.lastViewportWidth = w; this.lastViewportHeight = h;
     const cam = this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer;
     if (!this.forwardPass) {
-      this.forwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+      this.forwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
       this.forwardPass.setDcSource(this.dcWords);
     } else this.forwardPass.setViewport(w, h);
     if (!this.rasterizer) this.rasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.forwardPass, format: 'rgba8unorm' });
@@ -244,7 +245,7 @@ class Trainer {
     this.destroyMoreMetricSets();
     if (this.metricsTarget) this.metricsTarget.destroy();
     this.metricsViewportWidth = w; this.metricsViewportHeight = h;
-    this.metricsForwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, this.metricsCameraBuffer, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+    this.metricsForwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, this.metricsCameraBuffer, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
     this.metricsForwardPass.setDcSource(this.dcWords);
     this.metricsRasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.metricsForwardPass, format: 'rgba8unorm' });
     this.metricsPass = new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig });
@@ -258,7 +259,7 @@ class Trainer {
     const w = this.metricsViewportWidth, h = this.metricsViewportHeight;
     while (this.moreMetricSets.length < k) {
       const cam = this.device.createBuffer({ size: 272, label: 'metrics camera uniform' });
-      const fw = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.maxTileEntries });
+      const fw = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
       fw.setDcSource(this.dcWords);
       this.moreMetricSets.push([fw, new hip.TiledRasterizer({ device: this.device, forwardPass: fw, format: 'rgba8unorm' }),
         new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig }),
@@ -319,8 +320,49 @@ class Trainer {
   /** One training iteration (trainer.ts:568-660): the views are drawn with this.random, as the reference picks Math.random() per step. */
   async step() { return this.stepViews(undefined); }
 
-  /** step() on a given global batch of views (worldSize * viewsPerStep indices; with worldSize > 1 each rank takes its shard). */
+  /** step() on a given global batch of views (worldSize * viewsPerStep indices; with worldSize > 1 each rank takes its shard).
+   *  Tile-entry capacity: with maxTileEntries left at 0 the forward passes size their entry lists from the cloud (30 entries per Gaussian, at
+   *  least 2^20); a cloud that training has thinned out and whose survivors have grown can outrun that (c3 does, after ~3 000 iterations of
+   *  the default schedule).  The reference truncates such a list silently; the library skips the step on the device and reports it.  The
+   *  Trainer then doubles the lists (growTileEntryCapacity), warns, and training goes on -- the step or two that were skipped are lost
+   *  iterations.  A capacity the caller pinned is never touched: the error is the caller's. */
   async stepViews(viewIds) {
+    try {
+      await this.stepViewsOnce(viewIds);
+    } catch (e) {
+      if (!(e && e.code === 'WDGS_E_CAPACITY' && this.growTileEntryCapacity(e))) throw e;
+    }
+  }
+
+  /** maxTileEntries for a new forward pass: the caller's, or what growTileEntryCapacity has arrived at (0 = the library's own sizing). */
+  tileEntries() { return this.maxTileEntries || this.grownTileEntries; }
+
+  growTileEntryCapacity(error) {
+    if (this.maxTileEntries !== 0 || this.device.handle === null) return false;
+    let now = Math.max(this.grownTileEntries, 1 << 20);
+    for (const fw of this.forwardPasses()) now = Math.max(now, fw.getResources().maxTileEntries);
+    const m = /(\d+) entries needed/.exec(String(error && error.message));
+    const next = Math.min(Math.max(2 * now, m ? Math.floor(Number(m[1]) * 1.5) : 0), 0xFFFFF000);
+    if (next <= now) return false;
+    console.warn(`tile-entry lists grown from ${now} to ${next} entries after an overflow (${error.message}); the step that overflowed was skipped`);
+    this.grownTileEntries = next;
+    this.tickets = [];
+    try { this.device.synchronize(); } catch (_e) { /* a step still in flight overflowed as well */ }
+    this.invalidateCommandBuffers();
+    // forward passes own the lists: every pass set is rebuilt around lists of the new size (as a cloud the passes cannot follow rebuilds them)
+    for (const name of ['forwardPass', 'rasterizer', 'backwardPass', 'metricsForwardPass', 'metricsRasterizer', 'metricsPass']) {
+      if (this[name]) this[name].destroy();
+      this[name] = null;
+    }
+    this.destroyMoreOpSets();
+    this.destroyMoreMetricSets();
+    this.gradientOutputApplied = null;
+    this.ensurePipelines(this.lastViewportWidth, this.lastViewportHeight);
+    for (const fw of this.forwardPasses()) fw.setDcSource(this.dcWords);
+    return true;
+  }
+
+  async stepViewsOnce(viewIds) {
     if (!this.isTraining || !this.pointCloud) return;
     const t0 = process.hrtime();
     const nViews = this.worldSize * this.viewsPerRank;

@@ -85,6 +85,42 @@ def test_overflowing_step_is_reported_and_changes_nothing(hip_device, vpr, depth
 
 
 @pytest.mark.parametrize("depth", [1, 2])
+def test_lists_sized_by_the_library_grow_after_an_overflow(hip_device, depth):
+    """With ``maxTileEntries`` left to the library (30 entries per Gaussian, at least 2^20) a cloud of few, large splats outruns the lists --
+    what a long run of the default schedule arrives at (c3 after ~3 000 iterations).  The Trainer then doubles them, says so, and goes on
+    training; a pinned capacity stays an error (the test above)."""
+    import warnings
+    from webdgs_amd import synth
+    dev = hip_device
+    cfg = synth.SceneConfig(2, 6000, 512, 384, 1, 550.0, 0.2, "few-large-splats")   # 768 tiles, splats that cover most of them
+    g, sh = synth.make_gaussians(cfg)
+    cams = synth.circle_cameras(cfg, 2)
+    images = [dict(texture=dev.bufferFrom(np.zeros((cfg.height, cfg.width, 4), np.uint8)), width=cfg.width, height=cfg.height) for _ in cams]
+    t = Trainer(dev, seed=9, pipeline_depth=depth)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset([dict(camera=c, width=cfg.width, height=cfg.height) for c in cams], images)
+    t.start()
+    before = t.pointCloud.gaussian_3d_buffer.read(np.uint32).copy()
+    try:
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            for i in range(8):
+                t.step([i % 2])
+            t.drain()
+            dev.synchronize()
+        grown = [w for w in seen if issubclass(w.category, RuntimeWarning) and "tile-entry lists grown" in str(w.message)]
+        assert grown, "the overflow was reported as a warning"
+        cap = int(t.forwardPass.getResources()["maxTileEntries"])
+        needed = int(t.forwardPass.check()[0])
+        assert cap > (1 << 20) and needed > (1 << 20) and cap >= needed, (cap, needed)
+        assert (t.pointCloud.gaussian_3d_buffer.read(np.uint32) != before).any(), "training went on after the lists had grown"
+        assert t.getIteration() >= 8 - 2 * len(grown), "only the steps that overflowed are lost"
+    finally:
+        t.destroy()
+
+
+@pytest.mark.parametrize("depth", [1, 2])
 def test_kernel_times_are_collected_by_ticket_waits(hip_device, depth):
     """bench.py's per-kernel leg: eager steps with an event pair around every launch; the pairs are folded into the totals by the
     waits of the steps themselves (not only by a full synchronize), and none is lost when a wait finds later kernels unfinished."""

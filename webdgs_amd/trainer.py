@@ -31,6 +31,7 @@ class Trainer:
         self.optimizerHyperparameters = dict(ops.DEFAULT_ADAM_HYPERPARAMETERS)
         self.world_size, self.rank, self.views_per_rank = int(world_size), int(rank), max(1, int(views_per_rank))
         self.maxTileEntries = int(maxTileEntries)
+        self._grown_tile_entries = 0  # (auto sizing only: what an overflow has made of the lists, step())
         # the transport of the data-parallel exchange (parallel.Exchange); world_size == 1 needs none
         self.exchange = exchange if exchange is not None else (parallel.default_exchange(device, self.world_size) if self.world_size > 1 else parallel.Exchange())
         # sliced step (reduce-scatter / owned-slice Adam / all-gather): any real exchange, also a forced one in a world of one
@@ -315,7 +316,7 @@ class Trainer:
         w, h = self.lastViewportWidth, self.lastViewportHeight
         if self.forwardPass is None:
             self.forwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
-                                                    dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+                                                    dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
             self.forwardPass.setDcSource(self._dc_words)
         else:
             self.forwardPass.setViewport(w, h)
@@ -331,7 +332,7 @@ class Trainer:
             more[2].setViewport(w, h)
         while len(self._more_op_sets) < self._op_sets - 1:
             fw = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
-                                      dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+                                      dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
             fw.setDcSource(self._dc_words)
             self._more_op_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
                                        ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))])
@@ -352,7 +353,7 @@ class Trainer:
         self._destroy_more_metric_sets()
         self.metricsViewportWidth, self.metricsViewportHeight = w, h
         self.metricsForwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.metricsCameraBuffer,
-                                                       dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+                                                       dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
         self.metricsForwardPass.setDcSource(self._dc_words)
         self.metricsRasterizer = ops.TiledRasterizer(dict(device=self.device, forwardPass=self.metricsForwardPass, format="rgba8unorm"))
         self.metricsPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
@@ -366,7 +367,7 @@ class Trainer:
         w, h = self.metricsViewportWidth, self.metricsViewportHeight
         while len(self._more_metric_sets) < k:
             cam = self.device.createBuffer(272, "metrics camera uniform")
-            fw = ops.TiledForwardPass(self.device, self.pointCloud, cam, dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self.maxTileEntries))
+            fw = ops.TiledForwardPass(self.device, self.pointCloud, cam, dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
             fw.setDcSource(self._dc_words)
             self._more_metric_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
                                            ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig)),
@@ -434,7 +435,55 @@ class Trainer:
 
     def step(self, view_ids: Optional[list] = None) -> None:
         """One training iteration (trainer.ts:568-660).  ``view_ids``: the global batch's views (default: drawn at random, as the
-        reference picks ``Math.random()`` per step); with ``world_size > 1`` each rank takes its shard."""
+        reference picks ``Math.random()`` per step); with ``world_size > 1`` each rank takes its shard.
+
+        Tile-entry capacity: with ``maxTileEntries`` left at 0 the forward passes size their entry lists from the cloud (30 entries per
+        Gaussian, at least 2^20) -- a cloud that training has thinned out and whose survivors have grown can outrun that (c3 does, after
+        ~3 000 iterations of the default schedule).  The reference truncates such a list silently; the library skips the step on the device
+        and reports it.  The Trainer then doubles the lists (``_grow_tile_entry_capacity``), warns, and training goes on -- the step or two
+        that were skipped are lost iterations.  A capacity the caller pinned is never touched: the error is the caller's."""
+        try:
+            self._step(view_ids)
+        except ops.CapacityError as e:
+            if not self._grow_tile_entry_capacity(e):
+                raise
+
+    def _tile_entries(self) -> int:
+        """``maxTileEntries`` for a new forward pass: the caller's, or what ``_grow_tile_entry_capacity`` has arrived at (0 = the library's own sizing)."""
+        return self.maxTileEntries or self._grown_tile_entries
+
+    def _grow_tile_entry_capacity(self, error) -> bool:
+        import re
+        import warnings
+        if self.maxTileEntries != 0 or not self.device.handle:
+            return False
+        now = max([int(fw.getResources()["maxTileEntries"]) for fw in self._forward_passes()] + [self._grown_tile_entries, 1 << 20])
+        m = re.search(r"(\d+) entries needed", str(error))
+        new = min(max(2 * now, int(int(m.group(1)) * 1.5) if m else 0), 0xFFFFF000)
+        if new <= now:
+            return False
+        warnings.warn(f"tile-entry lists grown from {now} to {new} entries after an overflow ({error}); the step that overflowed was skipped", RuntimeWarning, stacklevel=3)
+        self._grown_tile_entries = new
+        self._tickets = []
+        try:
+            self.device.synchronize()
+        except ops.CapacityError:
+            pass  # (a step still in flight overflowed as well)
+        self._invalidate_command_buffers()
+        # forward passes own the lists: every pass set is rebuilt around lists of the new size (as a cloud the passes cannot follow rebuilds them)
+        for name in self._OP_NAMES:
+            if name != "optimizer" and getattr(self, name) is not None:
+                getattr(self, name).destroy()
+                setattr(self, name, None)
+        self._destroy_more_op_sets()
+        self._destroy_more_metric_sets()
+        self._gradient_output_applied = None
+        self.ensurePipelines(self.lastViewportWidth, self.lastViewportHeight)
+        for fw in self._forward_passes():
+            fw.setDcSource(self._dc_words)
+        return True
+
+    def _step(self, view_ids: Optional[list] = None) -> None:
         if not self.isTraining or self.pointCloud is None:
             return
         stepStart = time.perf_counter()
