@@ -3,7 +3,7 @@
 // BASELINE.json configuration, through bindings/ts/trainer.js over the N-API addon (no Python, no torch in the process).
 //
 //     node bindings/napi/bench.js [--config c3] [--steps 30] [--warmup 5] [--views-per-step 1] [--lanes 0] [--pipeline-depth 2] [--min-seconds 1]
-//                                 [--views 0] [--gpus 1] [--no-profile]
+//                                 [--views 0] [--gpus 1] [--no-profile] [--sustained-steps 0]
 //
 // Same workload as bench.py: the synthetic scene of SURVEY.md 8(d) (bindings/ts/synth.js generates the very bits webdgs_amd/synth.py does),
 // ground truth rendered by the HIP forward from the perturbed scene, 8 circle cameras (64 for a batched step), the reference's one-view step
@@ -19,9 +19,9 @@ const os = require('os');
 const path = require('path');
 
 function parseArgs(argv) {
-  const a = { config: 'c3', steps: 30, warmup: 5, viewsPerStep: 0, lanes: 0, pipelineDepth: 2, minSeconds: 1.0, views: 0, gpus: 1, profile: true };
+  const a = { config: 'c3', steps: 30, warmup: 5, viewsPerStep: 0, lanes: 0, pipelineDepth: 2, minSeconds: 1.0, views: 0, gpus: 1, profile: true, sustainedSteps: 0 };
   const names = { '--config': 'config', '--steps': 'steps', '--warmup': 'warmup', '--views-per-step': 'viewsPerStep', '--views-per-rank': 'viewsPerStep', '--lanes': 'lanes',
-    '--pipeline-depth': 'pipelineDepth', '--min-seconds': 'minSeconds', '--views': 'views', '--gpus': 'gpus' };
+    '--pipeline-depth': 'pipelineDepth', '--min-seconds': 'minSeconds', '--views': 'views', '--gpus': 'gpus', '--sustained-steps': 'sustainedSteps' };
   for (let i = 0; i < argv.length; i++) {
     if (argv[i] === '--no-profile') { a.profile = false; continue; }
     const k = names[argv[i]];
@@ -201,6 +201,38 @@ async function main() {
   }
   stats = trainer.forwardPass.check();
 
+  // ---- BASELINE c3 "as written" through this host (bench.py: run_sustained): a fresh Trainer at the reference's densify defaults, wall clock around
+  // every step() of a run that crosses the first densify events (--sustained-steps 608 = bench.py's default leg)
+  let sustained = null;
+  if (args.sustainedSteps > 0 && world === 1 && vpr === 1) {
+    const st = new Trainer(dev, undefined, { random: seededRandom(99), pipelineDepth: args.pipelineDepth });
+    st.setPointCloud(cloudOf(scene));
+    st.setDataset(cameras, images);
+    st.setMaxIterations(1e9);
+    st.start();
+    for (let i = 0; i < 3; i++) await st.step();
+    await st.warmupCommandBuffers();
+    st.drain(); dev.synchronize();
+    const startIt = st.getIteration(), plain = [], events = [], sizes = [st.getPointCount()];
+    const tAll = now();
+    while (st.getIteration() < args.sustainedSteps) {
+      const before = st.getLastDensifyPruneIteration(), t0 = now();
+      await st.step();
+      const dt = now() - t0;
+      if (st.getLastDensifyPruneIteration() !== before) { events.push(dt); sizes.push(st.getPointCount()); } else plain.push(dt);
+    }
+    st.drain(); dev.synchronize();
+    const total = now() - tAll, n = st.getIteration() - startIt;
+    const sortedPlain = plain.slice().sort((a, b) => a - b), med = sortedPlain.length ? sortedPlain[Math.floor(sortedPlain.length / 2)] : 0;
+    const rerecord = plain.reduce((acc, d) => acc + (d > 4 * med ? d - med : 0), 0);
+    const r2 = (x) => Math.round(x * 100) / 100;
+    sustained = { steps: n, crosses_iterations: [startIt, st.getIteration()], iters_per_s_overall: r2(n / total), iters_per_s_steady: med > 0 ? r2(1 / med) : null,
+      ms_per_step_median: Math.round(med * 1e7) / 1e4, densify_events: events.length,
+      ms_per_densify_event: events.length ? r2((events.reduce((a, b) => a + b, 0) + rerecord) / events.length * 1e3) : null, points: sizes, pipeline_depth: args.pipelineDepth,
+      schedule: 'reference defaults: warm-up 500, interval 100, 10 metric views at 1/2 resolution, maxNewPointsPerStep 5000' };
+    const sc = st.pointCloud; st.destroy(); sc.gaussian_3d_buffer.destroy(); sc.sh_buffer.destroy();
+  }
+
   const msPerStep = elapsed / args.steps * 1e3, viewsPerStep = world * vpr;
   if (rank === 0) {
     const r4 = (x) => Math.round(x * 1e4) / 1e4;
@@ -217,7 +249,7 @@ async function main() {
           (viewsPerStep === 1 ? " (BASELINE c3: the reference's one-view step)" : ` (BASELINE c4 shape: ${vpr} views per rank per global step)`),
         views_per_rank: vpr, global_batch_views: viewsPerStep, lanes: trainer.lanes, pipeline_depth: args.pipelineDepth, tile_entries_E: stats.totalTileEntries,
         visible_V: stats.visibleCount, parallelism: world > 1 ? `dp${world}: views sharded; ${exchange.name}` : 'single GPU', densify_schedule: 'disabled in this leg' },
-      kernel_ms_per_step: kernelMs,
+      kernel_ms_per_step: kernelMs, sustained, c3_as_written_iters_per_s: sustained ? sustained.iters_per_s_overall : null,
     }));
   }
   barrier();

@@ -14,7 +14,7 @@ echo "== bench c2"; timeout -k 10 300 python3 bench.py --config c2 > $O/${TAG}_b
 echo "== bench c5"; timeout -k 10 400 python3 bench.py --config c5 --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c5.json 2> $O/${TAG}_bench_c5.err
 echo "== bench c3, 8 views per step"; for L in 3 1; do timeout -k 10 500 python3 bench.py --views-per-rank 8 --lanes $L --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c3_vpr8_lanes${L}.json 2> $O/${TAG}_bench_vpr8.err; done
 echo "== the same measurement through the TypeScript-side host (node + N-API addon)"
-timeout -k 10 400 node bindings/napi/bench.js --config c3 > $O/${TAG}_benchjs_c3.json 2> $O/${TAG}_benchjs_c3.err
+timeout -k 10 400 node bindings/napi/bench.js --config c3 --sustained-steps 608 > $O/${TAG}_benchjs_c3.json 2> $O/${TAG}_benchjs_c3.err
 timeout -k 10 500 node bindings/napi/bench.js --config c3 --views-per-step 8 --steps 10 --warmup 2 > $O/${TAG}_benchjs_c3_vpr8.json 2> $O/${TAG}_benchjs_c3_vpr8.err
 echo "== kernel trace of the c3 bench"
 rm -rf $O/prof_${TAG}

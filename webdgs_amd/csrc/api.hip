@@ -4,7 +4,9 @@
 #include <cstring>
 #include <algorithm>
 #include <mutex>
+#include <map>
 #include <set>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -77,17 +79,106 @@ void wdgs_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---------------------------------------------------------------- device memory
+// hipFree is not cheap everywhere: with the ROCm 7.2 runtime a host links against (node's addon, a C++ host) one call takes ~100 us on an idle
+// device, with the 7.0 runtime PyTorch brings along ~1 us (profiles/r06s_free_cost.txt) -- and a densify event frees and allocates a cloud, six state
+// arrays and the densify scratch (3.5 ms of a 9 ms event in the node host).  Freed blocks are therefore kept, by size class (eighth-of-a-power-of-two
+// steps: a cloud that changed by a few per cent lands in its old class), and handed out again.  A block may still be in use by queued work when it is
+// freed, so one that has not seen a hipDeviceSynchronize since (`freed_epoch`: every stream of the process, a torch or RCCL side stream included) is only reused behind one.  WDGS_ALLOC_CACHE=0: plain hipMalloc /
+// hipFree.  The cache holds at most a quarter of the device's memory; wdgs_device_destroy empties it.
+namespace {
+struct CachedBlock { void* p; int device; unsigned long long freed_epoch; };
+struct LiveBlock { size_t rounded; int device; };
+std::mutex g_alloc_mutex;
+std::unordered_map<void*, LiveBlock> g_live_blocks;
+std::multimap<size_t, CachedBlock> g_cached_blocks;   // by size class
+size_t g_cached_bytes = 0, g_cache_limit = 0;
+unsigned long long g_sync_epoch = 1;   // (guarded by g_alloc_mutex)
+bool alloc_cache_enabled() {
+    static const bool on = !(std::getenv("WDGS_ALLOC_CACHE") && std::getenv("WDGS_ALLOC_CACHE")[0] == '0');
+    return on;
+}
+size_t size_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    size_t pow2 = 4096;
+    while (pow2 * 2 <= bytes) pow2 *= 2;
+    const size_t step = pow2 / 8;
+    return (bytes + step - 1) / step * step;
+}
+void release_cached_blocks(int device) {
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    for (auto it = g_cached_blocks.begin(); it != g_cached_blocks.end();) {
+        if (it->second.device == device) { (void)hipFree(it->second.p); g_cached_bytes -= it->first; it = g_cached_blocks.erase(it); } else ++it;
+    }
+}
+}  // namespace
+
 int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
-    WDGS_CHECK_HIP(hipMalloc(p, bytes));
+    if (!alloc_cache_enabled()) {
+        WDGS_CHECK_HIP(hipMalloc(p, bytes));
+    } else {
+        const size_t rounded = size_class(bytes);
+        int device = 0;
+        WDGS_CHECK_HIP(hipGetDevice(&device));
+        bool need_sync = false;
+        {
+            std::lock_guard<std::mutex> lock(g_alloc_mutex);
+            auto range = g_cached_blocks.equal_range(rounded);
+            for (auto it = range.first; it != range.second; ++it)
+                if (it->second.device == device) {
+                    *p = it->second.p;
+                    need_sync = it->second.freed_epoch == g_sync_epoch;
+                    g_cached_bytes -= rounded;
+                    g_cached_blocks.erase(it);
+                    break;
+                }
+        }
+        if (*p && need_sync) {   // freed since the last full synchronisation: queued work may still touch it
+            const hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) { (void)hipFree(*p); *p = nullptr; WDGS_CHECK_HIP(e); }
+            std::lock_guard<std::mutex> lock(g_alloc_mutex);
+            g_sync_epoch++;
+        }
+        if (!*p) {
+            hipError_t e = hipMalloc(p, rounded);
+            if (e != hipSuccess) {   // make room: what the cache holds is this device's memory too
+                (void)hipGetLastError();
+                release_cached_blocks(device);
+                e = hipMalloc(p, rounded);
+            }
+            WDGS_CHECK_HIP(e);
+        }
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        g_live_blocks[*p] = LiveBlock{rounded, device};
+    }
     if (zero) WDGS_CHECK_HIP(hipMemsetAsync(*p, 0, bytes, stream));
     return WDGS_OK;
 }
 
-static void free_dev(void* p) {
-    if (p) (void)hipFree(p);
+void wdgs_free(void* p) {
+    if (!p) return;
+    if (alloc_cache_enabled()) {
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        auto it = g_live_blocks.find(p);
+        if (it != g_live_blocks.end()) {
+            const LiveBlock b = it->second;
+            g_live_blocks.erase(it);
+            if (g_cache_limit == 0) {
+                size_t free_b = 0, total_b = 0;
+                g_cache_limit = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) ? total_b / 4 : ((size_t)8 << 30);
+            }
+            if (g_cached_bytes + b.rounded <= g_cache_limit) {
+                g_cached_blocks.emplace(b.rounded, CachedBlock{p, b.device, g_sync_epoch});
+                g_cached_bytes += b.rounded;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
 }
+static void free_dev(void* p) { wdgs_free(p); }
 
 struct wdgs_buffer {
     void* ptr;
@@ -349,6 +440,7 @@ int wdgs_queue_wait(wdgs_device* d, uint64_t ticket) {
     return deferred_checks(d);
 }
 
+static void reap_command_buffers(wdgs_device* d, size_t at_most);   // (defined with the command buffers, below)
 int wdgs_device_destroy(wdgs_device* d) {
     if (!d) return WDGS_OK;
     {
@@ -364,6 +456,8 @@ int wdgs_device_destroy(wdgs_device* d) {
     }
     (void)wdgs_sync_lanes(d);
     collect_profile(d);
+    reap_command_buffers(d, (size_t)-1);
+    release_cached_blocks(d->ordinal);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lane_events) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lane_marks) if (e) (void)hipEventDestroy(e);
@@ -414,7 +508,18 @@ static void forward_consume_projection(wdgs_tiled_forward* f);
 // projection another encode had already consumed: offsets scanned twice, a tile-entry count far beyond the entries really written, stale keys
 // with a zero tile field among them, and sort_scatter's atomicMin(&ranges[(key >> 16) - 1]) landing 16 GB past the table -- the device fault
 // behind the abort of gpurun_out/r04o_tests.log.
-struct wdgs_command_buffer_impl { hipGraph_t graph; hipGraphExec_t exec; std::vector<wdgs_tiled_forward*> consumes; };
+struct wdgs_command_buffer_impl { hipGraph_t graph; hipGraphExec_t exec; std::vector<wdgs_tiled_forward*> consumes; wdgs_device* dev; };
+static void command_buffer_release(wdgs_command_buffer_impl* c) {
+    (void)hipGraphExecDestroy(c->exec);
+    (void)hipGraphDestroy(c->graph);
+    delete c;
+}
+static void reap_command_buffers(wdgs_device* d, size_t at_most) {
+    while (at_most-- && !d->dead_command_buffers.empty()) {
+        command_buffer_release(static_cast<wdgs_command_buffer_impl*>(d->dead_command_buffers.back()));
+        d->dead_command_buffers.pop_back();
+    }
+}
 
 int wdgs_encoder_begin(wdgs_device* d) {
     WDGS_REQUIRE(d, WDGS_E_INVALID, "null device");
@@ -433,7 +538,7 @@ int wdgs_encoder_finish(wdgs_device* d, wdgs_command_buffer** out) {
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGraphDestroy(graph); d->capture_consumes.clear(); wdgs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return WDGS_E_HIP; }
-    auto* c = new wdgs_command_buffer_impl{graph, exec, std::move(d->capture_consumes)};
+    auto* c = new wdgs_command_buffer_impl{graph, exec, std::move(d->capture_consumes), d};
     d->capture_consumes.clear();
     *out = reinterpret_cast<wdgs_command_buffer*>(c);
     return WDGS_OK;
@@ -465,6 +570,7 @@ int wdgs_queue_submit(wdgs_device* d, wdgs_command_buffer* cmd) {
     }
     for (wdgs_tiled_forward* f : c->consumes) forward_consume_projection(f);
     WDGS_CHECK_HIP(hipGraphLaunch(c->exec, d->stream));
+    reap_command_buffers(d, 1);   // (behind the launch: the device is busy with it while the host pays)
     return WDGS_OK;
 }
 namespace {
@@ -486,9 +592,12 @@ int wdgs_queue_on_done(wdgs_device* d, wdgs_done_callback fn, void* user) {
 int wdgs_command_buffer_destroy(wdgs_command_buffer* cmd) {
     if (!cmd) return WDGS_OK;
     auto* c = reinterpret_cast<wdgs_command_buffer_impl*>(cmd);
-    (void)hipGraphExecDestroy(c->exec);
-    (void)hipGraphDestroy(c->graph);
-    delete c;
+    // WDGS_LAZY_GRAPH_DESTROY=0: destroy here and now
+    static const bool lazy = !(std::getenv("WDGS_LAZY_GRAPH_DESTROY") && std::getenv("WDGS_LAZY_GRAPH_DESTROY")[0] == '0');
+    if (lazy && wdgs_device_alive(c->dev)) {
+        c->dev->dead_command_buffers.push_back(c);
+        if (c->dev->dead_command_buffers.size() > 64u) reap_command_buffers(c->dev, 32u);   // (a host that never submits again must not pile them up)
+    } else command_buffer_release(c);
     return WDGS_OK;
 }
 

@@ -65,6 +65,9 @@ struct wdgs_device {
     // forward passes whose PROJECTION the open recording consumes (wdgs_tiled_forward_encode_projected while capturing): handed to the
     // command buffer by wdgs_encoder_finish, checked and consumed by every wdgs_queue_submit of it
     std::vector<wdgs_tiled_forward*> capture_consumes;
+    // command buffers whose destruction is owed (wdgs_command_buffer_destroy): hipGraphExecDestroy costs ~170 us with the ROCm 7.2 runtime, and a
+    // densify event drops one per training view; wdgs_queue_submit pays one off per call, behind its launch, where the device has work to do meanwhile
+    std::vector<void*> dead_command_buffers;
     int num_cus = 256;
 };
 
@@ -139,6 +142,7 @@ static inline u32 ceil_div(u32 a, u32 b) { return (a + b - 1u) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream);
+void wdgs_free(void* p);   // the counterpart of wdgs_alloc (api.hip: freed blocks are kept by size class)
 // true between wdgs_device_create and wdgs_device_destroy (api.hip): destroy functions check it before touching op->dev
 bool wdgs_device_alive(const wdgs_device* d);
 

@@ -418,9 +418,9 @@ struct wdgs_densify_prune {
 };
 
 static void densify_free(wdgs_densify_prune* op) {
-    if (op->actions) (void)hipFree(op->actions);
-    if (op->counts) (void)hipFree(op->counts);
-    if (op->offsets) (void)hipFree(op->offsets);
+    if (op->actions) wdgs_free(op->actions);
+    if (op->counts) wdgs_free(op->counts);
+    if (op->offsets) wdgs_free(op->offsets);
     op->actions = op->counts = op->offsets = nullptr;
     scan_scratch_destroy(&op->scan);
     op->capacity = 0;
@@ -445,7 +445,7 @@ int wdgs_densify_prune_destroy(wdgs_densify_prune* op) {
     if (!op) return WDGS_OK;
     if (wdgs_device_alive(op->dev) && !op->dev->capturing) (void)wdgs_sync_lanes(op->dev);
     densify_free(op);
-    if (op->total) (void)hipFree(op->total);
+    if (op->total) wdgs_free(op->total);
     delete op;
     return WDGS_OK;
 }

@@ -171,7 +171,7 @@ int scan_scratch_create(ScanScratch* s, u32 max_elements) {
 }
 
 void scan_scratch_destroy(ScanScratch* s) {
-    if (s->block_sums) (void)hipFree(s->block_sums);
+    if (s->block_sums) wdgs_free(s->block_sums);
     s->block_sums = nullptr;
     s->capacity_blocks = 0;
 }

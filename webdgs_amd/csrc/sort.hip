@@ -588,11 +588,11 @@ int wdgs_sorter_create(wdgs_device* dev, uint32_t max_capacity, const void* stat
 int wdgs_sorter_destroy(wdgs_sorter* s) {
     if (!s) return WDGS_OK;
     for (int i = 0; i < 2; i++) {
-        if (s->keys[i]) (void)hipFree(s->keys[i]);
-        if (s->vals[i]) (void)hipFree(s->vals[i]);
+        if (s->keys[i]) wdgs_free(s->keys[i]);
+        if (s->vals[i]) wdgs_free(s->vals[i]);
     }
-    if (s->counts) (void)hipFree(s->counts);
-    if (s->totals) (void)hipFree(s->totals);
+    if (s->counts) wdgs_free(s->counts);
+    if (s->totals) wdgs_free(s->totals);
     delete s;
     return WDGS_OK;
 }
