@@ -88,6 +88,16 @@ static napi_value deviceSynchronize(napi_env env, napi_callback_info info) {  //
     WDGS_OK_OR_THROW(wdgs_device_synchronize((wdgs_device*)get_ptr(env, argv[0])));
     return js_undefined(env);
 }
+static napi_value deviceMemoryInfo(napi_env env, napi_callback_info info) {  // (device) -> {free, total, cached} in bytes (doubles: exact below 2^53)
+    ARGS(1);
+    size_t f = 0, t = 0, c = 0;
+    WDGS_OK_OR_THROW(wdgs_device_memory_info((wdgs_device*)get_ptr(env, argv[0]), &f, &t, &c));
+    napi_value o, v; napi_create_object(env, &o);
+    napi_create_double(env, (double)f, &v); set_prop(env, o, "free", v);
+    napi_create_double(env, (double)t, &v); set_prop(env, o, "total", v);
+    napi_create_double(env, (double)c, &v); set_prop(env, o, "cached", v);
+    return o;
+}
 // ---- buffers ----------------------------------------------------------------------------------------------------
 static napi_value bufferCreate(napi_env env, napi_callback_info info) {
     ARGS(2);
@@ -820,7 +830,7 @@ static napi_value commGroup(napi_env env, napi_callback_info info) {  // (end: 0
     } while (0)
 
 static napi_value Init(napi_env env, napi_value exports) {
-    EXPORT_FN(abiVersion); EXPORT_FN(deviceCreate); EXPORT_FN(deviceDestroy); EXPORT_FN(deviceSynchronize);
+    EXPORT_FN(abiVersion); EXPORT_FN(deviceCreate); EXPORT_FN(deviceDestroy); EXPORT_FN(deviceSynchronize); EXPORT_FN(deviceMemoryInfo);
     EXPORT_FN(bufferCreate); EXPORT_FN(bufferDestroy); EXPORT_FN(copyToDevice); EXPORT_FN(copyToHost);
     EXPORT_FN(tiledForwardCreate); EXPORT_FN(tiledForwardEncode); EXPORT_FN(tiledForwardSetViewport); EXPORT_FN(tiledForwardGetResources); EXPORT_FN(tiledForwardDestroy);
     EXPORT_FN(tiledRasterizerCreate); EXPORT_FN(tiledRasterizerEncode); EXPORT_FN(tiledRasterizerGet); EXPORT_FN(tiledRasterizerDestroy);

@@ -34,6 +34,8 @@ export class HipDevice {
   createPinnedArrayBuffer(byteLength: number): ArrayBuffer;
   readBufferAsync(buffer: HipBuffer, offset: number, pinned: ArrayBuffer, byteLength: number): Promise<ArrayBuffer>;
   synchronize(): void;
+  /** device.limits as far as memory goes (trainer.ts:147): bytes; `cached` is what the library's allocation cache holds. */
+  memoryInfo(): { free: number; total: number; cached: number };
   /** Lanes (include/webdgs.h): lane 0 is the device's stream, 1..3 internal ones; work on different lanes may overlap. */
   selectLane(lane: number): void;
   laneOrder(waiterLane: number, signalLane: number): void;

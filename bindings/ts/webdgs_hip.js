@@ -93,6 +93,8 @@ class HipDevice {                        // GPUDevice + GPUQueue
   }
   /** Blocking variant of onSubmittedWorkDone; also raises deferred capacity errors (code WDGS_E_CAPACITY). */
   synchronize() { addon.deviceSynchronize(this.handle); }
+  /** device.limits as far as memory goes (trainer.ts:147): { free, total, cached } in bytes; cached = what the library's allocation cache holds. */
+  memoryInfo() { return addon.deviceMemoryInfo(this.handle); }
   selectLane(lane) { addon.deviceSelectLane(this.handle, lane); }            // include/webdgs.h "Lanes"
   laneOrder(waiter, signal) { addon.deviceLaneOrder(this.handle, waiter, signal); }
   laneMark(lane, mark) { addon.deviceLaneMark(this.handle, lane, mark); }          // remembers the current end of `lane` in mark `mark` ...

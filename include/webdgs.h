@@ -71,6 +71,9 @@ int wdgs_device_create(int hip_ordinal, void* external_hip_stream, wdgs_device**
 int wdgs_device_destroy(wdgs_device* dev);
 /* queue.onSubmittedWorkDone(): waits for the stream, then reports deferred device-side errors. */
 int wdgs_device_synchronize(wdgs_device* dev);
+/* device.limits (trainer.ts:147 reads maxStorageBufferBindingSize to bound the densify rebuild): the device's memory in bytes.  free_bytes counts what
+ * the library's allocation cache holds (cached_bytes: freed blocks kept for the next allocation of their size class) as used.  Any pointer may be NULL. */
+int wdgs_device_memory_info(wdgs_device* dev, size_t* free_bytes, size_t* total_bytes, size_t* cached_bytes);
 /* Per-kernel hipEvent timing (the reference only has a wall-clock meter, trainer.ts:570,647-651). */
 int wdgs_device_set_profiling(wdgs_device* dev, int enabled);
 /* After a synchronize: copies up to `cap` records; returns the number of distinct kernels through *count. */

@@ -1,0 +1,7 @@
+#!/bin/bash
+set -e
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+O=gpurun_out; mkdir -p $O
+timeout -k 10 900 python3 -m pytest tests/test_gpu_lifecycle.py tests/test_gpu_napi.py -x -q -m gpu > $O/r06w_pytest.txt 2>&1 || { tail -40 $O/r06w_pytest.txt; exit 1; }
+tail -3 $O/r06w_pytest.txt
+node bindings/napi/lifecycle_run.js | tail -1

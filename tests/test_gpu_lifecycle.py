@@ -1,0 +1,73 @@
+"""GPU: lifetimes.  Trainers come and go on one device -- set up, trained across a densify rebuild, destroyed, ten times over, in both hosts -- and the
+device's free memory settles: nothing the library allocated for a trainer outlives it except what its allocation cache keeps for the next one
+(include/webdgs.h: wdgs_device_destroy empties the cache)."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+from webdgs_amd import ops, synth
+from webdgs_amd.trainer import Trainer
+
+import harness
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dataset(dev, cfg, g, sh, views):
+    tg, tsh = synth.make_target_scene(g, sh)
+    cams = synth.circle_cameras(cfg, views)
+    cameras, images = [], []
+    for c in cams:
+        tp = harness.HipPipeline(dev, cfg, tg, tsh, c)
+        tp.forward()
+        images.append(dict(texture=dev.bufferFrom(tp.rast.getOutputTextureView().read(np.uint8)), width=cfg.width, height=cfg.height))
+        cameras.append(dict(camera=c, width=cfg.width, height=cfg.height))
+        tp.destroy()
+    return cameras, images
+
+
+@pytest.mark.parametrize("vpr", [1, 3])
+def test_trainers_come_and_go_without_leaking(hip_device, vpr):
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=20000, width=320, height=240, s0=0.006)
+    g, sh, _ = harness.scene(cfg)
+    cameras, images = _dataset(dev, cfg, g, sh, 4)
+    dens = dict(schedule=dict(enabled=True, warmupIterations=10, interval=10, stopIterations=100), metricViews=3, cloneThresholdCount=5, splitScaleThreshold=0.03,
+                pruneOpacity=0.2, maxNewPointsPerStep=500)
+    free = []
+    for cycle in range(10):
+        t = Trainer(dev, seed=cycle, views_per_rank=vpr, pipeline_depth=2)
+        t.setDensifyPruneConfig(dens)
+        t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+        t.setDataset(cameras, images)
+        t.start()
+        for _ in range(25):
+            t.step()
+        t.drain()
+        dev.synchronize()
+        assert t.getLastDensifyPruneIteration() == 20 and t.getPointCount() != cfg.num_points
+        cloud = t.pointCloud
+        t.destroy()
+        cloud.gaussian_3d_buffer.destroy(); cloud.sh_buffer.destroy()
+        dev.synchronize()
+        free.append(dev.memoryInfo()["free"])
+    drift = (free[3] - free[-1]) / 2 ** 20
+    assert drift < 64.0, f"free device memory keeps falling from cycle to cycle: {[round(f / 2 ** 20) for f in free]} MiB"
+    info = dev.memoryInfo()
+    assert 0 < info["cached"] < info["total"] // 4 and info["free"] < info["total"], info
+
+
+def test_js_trainers_come_and_go_without_leaking():
+    node = shutil.which("node")
+    if not node or not os.path.exists(os.path.join(ROOT, "bindings", "napi", "webdgs_napi.node")):
+        pytest.skip("node or the N-API addon is not available")
+    r = subprocess.run([node, os.path.join(ROOT, "bindings", "napi", "lifecycle_run.js")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["cycles"] == 10 and all(out["densified"]), out
+    free = out["free_mib"]
+    assert free[3] - free[-1] < 64.0, f"free device memory keeps falling from cycle to cycle: {free} MiB"

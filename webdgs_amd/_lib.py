@@ -100,6 +100,7 @@ SIGNATURES = {
     "wdgs_device_create": (_I, [_I, _P, C.POINTER(_P)]),
     "wdgs_device_destroy": (_I, [_P]),
     "wdgs_device_synchronize": (_I, [_P]),
+    "wdgs_device_memory_info": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "wdgs_device_set_profiling": (_I, [_P, _I]),
     "wdgs_device_get_kernel_times": (_I, [_P, C.POINTER(KernelTime), _U, C.POINTER(_U)]),
     "wdgs_device_reset_kernel_times": (_I, [_P]),

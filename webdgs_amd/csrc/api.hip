@@ -440,6 +440,21 @@ int wdgs_queue_wait(wdgs_device* d, uint64_t ticket) {
     return deferred_checks(d);
 }
 
+int wdgs_device_memory_info(wdgs_device* d, size_t* free_bytes, size_t* total_bytes, size_t* cached_bytes) {
+    WDGS_REQUIRE(d, WDGS_E_INVALID, "wdgs_device_memory_info: null device");
+    size_t f = 0, t = 0;
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    WDGS_CHECK_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (cached_bytes) {
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        size_t c = 0;
+        for (const auto& kv : g_cached_blocks) if (kv.second.device == d->ordinal) c += kv.first;
+        *cached_bytes = c;
+    }
+    return WDGS_OK;
+}
 static void reap_command_buffers(wdgs_device* d, size_t at_most);   // (defined with the command buffers, below)
 int wdgs_device_destroy(wdgs_device* d) {
     if (!d) return WDGS_OK;

@@ -210,6 +210,12 @@ class HipDevice:
         check(self.lib.wdgs_device_synchronize(self.handle))
         self._keepalive.clear()
 
+    def memoryInfo(self) -> dict:
+        """``device.limits`` as far as memory goes (trainer.ts:147): bytes free / total on the device, and what the library's allocation cache holds."""
+        f, t, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        check(self.lib.wdgs_device_memory_info(self.handle, C.byref(f), C.byref(t), C.byref(c)))
+        return dict(free=int(f.value), total=int(t.value), cached=int(c.value))
+
     def selectLane(self, lane: int) -> None:
         """Directs every later encode / submit to lane 0 (this device's stream) or an internal one, 1..MAX_LANES-1 (``include/webdgs.h``: lanes)."""
         check(self.lib.wdgs_device_select_lane(self.handle, int(lane)))
