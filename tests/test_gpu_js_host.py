@@ -303,6 +303,88 @@ def test_tile_entry_lists_grow_after_an_overflow_in_both_hosts_alike(hip_device,
         t.destroy()
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+def test_a_live_trainer_follows_its_host_in_both_hosts_alike(hip_device, orc, tmp_path, depth):
+    """What a host changes under a running Trainer -- loss weights, learning rates, a dataset of another image size, stop / start, the densify
+    schedule switched on -- invalidates recordings and passes in different ways in the two hosts (the JS Trainer rebuilds its backward pass for new
+    loss weights, the Python one updates it in place ...): same sequence, same view draws, clouds and optimizer state sha256-equal."""
+    import hashlib
+    _need_node()
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=5000, width=128, height=96, s0=0.01)
+    g, sh, _ = harness.scene(cfg)
+    tg, tsh = synth.make_target_scene(g, sh)
+    views, size_a, size_b = 4, (128, 96), (96, 64)
+
+    def dataset(w, h):
+        c = synth.SceneConfig(cfg.config_id, cfg.num_points, w, h, cfg.sh_deg, cfg.fy * w / cfg.width, cfg.s0, "views")
+        cams = synth.circle_cameras(c, views)
+        st, ti = synth.render_settings(c), synth.tile_info(w, h, 0)
+        return cams, [orc.forward(tg, tsh, cams[i], st, ti)["rgba8"] for i in range(views)]
+
+    cams_a, imgs_a = dataset(*size_a)
+    cams_b, imgs_b = dataset(*size_b)
+    dens = dict(schedule=dict(enabled=True, warmupIterations=4, interval=50, stopIterations=40), metricViews=3, metricDownscale=2, metricThreshold=0.5,
+                cloneThresholdCount=5, splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300, maxBufferBytes=128 * 1024 * 1024)
+    rng = np.random.default_rng(11)
+    # 4 + 3 + 3 + 3 steps, stop / start, 2 steps, schedule on, 6 steps: the restarted count reaches 4 on its 4th step -> one event of 3 metric views
+    draws = [int(v) for v in rng.integers(views, size=13 + 2)] + [int(v) for v in rng.integers(views, size=2)] + [int(v) for v in rng.integers(views, size=3)] + \
+            [int(v) for v in rng.integers(views, size=4)]
+    g.tofile(tmp_path / "gaussians.bin"); sh.tofile(tmp_path / "sh.bin")
+    for tag, cams, imgs in (("a", cams_a, imgs_a), ("b", cams_b, imgs_b)):
+        np.ascontiguousarray(cams, np.float32).tofile(tmp_path / f"cameras_{tag}.bin")
+        np.stack(imgs).tofile(tmp_path / f"images_{tag}.bin")
+    (tmp_path / "meta.json").write_text(json.dumps(dict(num_points=cfg.num_points, sh_deg=cfg.sh_deg, views=views, a=size_a, b=size_b, draws=draws, densify=dens,
+                                                        pipeline_depth=depth)))
+    r = subprocess.run([NODE, os.path.join(ROOT, "bindings", "napi", "host_changes_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"exit code {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+
+    t = Trainer(dev, seed=0, pipeline_depth=depth)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    sets = {}
+    for tag, cams, imgs, (w, h) in (("a", cams_a, imgs_a, size_a), ("b", cams_b, imgs_b, size_b)):
+        sets[tag] = ([dict(camera=cams[i], width=w, height=h) for i in range(views)], [dict(texture=dev.bufferFrom(imgs[i]), width=w, height=h) for i in range(views)])
+    t.setDataset(*sets["a"])
+    t.start()
+    t._rng = _FixedViews(draws)
+    seen = []
+    try:
+        def steps(n):
+            for _ in range(n):
+                t.step()
+        steps(4)
+        t.setTrainingConfig(dict(lambda_l1=0.6, lambda_dssim=0.4))
+        steps(3)
+        hp = t.getOptimizerHyperparameters()
+        t.setOptimizerHyperparameters(dict(lr_pos=hp["lr_pos"] * 2, lr_color=hp["lr_color"] * 0.5))
+        steps(3)
+        t.setDataset(*sets["b"])
+        steps(3)
+        seen.append(t.getIteration())
+        t.stop(); t.start()
+        seen.append(t.getIteration())
+        steps(2)
+        t.setDensifyPruneConfig(dens)
+        steps(6)
+        t.drain()
+        dev.synchronize()
+        assert t._rng.i == len(draws), "the schedule of view draws was used up exactly"
+        n = t.getPointCount()
+        assert (out["num_points"], out["iteration"], out["iterations_seen"], out["last_densify"]) == (n, t.getIteration(), seen, t.getLastDensifyPruneIteration()), out
+        assert n != cfg.num_points and t.getLastDensifyPruneIteration() == 4, "the schedule switched on mid-run fired"
+        assert out["training_config"] == t.getTrainingConfig() and out["lr_pos"] == pytest.approx(t.getOptimizerHyperparameters()["lr_pos"], rel=1e-7)
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        assert out["hashes"]["gaussians"] == sha(t.pointCloud.gaussian_3d_buffer.read(np.uint32)[: n * 6]), "node vs python: gaussians"
+        assert out["hashes"]["sh"] == sha(t.pointCloud.sh_buffer.read(np.uint32)[: n * 24]), "node vs python: sh"
+        words = dict(optPosBuffer=12, optRotBuffer=12, optScaleBuffer=12, optOpacityBuffer=3, paramSH=48, stateSH=96)
+        for k, b in t.optimizer.getStateBuffers().items():
+            assert out["hashes"][f"state_{k}"] == sha(b.read(np.uint32)[: n * words[k]]), f"node vs python: state {k}"
+    finally:
+        t.destroy()
+
+
 def test_bench_js_prints_its_line(tmp_path):
     _need_node()
     for extra in ([], ["--views-per-step", "3", "--lanes", "2", "--views", "4"]):
