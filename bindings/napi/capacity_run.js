@@ -1,4 +1,4 @@
-// node bindings/napi/capacity_run.js <depth> -- a cloud of few, large splats outruns the tile-entry lists the library sized for it: the JS Trainer
+// node bindings/napi/capacity_run.js <depth> [views per step] -- a cloud of few, large splats outruns the tile-entry lists the library sized for it: the JS Trainer
 // (maxTileEntries left at 0) doubles them, warns and goes on training (tests/test_gpu_js_host.py compares the outcome with the Python host's).
 'use strict';
 const path = require('path');
@@ -8,7 +8,7 @@ const synth = require(path.join(__dirname, '..', 'ts', 'synth.js'));
 const { Trainer } = require(path.join(__dirname, '..', 'ts', 'trainer.js'));
 
 async function main() {
-  const depth = Number(process.argv[2] || 1);
+  const depth = Number(process.argv[2] || 1), vpr = Number(process.argv[3] || 1);
   const cfg = { config_id: 2, num_points: 6000, width: 512, height: 384, sh_deg: 1, fy: 550.0, s0: 0.2, name: 'few-large-splats' };
   const dev = new hip.HipDevice(0);
   const made = synth.makeGaussians(cfg), g = made.gaussians, sh = made.sh;
@@ -19,12 +19,12 @@ async function main() {
   const images = cams.map(() => ({ texture: upload(black), width: cfg.width, height: cfg.height }));
   const warnings = [];
   const warn = console.warn; console.warn = (m) => warnings.push(String(m));
-  const t = new Trainer(dev, undefined, { pipelineDepth: depth });
+  const t = new Trainer(dev, undefined, { pipelineDepth: depth, viewsPerStep: vpr, lanes: vpr > 1 ? 2 : 0 });
   t.setDensifyPruneConfig({ schedule: { enabled: false } });
   t.setPointCloud(pc);
   t.setDataset(cams.map((c) => ({ camera: c, width: cfg.width, height: cfg.height })), images);
   t.start();
-  for (let i = 0; i < 8; i++) await t.stepViews([i % 2]);
+  for (let i = 0; i < 8; i++) { const ids = []; for (let k = 0; k < vpr; k++) ids.push((i + k) % 2); await t.stepViews(ids); }
   t.drain(); dev.synchronize();
   console.warn = warn;
   const cap = t.forwardPass.getResources().maxTileEntries;

@@ -264,14 +264,14 @@ def test_keep_gradients_switch_is_obeyed_after_set_point_cloud(hip_device, orc):
         t.destroy()
 
 
-@pytest.mark.parametrize("depth", [1, 2])
-def test_tile_entry_lists_grow_after_an_overflow_in_both_hosts_alike(hip_device, depth):
+@pytest.mark.parametrize("depth,vpr", [(1, 1), (2, 1), (1, 3), (2, 3)])
+def test_tile_entry_lists_grow_after_an_overflow_in_both_hosts_alike(hip_device, depth, vpr):
     """A cloud of few, large splats outruns the tile-entry lists the library sized for it (what a long run of the default schedule arrives at).
     Both Trainers double the lists, warn and go on; the steps lost to the overflow are the same ones, so the clouds end up byte-identical."""
     import hashlib
     import warnings
     _need_node()
-    r = subprocess.run([NODE, os.path.join(ROOT, "bindings", "napi", "capacity_run.js"), str(depth)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([NODE, os.path.join(ROOT, "bindings", "napi", "capacity_run.js"), str(depth), str(vpr)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["grown"] >= 1 and out["cap"] >= out["needed"] > (1 << 20), out
@@ -281,7 +281,7 @@ def test_tile_entry_lists_grow_after_an_overflow_in_both_hosts_alike(hip_device,
     g, sh = synth.make_gaussians(cfg)
     cams = synth.circle_cameras(cfg, 2)
     images = [dict(texture=dev.bufferFrom(np.zeros((cfg.height, cfg.width, 4), np.uint8)), width=cfg.width, height=cfg.height) for _ in cams]
-    t = Trainer(dev, seed=0, pipeline_depth=depth)
+    t = Trainer(dev, seed=0, pipeline_depth=depth, views_per_rank=vpr, overlap_views=2 if vpr > 1 else None)
     t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset([dict(camera=c, width=cfg.width, height=cfg.height) for c in cams], images)
@@ -290,7 +290,7 @@ def test_tile_entry_lists_grow_after_an_overflow_in_both_hosts_alike(hip_device,
         with warnings.catch_warnings(record=True) as seen:
             warnings.simplefilter("always")
             for i in range(8):
-                t.step([i % 2])
+                t.step([(i + k) % 2 for k in range(vpr)])
             t.drain()
             dev.synchronize()
         grown = sum("tile-entry lists grown" in str(w.message) for w in seen)
