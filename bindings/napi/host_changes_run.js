@@ -48,13 +48,22 @@ async function main() {
   t.setDensifyPruneConfig(meta.densify);
   await steps(6);
   t.drain(); dev.synchronize();
-  if (drawn !== draws.length) throw new Error(`drew ${drawn} views, schedule has ${draws.length}`);
   const n = t.getPointCount();
   const sha = (buf, bytes) => crypto.createHash('sha256').update(Buffer.from(dev.readBuffer(buf, bytes))).digest('hex');
   const st = t.optimizer.getStateBuffers(), rowBytes = { optPosBuffer: 48, optRotBuffer: 48, optScaleBuffer: 48, optOpacityBuffer: 12, paramSH: 192, stateSH: 384 };
   const hashes = { gaussians: sha(t.pointCloud.gaussian_3d_buffer, n * 24), sh: sha(t.pointCloud.sh_buffer, n * 96) };
   for (const k of Object.keys(rowBytes)) hashes[`state_${k}`] = sha(st[k], n * rowBytes[k]);
-  console.log(JSON.stringify({ num_points: n, iteration: t.getIteration(), iterations_seen: log, last_densify: t.getLastDensifyPruneIteration(), hashes,
+  // the debug helper of trainer.ts:194 -- a swap to a zero-filled cloud of another size, applied by the host at a step boundary
+  const before = { iteration: t.getIteration(), last_densify: t.getLastDensifyPruneIteration() };
+  t.requestResizeTo(3000);
+  const req = t.consumePointCloudSwapRequest();
+  t.applyPointCloudSwap(req);
+  await steps(2);
+  t.drain(); dev.synchronize();
+  if (drawn !== draws.length) throw new Error(`drew ${drawn} views, schedule has ${draws.length}`);
+  const resized = { num_points: t.getPointCount(), iteration: t.getIteration(), gaussians: sha(t.pointCloud.gaussian_3d_buffer, 3000 * 24), sh: sha(t.pointCloud.sh_buffer, 3000 * 96),
+    stateSH: sha(t.optimizer.getStateBuffers().stateSH, 3000 * 384) };
+  console.log(JSON.stringify({ resized, num_points: n, iteration: before.iteration, iterations_seen: log, last_densify: before.last_densify, hashes,
     training_config: t.getTrainingConfig(), lr_pos: t.getOptimizerHyperparameters().lr_pos }));
   const last = t.pointCloud; t.destroy(); last.gaussian_3d_buffer.destroy(); last.sh_buffer.destroy();
   for (const d of [a, b]) for (const im of d.images) im.texture.destroy();

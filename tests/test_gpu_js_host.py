@@ -329,7 +329,7 @@ def test_a_live_trainer_follows_its_host_in_both_hosts_alike(hip_device, orc, tm
     rng = np.random.default_rng(11)
     # 4 + 3 + 3 + 3 steps, stop / start, 2 steps, schedule on, 6 steps: the restarted count reaches 4 on its 4th step -> one event of 3 metric views
     draws = [int(v) for v in rng.integers(views, size=13 + 2)] + [int(v) for v in rng.integers(views, size=2)] + [int(v) for v in rng.integers(views, size=3)] + \
-            [int(v) for v in rng.integers(views, size=4)]
+            [int(v) for v in rng.integers(views, size=4)] + [int(v) for v in rng.integers(views, size=2)]   # (+ 2 steps on the resized cloud)
     g.tofile(tmp_path / "gaussians.bin"); sh.tofile(tmp_path / "sh.bin")
     for tag, cams, imgs in (("a", cams_a, imgs_a), ("b", cams_b, imgs_b)):
         np.ascontiguousarray(cams, np.float32).tofile(tmp_path / f"cameras_{tag}.bin")
@@ -370,7 +370,7 @@ def test_a_live_trainer_follows_its_host_in_both_hosts_alike(hip_device, orc, tm
         steps(6)
         t.drain()
         dev.synchronize()
-        assert t._rng.i == len(draws), "the schedule of view draws was used up exactly"
+        assert t._rng.i == len(draws) - 2
         n = t.getPointCount()
         assert (out["num_points"], out["iteration"], out["iterations_seen"], out["last_densify"]) == (n, t.getIteration(), seen, t.getLastDensifyPruneIteration()), out
         assert n != cfg.num_points and t.getLastDensifyPruneIteration() == 4, "the schedule switched on mid-run fired"
@@ -381,6 +381,17 @@ def test_a_live_trainer_follows_its_host_in_both_hosts_alike(hip_device, orc, tm
         words = dict(optPosBuffer=12, optRotBuffer=12, optScaleBuffer=12, optOpacityBuffer=3, paramSH=48, stateSH=96)
         for k, b in t.optimizer.getStateBuffers().items():
             assert out["hashes"][f"state_{k}"] == sha(b.read(np.uint32)[: n * words[k]]), f"node vs python: state {k}"
+        # the debug helper of trainer.ts:194: a swap to a zero-filled cloud of another size, applied by the host at a step boundary; two more steps
+        t.requestResizeTo(3000)
+        t.applyPointCloudSwap(t.consumePointCloudSwapRequest())
+        steps(2)
+        t.drain()
+        dev.synchronize()
+        assert t._rng.i == len(draws), "the schedule of view draws was used up exactly"
+        rz = out["resized"]
+        assert (rz["num_points"], rz["iteration"]) == (t.getPointCount(), t.getIteration()) == (3000, 10)
+        assert rz["gaussians"] == sha(t.pointCloud.gaussian_3d_buffer.read(np.uint32)[: 3000 * 6]) and rz["sh"] == sha(t.pointCloud.sh_buffer.read(np.uint32)[: 3000 * 24])
+        assert rz["stateSH"] == sha(t.optimizer.getStateBuffers()["stateSH"].read(np.uint32)[: 3000 * 96])
     finally:
         t.destroy()
 
