@@ -18,14 +18,36 @@ def main():
     vpr = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     rank, world, _ = parallel.init_from_env()
     dev = ops.HipDevice(int(os.environ.get("WDGS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
-    cfg, g, sh, cameras, images = dp_common.dataset(dev)
+    overflow = os.environ.get("WDGS_DP_TEST_OVERFLOW") == "1"
+    if overflow:
+        # few, large splats on 768 tiles: the lists the library sizes for this cloud (2^20 entries) overflow under view 0; view 1 looks at nothing.
+        # Rank 0 always draws view 0, rank 1 view 1: only ONE rank overflows, both must skip the step, grow their lists and stay replicas.
+        import warnings
+        from webdgs_amd import synth
+        warnings.simplefilter("always")
+        cfg = synth.SceneConfig(2, 6000, 512, 384, 1, 550.0, 0.2, "few-large-splats")
+        g, sh = synth.make_gaussians(cfg)
+        away = np.eye(4, dtype=np.float64)
+        away[2, 3] = -100.0  # the camera 100 units down the z axis, past the whole scene
+        cams = [synth.circle_cameras(cfg, 1)[0], synth.camera_block(away, cfg.width, cfg.height, cfg.fy)]
+        black = np.zeros((cfg.height, cfg.width, 4), np.uint8)
+        cameras = [dict(camera=c, width=cfg.width, height=cfg.height) for c in cams]
+        images = [dict(texture=dev.bufferFrom(black), width=cfg.width, height=cfg.height) for _ in cams]
+    else:
+        cfg, g, sh, cameras, images = dp_common.dataset(dev)
     t = Trainer(dev, seed=11, world_size=world, rank=rank, views_per_rank=vpr, use_command_buffers=use_cb)
     t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
     t.start()
     import torch
-    for i, ids in enumerate(dp_common.view_schedule(steps, world, vpr)):
+    schedule = [[r % 2 for r in range(world * vpr)] for _ in range(steps)] if overflow else dp_common.view_schedule(steps, world, vpr)
+    grown = []
+    if overflow:
+        import warnings
+        _show = warnings.showwarning
+        warnings.showwarning = lambda message, *a, **k: (grown.append(str(message)), _show(message, *a, **k))
+    for i, ids in enumerate(schedule):
         if i == 3:  # ranks in lock-step from here on: the condition under which an unfenced exchange was overtaken by Adam
             torch.cuda.synchronize()
             parallel.barrier()
@@ -41,7 +63,8 @@ def main():
     st = {k: b.read(np.uint32) for k, b in t.optimizer.getStateBuffers().items()}
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gaussians=t.pointCloud.gaussian_3d_buffer.read(np.uint32),
              sh=t.pointCloud.sh_buffer.read(np.uint32), iteration=np.array([t.optimizer.getIteration()]), own=np.array([own_first, own_count]),
-             stale_pos=stale, **{"state_" + k: v for k, v in st.items()})
+             stale_pos=stale, grown=np.array([sum("tile-entry lists grown" in m for m in grown)]), host_iteration=np.array([t.getIteration()]),
+             cap=np.array([int(t.forwardPass.getResources()["maxTileEntries"])]), **{"state_" + k: v for k, v in st.items()})
     parallel.barrier()
     t.destroy()
     dev.destroy()

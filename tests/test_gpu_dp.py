@@ -243,3 +243,28 @@ def test_a_rank_with_an_empty_slice(tmp_path):
     assert_bits_equal(ranks[0]["sh"], ranks[1]["sh"], "replica SH rows with an empty slice on rank 1")
     for k in ("optPosBuffer", "stateSH"):
         assert_bits_equal(ranks[0]["state_" + k], ranks[1]["state_" + k], f"gathered state {k} with an empty slice on rank 1")
+
+
+def test_one_rank_overflows_both_grow_their_lists_and_stay_replicas(tmp_path):
+    """Two ranks over gloo on the test box's one GPU; rank 0's view needs more tile entries than the lists the library sized (2^20), rank 1's view sees
+    nothing.  The overflow word travels with the exchange, so BOTH skip the step; rank 0 reports its own overflow, rank 1 the step skipped on every
+    rank; both Trainers grow their lists and go on -- and the replicas stay bit-identical, with the same count of iterations."""
+    env = dict(os.environ, WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_DP_TEST_OVERFLOW="1")
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), "8", "1", "1"], env))
+    assert r.returncode == 0, _verdict(r)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    assert int(ranks[0]["grown"][0]) >= 1 and int(ranks[1]["grown"][0]) >= 1, "both ranks grew their lists"
+    assert int(ranks[0]["cap"][0]) > (1 << 20) and int(ranks[1]["cap"][0]) > (1 << 20)
+    assert int(ranks[0]["host_iteration"][0]) == int(ranks[1]["host_iteration"][0]) and int(ranks[0]["iteration"][0]) == int(ranks[1]["iteration"][0])
+    assert_bits_equal(ranks[0]["gaussians"], ranks[1]["gaussians"], "replicas after one rank's overflow")
+    assert_bits_equal(ranks[0]["sh"], ranks[1]["sh"], "replica SH rows after one rank's overflow")
+    for k in ("optPosBuffer", "stateSH"):
+        assert_bits_equal(ranks[0]["state_" + k], ranks[1]["state_" + k], f"gathered state {k} after one rank's overflow")
+    g0 = synth_initial_gaussians()
+    assert (ranks[0]["gaussians"][: g0.size] != g0).any(), "training went on after the growth"
+
+
+def synth_initial_gaussians():
+    from webdgs_amd import synth
+    return synth.make_gaussians(synth.SceneConfig(2, 6000, 512, 384, 1, 550.0, 0.2, "few-large-splats"))[0].reshape(-1)
