@@ -1,0 +1,6 @@
+#!/bin/bash
+set -e
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+O=gpurun_out; mkdir -p $O
+timeout -k 10 900 python3 -m pytest tests/test_gpu_lifecycle.py tests/test_gpu_pipeline.py tests/test_gpu_ops.py -x -q -m gpu > $O/r07b_pytest.txt 2>&1 || { tail -40 $O/r07b_pytest.txt; exit 1; }
+tail -3 $O/r07b_pytest.txt

@@ -71,3 +71,35 @@ def test_js_trainers_come_and_go_without_leaking():
     assert out["cycles"] == 10 and all(out["densified"]), out
     free = out["free_mib"]
     assert free[3] - free[-1] < 64.0, f"free device memory keeps falling from cycle to cycle: {free} MiB"
+
+
+def test_freed_blocks_are_kept_by_size_class_and_handed_out_again(hip_device):
+    """``wdgs_alloc`` / ``wdgs_free`` (csrc/api.hip): a freed block waits, by size class, for the next allocation of its class -- a cloud resized by a few
+    per cent gets its old blocks back -- and ``memoryInfo()`` counts what waits as ``cached``.  (Through ``wdgs_buffer_create``: the JS host's
+    ``createBuffer``; the Python host's own buffers are torch tensors.)"""
+    import ctypes as C
+    from webdgs_amd._lib import check
+    dev = hip_device
+    lib = dev.lib
+
+    def create(size):
+        h = C.c_void_p()
+        check(lib.wdgs_buffer_create(dev.handle, C.c_size_t(size), C.byref(h)))
+        return h, int(lib.wdgs_buffer_ptr(h))
+
+    dev.synchronize()
+    a, pa = create(1_000_000)
+    base = dev.memoryInfo()["cached"]   # (with `a` out: it may itself have come from the cache)
+    check(lib.wdgs_copy_to_device(dev.handle, C.c_void_p(pa), np.full(250_000, 7, np.uint32).ctypes.data_as(C.c_void_p), C.c_size_t(1_000_000)))
+    dev.synchronize()
+    check(lib.wdgs_buffer_destroy(a))
+    assert dev.memoryInfo()["cached"] == base + (1 << 20), "1 000 000 bytes wait in the 2^20 class"
+    b, pb = create(1_040_000)   # the same class
+    assert dev.memoryInfo()["cached"] == base, "taken from the class again (this block or another one waiting there)"
+    back = np.empty(260_000, np.uint32)
+    check(lib.wdgs_copy_to_host(dev.handle, back.ctypes.data_as(C.c_void_p), C.c_void_p(pb), C.c_size_t(1_040_000)))
+    assert not back.any(), "a block handed out again is zeroed like a new one"
+    c, pc = create(1_200_000)   # the next class
+    assert pc not in (pa, pb)
+    check(lib.wdgs_buffer_destroy(b)); check(lib.wdgs_buffer_destroy(c))
+    dev.synchronize()

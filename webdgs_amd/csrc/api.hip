@@ -123,11 +123,14 @@ int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream) {
         int device = 0;
         WDGS_CHECK_HIP(hipGetDevice(&device));
         bool need_sync = false;
+        // (an allocation while `stream` records -- relaxed capture allows hipMalloc -- cannot synchronise the device: it only takes blocks that need no wait)
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        const bool recording = stream && hipStreamIsCapturing(stream, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
         {
             std::lock_guard<std::mutex> lock(g_alloc_mutex);
             auto range = g_cached_blocks.equal_range(rounded);
             for (auto it = range.first; it != range.second; ++it)
-                if (it->second.device == device) {
+                if (it->second.device == device && !(recording && it->second.freed_epoch == g_sync_epoch)) {
                     *p = it->second.p;
                     need_sync = it->second.freed_epoch == g_sync_epoch;
                     g_cached_bytes -= rounded;
