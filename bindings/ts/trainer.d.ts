@@ -36,6 +36,13 @@ export class Trainer {
   tileEntries(): number;
   /** Doubles the library-sized tile-entry lists after a WDGS_E_CAPACITY report and rebuilds the passes; false when the caller pinned maxTileEntries. */
   growTileEntryCapacity(error: Error): boolean;
+  /** Entries needed by this trainer's passes among those a capacity report names; [] if it names only other owners' passes; null if it names none. */
+  ownOverflow(error: Error): number[] | null;
+  /** true (after one console.warn) for a capacity report about passes this trainer does not own (a Viewer on the same device). */
+  notOurs(error: Error): boolean;
+  /** device.queue.wait / device.synchronize with other owners' capacity reports filtered out. */
+  wait(ticket: number): void;
+  synchronize(): void;
   /** Records every view's command buffers up front; the number of steps taken depends on the dataset size only. */
   warmupCommandBuffers(): Promise<number>;
   /** Awaits every step still in flight (pipelineDepth > 1). */

@@ -102,7 +102,7 @@ class Trainer {
   forwardPasses() { return [this.forwardPass, this.metricsForwardPass].concat(this.moreOpSets.map((m) => m[0]), this.moreMetricSets.map((m) => m[0])).filter((p) => p); }
   applyPointCloudSwap(request) {   // trainer.ts:201-237
     this.drain();
-    this.device.synchronize();
+    this.synchronize();
     const oldParams = this.optimizer ? this.optimizer.getHyperparameters() : null;
     this.invalidateCommandBuffers();
     if (this.optimizer) { this.optimizer.destroy(); this.optimizer = null; }
@@ -199,7 +199,7 @@ class Trainer {
     let deferred = null;
     if (this.tickets.length && this.device.handle !== null) {
       this.tickets = [];
-      try { this.device.synchronize(); } catch (e) { deferred = e; }
+      try { this.synchronize(); } catch (e) { deferred = e; }
     }
     for (const c of this.commandBuffers.values()) c.destroy();
     this.commandBuffers.clear();
@@ -339,10 +339,10 @@ class Trainer {
 
   growTileEntryCapacity(error) {
     if (this.maxTileEntries !== 0 || this.device.handle === null) return false;
+    const mine = this.ownOverflow(error) || [];   // (a report about other owners' passes only never gets here: wait / synchronize)
     let now = Math.max(this.grownTileEntries, 1 << 20);
     for (const fw of this.forwardPasses()) now = Math.max(now, fw.getResources().maxTileEntries);
-    const m = /(\d+) entries needed/.exec(String(error && error.message));
-    const next = Math.min(Math.max(2 * now, m ? Math.floor(Number(m[1]) * 1.5) : 0), 0xFFFFF000);
+    const next = Math.min(Math.max(2 * now, mine.length ? Math.floor(Math.max.apply(null, mine) * 1.5) : 0), 0xFFFFF000);
     if (next <= now) return false;
     console.warn(`tile-entry lists grown from ${now} to ${next} entries after an overflow (${error.message}); the step that overflowed was skipped`);
     this.grownTileEntries = next;
@@ -405,19 +405,41 @@ class Trainer {
     if (this.iteration >= this.maxIterations) this.stop();
   }
 
+  /** The entries needed by THIS trainer's passes among those a capacity report names (csrc/api.hip: deferred_checks names every pass that overflowed),
+   *  [] if it names only other owners' passes, null if it names none (a step skipped on every rank). */
+  ownOverflow(error) {
+    const named = [], re = /(\d+) entries needed, max_tile_entries = \d+ \(forward pass (0x[0-9a-fA-F]+)\)/g, text = String(error && error.message);
+    for (let m = re.exec(text); m; m = re.exec(text)) named.push([Number(m[1]), BigInt(m[2])]);
+    if (!named.length) return null;
+    const own = this.forwardPasses().map((fw) => BigInt(fw.handle));
+    return named.filter((n) => own.some((h) => h === n[1])).map((n) => n[0]);
+  }
+  /** true (after saying so once) for a capacity report about passes this trainer does not own -- a Viewer rendering the same cloud on this device: the
+   *  report is device-wide, whoever waits first gets it, and it is the pass's owner who has to enlarge its lists. */
+  notOurs(error) {
+    if (!(error && error.code === 'WDGS_E_CAPACITY')) return false;
+    const mine = this.ownOverflow(error);
+    if (mine === null || mine.length) return false;
+    if (!this.foreignOverflowWarned) console.warn(`a forward pass that is not this trainer's overflowed its tile-entry lists (${error.message}); its owner has to enlarge them`);
+    this.foreignOverflowWarned = true;
+    return true;
+  }
+  wait(ticket) { try { this.device.queue.wait(ticket); } catch (e) { if (!this.notOurs(e)) throw e; } }
+  synchronize() { try { this.device.synchronize(); } catch (e) { if (!this.notOurs(e)) throw e; } }
+
   /** `await onSubmittedWorkDone()` (trainer.ts:639-645) + the deferred capacity check.  Depth 1: this step's own completion, through the
    *  Promise, as the reference awaits it.  Depth d > 1: a ticket for this step is kept and the step d - 1 submissions ago is awaited. */
   async finishStep() {
     if (this.pipelineDepth <= 1) {
       await this.device.queue.onSubmittedWorkDone();
-      this.device.synchronize();   // deferred device-side checks (tile-entry overflow) surface here as a thrown Error
+      this.synchronize();   // deferred device-side checks (tile-entry overflow) surface here as a thrown Error
       return;
     }
     this.tickets.push(this.device.queue.mark());
-    while (this.tickets.length >= this.pipelineDepth) this.device.queue.wait(this.tickets.shift());
+    while (this.tickets.length >= this.pipelineDepth) this.wait(this.tickets.shift());
   }
   /** Awaits every step still in flight (a no-op at pipelineDepth 1). */
-  drain() { const t = this.tickets; this.tickets = []; for (const ticket of t) this.device.queue.wait(ticket); }
+  drain() { const t = this.tickets; this.tickets = []; for (const ticket of t) this.wait(ticket); }
 
   applyGradientOutput() {
     const want = this.keepGradients || !this.fuseGeometryAdam;

@@ -120,6 +120,54 @@ def test_lists_sized_by_the_library_grow_after_an_overflow(hip_device, depth):
         t.destroy()
 
 
+def test_another_owners_overflow_is_not_the_trainers_to_answer(hip_device):
+    """A Viewer renders the cloud a Trainer trains, through a forward pass of its own whose lists overflow at every frame (as they do beside a
+    long run of the default schedule).  The device-wide report names the passes; the Trainer grows ITS lists once, for its own overflow, says
+    once that someone else's pass overflowed, and is not driven to ever larger lists by frames it does not own."""
+    import warnings
+    from webdgs_amd import synth
+    from webdgs_amd.viewer import Viewer
+    dev = hip_device
+    cfg = synth.SceneConfig(2, 6000, 512, 384, 1, 550.0, 0.2, "few-large-splats")
+    g, sh = synth.make_gaussians(cfg)
+    cams = synth.circle_cameras(cfg, 2)
+    images = [dict(texture=dev.bufferFrom(np.zeros((cfg.height, cfg.width, 4), np.uint8)), width=cfg.width, height=cfg.height) for _ in cams]
+    pc = ops.createPointCloud(dev, g, sh, cfg.sh_deg)
+    v = Viewer(dev, cfg.width, cfg.height)
+    v.setCamera(cams[0])
+    v.setPointCloud(pc)
+    v.setRenderMode("gaussian")
+    t = Trainer(dev, seed=9, pipeline_depth=2)
+    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    t.setPointCloud(pc)
+    t.setDataset([dict(camera=c, width=cfg.width, height=cfg.height) for c in cams], images)
+    t.start()
+    try:
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            for i in range(12):
+                v.render(None)
+                t.step([i % 2])
+            t.drain()
+            try:
+                dev.synchronize()
+            except ops.CapacityError:
+                pass  # (the last frame's report, which nobody has taken yet)
+        texts = [str(w.message) for w in seen if issubclass(w.category, RuntimeWarning)]
+        grown = [m for m in texts if "tile-entry lists grown" in m]
+        foreign = [m for m in texts if "not this trainer's" in m]
+        assert len(grown) == 1 and len(foreign) == 1, texts
+        cap = int(t.forwardPass.getResources()["maxTileEntries"])
+        assert (1 << 20) < cap <= (4 << 20), cap
+        assert int(v.getForwardPass().getResources()["maxTileEntries"]) <= (1 << 20) + 4096, "the viewer's lists are its owner's business"
+        assert t.getIteration() >= 9
+    finally:
+        t.pointCloud = None  # (the cloud is shared: destroyed below, once)
+        t.destroy()
+        v.destroy()
+        pc.gaussian_3d_buffer.destroy(); pc.sh_buffer.destroy()
+
+
 @pytest.mark.parametrize("depth", [1, 2])
 def test_kernel_times_are_collected_by_ticket_waits(hip_device, depth):
     """bench.py's per-kernel leg: eager steps with an event pair around every launch; the pairs are folded into the totals by the

@@ -1,5 +1,6 @@
 // C ABI of libwebdgs_hip.so (include/webdgs.h): handle types, ownership, launch sequencing.
 #include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -398,15 +399,24 @@ static int deferred_checks(wdgs_device* d) {
     // and a read followed by a plain store of 0 would lose a note the device writes between the two.  The device writes
     // whole aligned words into pinned host memory; the exchange either sees the note (and reports it now) or leaves it for the next check.
     const u32 skipped = __atomic_exchange_n(d->host_guard, 0u, __ATOMIC_ACQ_REL);
-    u32 needed = 0u, cap = 0u;  // every pass's word is consumed; the first overflow found is the one reported
+    // every pass's word is consumed; the report names every pass that overflowed (up to four), so that a host whose passes share the device with
+    // another owner's -- a Trainer beside a Viewer -- can tell its own
+    char report[384];
+    size_t at = 0;
+    u32 found = 0u;
     for (wdgs_tiled_forward* f : d->forwards) {
         if (!f->encoded) continue;
         // written by update_stats before the stream drained (no device round trip here); sticky across the encodes since the last
         // check: the exchange consumes it
         const u32 v = __atomic_exchange_n(f->host_stats + 2, 0u, __ATOMIC_ACQ_REL);
-        if (v != 0u && needed == 0u) { needed = v; cap = f->tile_info.max_tile_entries; }
+        if (v != 0u && found < 4u && at < sizeof(report)) {
+            const int w = std::snprintf(report + at, sizeof(report) - at, "%s%u entries needed, max_tile_entries = %u (forward pass %p)", found ? "; " : "", v,
+                                        f->tile_info.max_tile_entries, (void*)f);
+            if (w > 0) at += (size_t)w;
+            found++;
+        }
     }
-    WDGS_REQUIRE(needed == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (raise wdgs_tiled_forward_config.max_tile_entries)", needed, cap);
+    WDGS_REQUIRE(found == 0u, WDGS_E_CAPACITY, "tile entries overflow: %s (raise wdgs_tiled_forward_config.max_tile_entries)", report);
     WDGS_REQUIRE(skipped == 0u, WDGS_E_CAPACITY, "an optimizer step was skipped on every rank: tile entries overflowed on another rank (its own error names the size)");
     return WDGS_OK;
 }
@@ -1051,7 +1061,7 @@ int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
     for (int i = 0; i < 4; i++) st[i] = ((const volatile u32*)op->host_stats)[i];
     st[2] = __atomic_exchange_n(op->host_stats + 2, 0u, __ATOMIC_ACQ_REL);  // the overflow word is sticky (set by any encode since the last check): consumed here, atomically
     if (stats_out) std::memcpy(stats_out, st, sizeof(st));
-    WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u", st[2], op->tile_info.max_tile_entries);
+    WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (forward pass %p)", st[2], op->tile_info.max_tile_entries, (void*)op);
     return WDGS_OK;
 }
 

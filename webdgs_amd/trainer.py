@@ -32,6 +32,7 @@ class Trainer:
         self.world_size, self.rank, self.views_per_rank = int(world_size), int(rank), max(1, int(views_per_rank))
         self.maxTileEntries = int(maxTileEntries)
         self._grown_tile_entries = 0  # (auto sizing only: what an overflow has made of the lists, step())
+        self._foreign_overflow_warned = False
         # the transport of the data-parallel exchange (parallel.Exchange); world_size == 1 needs none
         self.exchange = exchange if exchange is not None else (parallel.default_exchange(device, self.world_size) if self.world_size > 1 else parallel.Exchange())
         # sliced step (reduce-scatter / owned-slice Adam / all-gather): any real exchange, also a forced one in a world of one
@@ -162,7 +163,7 @@ class Trainer:
         with headroom when the cloud outgrew them) -- only the optimizer, which adopts the rebuilt state arrays, is new.  Passes that
         cannot follow (another SH degree) are rebuilt as the reference does."""
         self.drain()
-        self.device.synchronize()
+        self._synchronize()
         oldParams = self.optimizer.getHyperparameters() if self.optimizer else None
         if self.optimizer is not None:
             self.optimizer.destroy()
@@ -208,7 +209,7 @@ class Trainer:
         if self._tickets and self.device.handle:  # steps in flight replay these recordings: wait before destroying them
             self._tickets = []
             try:
-                self.device.synchronize()
+                self._synchronize()
             except ops.CapacityError as e:  # (reported once the recordings are gone: the caller must still hear of it)
                 deferred = e
         for c in self._cmd_cache.values():
@@ -457,9 +458,9 @@ class Trainer:
         import warnings
         if self.maxTileEntries != 0 or not self.device.handle:
             return False
+        mine = self._own_overflow(error) or []   # (a report about other owners' passes only never gets here: _wait / _synchronize)
         now = max([int(fw.getResources()["maxTileEntries"]) for fw in self._forward_passes()] + [self._grown_tile_entries, 1 << 20])
-        m = re.search(r"(\d+) entries needed", str(error))
-        new = min(max(2 * now, int(int(m.group(1)) * 1.5) if m else 0), 0xFFFFF000)
+        new = min(max(2 * now, int(max(mine) * 1.5) if mine else 0), 0xFFFFF000)
         if new <= now:
             return False
         warnings.warn(f"tile-entry lists grown from {now} to {new} entries after an overflow ({error}); the step that overflowed was skipped", RuntimeWarning, stacklevel=3)
@@ -701,19 +702,54 @@ class Trainer:
         self._exchange_events = []
         return float(ms)
 
+    def _own_overflow(self, error) -> Optional[list]:
+        """The entries needed by THIS trainer's passes among those a capacity report names (csrc/api.hip: deferred_checks names every pass that
+        overflowed), ``[]`` if it names only other owners' passes, ``None`` if it names none (a step skipped on every rank)."""
+        import re
+        named = re.findall(r"(\d+) entries needed, max_tile_entries = \d+ \(forward pass (0x[0-9a-fA-F]+)\)", str(error))
+        if not named:
+            return None
+        own = {int(fw.handle.value or 0) for fw in self._forward_passes()}
+        return [int(n) for n, h in named if int(h, 16) in own]
+
+    def _not_ours(self, error) -> bool:
+        """True (after saying so once) for a capacity report about passes this trainer does not own -- a Viewer rendering the same cloud on this
+        device: the report is device-wide, whoever waits first gets it, and it is the pass's owner who has to enlarge its lists."""
+        if self._own_overflow(error) != []:
+            return False
+        if not self._foreign_overflow_warned:
+            import warnings
+            warnings.warn(f"a forward pass that is not this trainer's overflowed its tile-entry lists ({error}); its owner has to enlarge them", RuntimeWarning, stacklevel=4)
+            self._foreign_overflow_warned = True
+        return True
+
+    def _wait(self, ticket) -> None:
+        try:
+            self.device.queue.wait(ticket)
+        except ops.CapacityError as e:
+            if not self._not_ours(e):
+                raise
+
+    def _synchronize(self) -> None:
+        try:
+            self.device.synchronize()
+        except ops.CapacityError as e:
+            if not self._not_ours(e):
+                raise
+
     def _finish_step(self, n_views: int) -> None:
         """``await onSubmittedWorkDone()`` (trainer.ts:639-645) + the deferred capacity check, for the step ``pipeline_depth - 1``
         submissions ago.  In a batched step the guard word was summed over all ranks by the exchange and the optimizer kernels leave
         a host-visible note when they skip themselves, so every rank raises at the same step."""
         self._tickets.append(self.device.queue.mark())
         while len(self._tickets) >= self.pipeline_depth:
-            self.device.queue.wait(self._tickets.pop(0))
+            self._wait(self._tickets.pop(0))
 
     def drain(self) -> None:
         """Awaits every step still in flight (a no-op at ``pipeline_depth`` 1)."""
         tickets, self._tickets = self._tickets, []
         for t in tickets:
-            self.device.queue.wait(t)
+            self._wait(t)
 
     def syncOptimizerState(self) -> None:
         """Brings every rank's optimizer state up to date: after sliced steps a rank holds current (param, m, v) only for the
@@ -819,6 +855,6 @@ class Trainer:
         self.densifyPrune.encodeScatter(encoder, dict(pointCloud=self.pointCloud, optimizerState=self.optimizer.getStateBuffers(),
                                                       outOffsetBuffer=prepared["outOffsetBuffer"], outNumPoints=outN, resetNewOptimizerState=True),
                                         dict(outPointCloud=outPointCloud, outOptimizerState=outState))
-        self.device.synchronize()
+        self._synchronize()
         self.requestPointCloudSwap(outPointCloud, dict(iteration=self.optimizer.getIteration(), buffers=outState))
         self.lastDensifyPruneIteration = self.iteration
