@@ -17,6 +17,19 @@ async function main() {
   const pc = { type: 'full', num_points: cfg.num_points, sh_deg: cfg.sh_deg, gaussian_3d_buffer: upload(g), sh_buffer: upload(sh) };
   const black = new Uint8Array(cfg.width * cfg.height * 4);
   const images = cams.map(() => ({ texture: upload(black), width: cfg.width, height: cfg.height }));
+  // a Viewer on the same kind of cloud: its first frame outruns the lists the library sized for it; readFrame() rebuilds the passes and renders again
+  const { Viewer } = require(path.join(__dirname, '..', 'ts', 'viewer.js'));
+  const vpc = { type: 'full', num_points: cfg.num_points, sh_deg: cfg.sh_deg, gaussian_3d_buffer: upload(g), sh_buffer: upload(sh) };
+  const viewer = new Viewer(dev, null, { width: cfg.width, height: cfg.height });
+  viewer.setPointCloud(vpc);
+  viewer.setRenderMode('gaussian');
+  dev.queue.writeBuffer(viewer.camera.uniform_buffer, 0, cams[0]);
+  viewer.render(null);
+  const frame = viewer.readFrame();
+  const viewerOut = { frame: crypto.createHash('sha256').update(Buffer.from(frame.buffer, frame.byteOffset, frame.byteLength)).digest('hex'),
+    cap: viewer.getForwardPass().getResources().maxTileEntries };
+  viewer.forwardPass.destroy(); viewer.rasterizer.destroy(); vpc.gaussian_3d_buffer.destroy(); vpc.sh_buffer.destroy();
+  try { dev.synchronize(); } catch (_e) { /* (nothing of the viewer's is left to report) */ }
   const warnings = [];
   const warn = console.warn; console.warn = (m) => warnings.push(String(m));
   const t = new Trainer(dev, undefined, { pipelineDepth: depth, viewsPerStep: vpr, lanes: vpr > 1 ? 2 : 0 });
@@ -31,7 +44,7 @@ async function main() {
   const needed = t.forwardPass.check().totalTileEntries;
   const n = t.getPointCount();
   const sha = (buf, bytes) => crypto.createHash('sha256').update(Buffer.from(dev.readBuffer(buf, bytes))).digest('hex');
-  console.log(JSON.stringify({ grown: warnings.filter((w) => w.indexOf('tile-entry lists grown') >= 0).length, cap, needed, iteration: t.getIteration(),
+  console.log(JSON.stringify({ viewer: viewerOut, grown: warnings.filter((w) => w.indexOf('tile-entry lists grown') >= 0).length, cap, needed, iteration: t.getIteration(),
     gaussians: sha(t.pointCloud.gaussian_3d_buffer, n * 24), sh: sha(t.pointCloud.sh_buffer, n * 96) }));
   const last = t.pointCloud; t.destroy(); last.gaussian_3d_buffer.destroy(); last.sh_buffer.destroy();
   for (const im of images) im.texture.destroy();

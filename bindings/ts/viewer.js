@@ -25,13 +25,21 @@ class Viewer {
     this.handleResize();
   }
   setPointCloud(pointCloud) {   // viewer.ts:46-66
+    this.settings = { renderMode: 'pointcloud' };   // (a new cloud starts in point-cloud mode, default scale and point size)
+    this.tileEntries = 0;
+    this.pointCloud = pointCloud;
+    this.buildPasses();
+    this.camera.on_update_canvas();
+  }
+  buildPasses() {
     if (this.forwardPass) this.forwardPass.destroy();
     if (this.rasterizer) this.rasterizer.destroy();
-    this.pointCloud = pointCloud;
-    this.forwardPass = new hip.TiledForwardPass(this.device, pointCloud, this.camera.uniform_buffer,
-      { viewportWidth: this.canvas.width, viewportHeight: this.canvas.height, renderMode: 'pointcloud' });
+    this.forwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, this.camera.uniform_buffer,
+      { viewportWidth: this.canvas.width, viewportHeight: this.canvas.height, renderMode: 'pointcloud', maxTileEntries: this.tileEntries });
     this.rasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.forwardPass, format: this.presentationFormat });
-    this.camera.on_update_canvas();
+    if (this.settings.renderMode !== undefined) this.forwardPass.setRenderMode(this.settings.renderMode);
+    if (this.settings.gaussianScale !== undefined) this.forwardPass.setGaussianScale(this.settings.gaussianScale);
+    if (this.settings.pointSize !== undefined) this.forwardPass.setPointSize(this.settings.pointSize);
   }
   update(dt) { this.cameraControl.update(dt); }
   /** The image this frame is presented into: the context's current texture, or the viewer's own frame buffer. */
@@ -52,9 +60,9 @@ class Viewer {
     this.rasterizer.encode(commandEncoder, swap.width, swap.height);
     this.rasterizer.blitToTexture(commandEncoder, swap);
   }
-  setRenderMode(mode) { if (this.forwardPass) this.forwardPass.setRenderMode(mode); }
-  setGaussianScale(value) { if (this.forwardPass) this.forwardPass.setGaussianScale(value); }
-  setPointSize(value) { if (this.forwardPass) this.forwardPass.setPointSize(value); }
+  setRenderMode(mode) { if (this.forwardPass) { this.settings.renderMode = mode; this.forwardPass.setRenderMode(mode); } }
+  setGaussianScale(value) { if (this.forwardPass) { this.settings.gaussianScale = value; this.forwardPass.setGaussianScale(value); } }
+  setPointSize(value) { if (this.forwardPass) { this.settings.pointSize = value; this.forwardPass.setPointSize(value); } }
   getForwardPass() { return this.forwardPass; }
   handleResize() {   // viewer.ts:106-113
     if (!this.canvas) return;
@@ -66,7 +74,21 @@ class Viewer {
   /** New canvas size (the ResizeObserver callback of viewer.ts:37-40). */
   resize(width, height) { this.canvas.width = width; this.canvas.height = height; if (this.canvas.clientWidth !== undefined) { this.canvas.clientWidth = width; this.canvas.clientHeight = height; } this.handleResize(); }
   /** The presented image as a Uint8Array of width * height * 4 bytes (synchronises). */
-  readFrame() { const f = this.currentTexture(); return new Uint8Array(this.device.readBuffer(f, 4 * f.width * f.height)); }
+  readFrame() {
+    // If the frame's tile-entry list outran what the library sized for the cloud (the reference would show the truncated picture; the library reports it),
+    // the viewer's passes are rebuilt around larger lists and the frame is rendered again -- other owners' reports on the same device are left to them.
+    for (let attempt = 0; attempt < 4 && this.forwardPass; attempt++) {   // this viewer's own pass: its word is consumed by its own check
+      try { this.forwardPass.check(); break; } catch (e) {
+        const m = e && e.code === 'WDGS_E_CAPACITY' && /(\d+) entries needed, max_tile_entries = (\d+)/.exec(String(e.message));
+        if (!m) throw e;
+        this.tileEntries = Math.min(Math.max(2 * Number(m[2]), Math.floor(Number(m[1]) * 1.5)), 0xFFFFF000);
+        this.buildPasses();
+        this.render(null);
+      }
+    }
+    const f = this.currentTexture();
+    return new Uint8Array(this.device.readBuffer(f, 4 * f.width * f.height));
+  }
   savePNG(file) { const f = this.currentTexture(); fs.writeFileSync(file, encodePNG(this.readFrame(), f.width, f.height)); }
   destroy() {
     if (this.forwardPass) this.forwardPass.destroy();

@@ -280,6 +280,25 @@ def test_tile_entry_lists_grow_after_an_overflow_in_both_hosts_alike(hip_device,
     cfg = synth.SceneConfig(2, 6000, 512, 384, 1, 550.0, 0.2, "few-large-splats")
     g, sh = synth.make_gaussians(cfg)
     cams = synth.circle_cameras(cfg, 2)
+    # the Viewers: a first frame that outruns the library-sized lists is rendered again around larger ones by readFrame() -- in both hosts the picture
+    # a pass with lists pinned large enough gives
+    vpc = ops.createPointCloud(dev, g, sh, cfg.sh_deg)
+    v = Viewer(dev, cfg.width, cfg.height)
+    v.setCamera(cams[0]); v.setPointCloud(vpc); v.setRenderMode("gaussian")
+    v.render(None)
+    frame = v.readFrame().copy()
+    vcap = int(v.getForwardPass().getResources()["maxTileEntries"])
+    v.destroy()
+    cam = dev.bufferFrom(np.asarray(cams[0], np.float32))
+    fw = ops.TiledForwardPass(dev, vpc, cam, dict(viewportWidth=cfg.width, viewportHeight=cfg.height, renderMode="gaussian", maxTileEntries=8 << 20))
+    rs = ops.TiledRasterizer(dict(device=dev, forwardPass=fw))
+    fw.encode(None); rs.encode(None, cfg.width, cfg.height)
+    whole = rs.getOutputTextureView().read(np.uint8).reshape(cfg.height, cfg.width, 4).copy()
+    assert int(fw.check()[0]) > (1 << 20)
+    rs.destroy(); fw.destroy(); vpc.gaussian_3d_buffer.destroy(); vpc.sh_buffer.destroy()
+    assert vcap > (1 << 20), "the Python viewer grew its lists"
+    assert_bits_equal(frame, whole, "the Python viewer's frame after the growth vs a pass with room from the start")
+    assert out["viewer"]["cap"] == vcap and out["viewer"]["frame"] == hashlib.sha256(whole.tobytes()).hexdigest(), "the JS viewer's frame likewise"
     images = [dict(texture=dev.bufferFrom(np.zeros((cfg.height, cfg.width, 4), np.uint8)), width=cfg.width, height=cfg.height) for _ in cams]
     t = Trainer(dev, seed=0, pipeline_depth=depth, views_per_rank=vpr, overlap_views=2 if vpr > 1 else None)
     t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))

@@ -15,6 +15,7 @@ from typing import Optional
 import numpy as np
 
 from . import loaders
+from ._lib import CapacityError
 from .ops import HipBuffer, HipDevice, HipEncoder, PointCloud, TiledForwardPass, TiledRasterizer
 
 
@@ -93,14 +94,22 @@ class Viewer:
         self.cameraBuffer.write(block)
 
     def setPointCloud(self, pointCloud: PointCloud) -> None:
+        self._settings = dict(renderMode="pointcloud")  # (viewer.ts:46-66: a new cloud starts in point-cloud mode, default scale and point size)
+        self._tile_entries = 0
+        self.pointCloud = pointCloud
+        self._build_passes()
+
+    def _build_passes(self) -> None:
         if self.forwardPass is not None:
             self.forwardPass.destroy()
         if self.rasterizer is not None:
             self.rasterizer.destroy()
-        self.pointCloud = pointCloud
-        self.forwardPass = TiledForwardPass(self.device, pointCloud, self.cameraBuffer,
-                                            dict(viewportWidth=self.width, viewportHeight=self.height, renderMode="pointcloud"))
+        self.forwardPass = TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
+                                            dict(viewportWidth=self.width, viewportHeight=self.height, renderMode="pointcloud", maxTileEntries=self._tile_entries))
         self.rasterizer = TiledRasterizer(dict(device=self.device, forwardPass=self.forwardPass, format=self.presentationFormat))
+        for k, apply in (("renderMode", self.forwardPass.setRenderMode), ("gaussianScale", self.forwardPass.setGaussianScale), ("pointSize", self.forwardPass.setPointSize)):
+            if k in self._settings:
+                apply(self._settings[k])
 
     def update(self, dt: float) -> None:
         """Camera-control integration step of the reference (viewer.ts:68-70); no interactive control here."""
@@ -115,14 +124,17 @@ class Viewer:
     # ---- pass-through setters / getters (viewer.ts:89-104)
     def setRenderMode(self, mode: str) -> None:
         if self.forwardPass is not None:
+            self._settings["renderMode"] = mode
             self.forwardPass.setRenderMode(mode)
 
     def setGaussianScale(self, value: float) -> None:
         if self.forwardPass is not None:
+            self._settings["gaussianScale"] = value
             self.forwardPass.setGaussianScale(value)
 
     def setPointSize(self, value: float) -> None:
         if self.forwardPass is not None:
+            self._settings["pointSize"] = value
             self.forwardPass.setPointSize(value)
 
     def getForwardPass(self) -> Optional[TiledForwardPass]:
@@ -140,7 +152,30 @@ class Viewer:
 
     # ---- presentation
     def readFrame(self) -> np.ndarray:
-        """The presented image as ``[H, W, 4]`` uint8 (synchronises)."""
+        """The presented image as ``[H, W, 4]`` uint8 (synchronises).  If the frame's tile-entry list outran what the library sized for the cloud
+        (the reference would show the truncated picture; the library reports it), the viewer's passes are rebuilt around larger lists and the
+        frame is rendered again -- other owners' reports on the same device are left to them."""
+        import re
+        for _ in range(4):  # this viewer's own pass: its word is consumed by its own check
+            if self.forwardPass is None:
+                break
+            try:
+                self.forwardPass.check()
+                break
+            except CapacityError as e:
+                m = re.search(r"(\d+) entries needed, max_tile_entries = (\d+)", str(e))
+                if not m:
+                    raise
+                self._tile_entries = min(max(2 * int(m.group(2)), int(int(m.group(1)) * 1.5)), 0xFFFFF000)
+                self._build_passes()
+                self.render(None)
+        for _ in range(4):  # the read synchronises the device: a report about someone else's pass may surface here -- consumed, and not this viewer's
+            try:
+                return self.frameBuffer.read(np.uint8, 4 * self.width * self.height).reshape(self.height, self.width, 4)
+            except CapacityError as e:
+                own = hex(int(self.forwardPass.handle.value or 0)) if self.forwardPass is not None else ""
+                if own and own in str(e).lower():
+                    raise
         return self.frameBuffer.read(np.uint8, 4 * self.width * self.height).reshape(self.height, self.width, 4)
 
     def savePNG(self, path: str) -> None:
