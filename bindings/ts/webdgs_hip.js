@@ -187,7 +187,7 @@ class TiledForwardPass {                 // tiled-forward-pass.ts:62
   getStatsBuffer() { return this.getResources().statsBuffer; }
   /** Synchronises; throws (code WDGS_E_CAPACITY) if an encode since the last check overflowed maxTileEntries. */
   check() { return addon.tiledForwardCheck(this.handle); }
-  destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledForwardDestroy(this.handle); }
+  destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledForwardDestroy(this.handle); this.handle = null; }   // (a call after destroy meets the library's null check, not freed memory)
 }
 
 class TiledRasterizer {                  // tiled-rasterizer.ts:34
@@ -204,7 +204,7 @@ class TiledRasterizer {                  // tiled-rasterizer.ts:34
    *  `width` / `height` (a canvas of another size: the blit is a bilinear resample), otherwise it has the rasterizer's size.  The blit covers
    *  the whole target, so the reference's clear colour never shows and is accepted only for signature compatibility. */
   blitToTexture(_encoder, target, _clearColor) { addon.tiledRasterizerBlit(this.handle, target.ptr, dflt(target.width, this.w), dflt(target.height, this.h)); }
-  destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledRasterizerDestroy(this.handle); }
+  destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledRasterizerDestroy(this.handle); this.handle = null; }
 }
 
 const resourcePtrs = (r) => ({ splatBuffer: r.splatBuffer.ptr, tileOffsetsBuffer: r.tileOffsetsBuffer.ptr, tileIndicesBuffer: r.tileIndicesBuffer.ptr,
@@ -258,7 +258,7 @@ class TiledBackwardPass {                // tiled-backward-pass.ts:71
   getLossTextureView() { return this.device.view(addon.tiledBackwardGet(this.handle, 2), 16 * this.w * this.h); }
   getMetricMapTextureView() { return this.device.view(addon.tiledBackwardGet(this.handle, 3), 4 * this.w * this.h); }
   getMetricMapTexture() { return this.getMetricMapTextureView(); }   // (texture and view are the same r32uint image buffer here)
-  destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledBackwardDestroy(this.handle); }
+  destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledBackwardDestroy(this.handle); this.handle = null; }
 }
 
 const DEFAULT_ADAM_HYPERPARAMETERS = { lr_pos: 0.00016, lr_color: 0.0025, lr_opacity: 0.05, lr_scale: 0.005, lr_rot: 0.001, beta1: 0.9, beta2: 0.999, epsilon: 1e-8 };  // adam-config.ts:12-21
@@ -344,6 +344,7 @@ class Optimizer {                        // optimizer.ts:40
     if (this.deferredCloud && !this.deferredCloud.sh_buffer.destroyed) this.setDeferredSH(this.deferredCloud, false);  // the cloud outlives its optimizer: leave its rows current
     this.destroyed = true;
     addon.optimizerDestroy(this.handle);
+    this.handle = null;
     if (this.buffers) for (const k of STATE_KEYS) this.buffers[k].destroy();
   }
 }
