@@ -90,12 +90,14 @@ def test_train_step_bit_exact(orc, hip_device, base, kw):
         pipe.destroy()
 
 
-@pytest.mark.parametrize("env", [dict(WDGS_BWR_SUMS="butterfly"), dict(WDGS_BWR_WPW="4", WDGS_RASTER_WPW="1"), dict(WDGS_BWR_PRIO="0", WDGS_FWR_PRIO="0")],
-                         ids=["register-butterfly", "other-workgroup-shapes", "no-issue-priorities"])
+@pytest.mark.parametrize("env", [dict(WDGS_BWR_SUMS="butterfly"), dict(WDGS_BWR_WPW="4", WDGS_RASTER_WPW="1"), dict(WDGS_BWR_PRIO="0", WDGS_FWR_PRIO="0"),
+                                 dict(WDGS_BWR_LONG="32", WDGS_FWR_LONG="32")],
+                         ids=["register-butterfly", "other-workgroup-shapes", "no-issue-priorities", "long-list-passes"])
 def test_alternative_kernel_forms_stay_bit_exact(env):
     """The forms kept for same-box A/B measurements -- backward_rasterize's register-only reduction (round 2) and the other
     waves-per-workgroup shapes of the two rasterization kernels, and the rasterization kernels without the issue priorities they set on grids
-    that fit the chip (every case of this file does) -- are selected by environment variables that the library reads once per
+    that fit the chip (every case of this file does), and the opt-in passes of both rasterization kernels over long tile lists (here: every list
+    above 32 entries, i.e. nearly all of c1's) -- are selected by environment variables that the library reads once per
     process: the train-step parity case runs again in a child process under each."""
     import os
     import subprocess
