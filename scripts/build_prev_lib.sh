@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds the library from a committed state of webdgs_amd/csrc (default HEAD) as webdgs_amd/lib/libwebdgs_hip_prev.so, for same-box A/B runs
-# against the working tree's build (scripts/_gpu_ab_lib.sh; WDGS_LIB_PATH).   bash scripts/build_prev_lib.sh [commit]
+# against the working tree's build (scripts/runs/_gpu_ab_lib.sh; WDGS_LIB_PATH).   bash scripts/build_prev_lib.sh [commit]
 set -e
 REV=${1:-HEAD}
 R=$(cd $(dirname $0)/.. && pwd)
