@@ -120,8 +120,10 @@ static vec3 computeColorFromSH(const u32* sh, vec3 dir, u32 v_idx, u32 sh_deg) {
 }
 
 // tiled-forward.wgsl:121-136
+// PIN: bitcast<u32> of a NaN is implementation-defined (which NaN an operation returns differs between machines: sign and payload), and here the bits
+// become a sort key.  A NaN depth counts as the canonical quiet NaN 0x7FC00000 -- it sorts behind every number.
 static u32 float_to_ordered_uint(f32 x) {
-    const u32 bits = f2bits(x);
+    const u32 bits = (x != x) ? 0x7FC00000u : f2bits(x);
     const u32 mask = ((bits & 0x80000000u) != 0u) ? 0xFFFFFFFFu : 0x80000000u;
     return bits ^ mask;
 }

@@ -13,7 +13,7 @@
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
 int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*, void*,
-                         const void*);
+                         const void*, void*, const void*);
 int launch_emit_scatter(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, const void*, const void*, void*, void*, u32);
 int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges);
 extern "C" void sorter_set_final_out_index(wdgs_sorter* s, int i);
@@ -21,7 +21,7 @@ int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*,
 int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
 int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
-                     void*, void*);
+                     void*, void*, const void*, const void*);
 int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdgs_training_config&, void*, void*, u32, const void*);
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
                               void*, void*);
@@ -29,7 +29,7 @@ int launch_acc_clear_if_dirty(wdgs_device*, void*, u32, void*);
 int launch_geometry_backward_views(wdgs_device*, u32, u32, const void* const*, const RenderSettings&, const void*, void* const*, void* const*, const void* const*,
                                    const void* const*, void* const*, void*, void*, void*, u32);
 int launch_project_count_views(wdgs_device*, u32, u32, const void*, const void*, const void* const*, const RenderSettings&, const TileInfo&, void* const*, void* const*,
-                               void* const*, void* const*, void* const*, void* const*, const void*);
+                               void* const*, void* const*, void* const*, void* const*, const void*, void* const*, const void* const*);
 int launch_geometry_backward(wdgs_device*, u32, const void*, const RenderSettings&, const void*, void*, void*);
 int launch_geometry_backward_adam(wdgs_device*, u32, const void*, const RenderSettings&, void*, void*, void*, void*, const wdgs_adam_hyperparameters&, const void*,
                                   const wdgs_optimizer_state&, const CsView&, void*, const void*, void*);
@@ -201,7 +201,11 @@ struct wdgs_tiled_forward {
     wdgs_tiled_forward_config cfg;
     RenderSettings settings;
     TileInfo tile_info;
-    u32* stats;   // {total_tile_entries, visible_gaussians, overflow (0 or requested total), pad} + 64 visible-count shards
+    u32* stats;   // {total_tile_entries, visible_gaussians, overflow (0 or requested total), pad} + 64 visible-count shards + the frame number (FRAME_WORD)
+    // u32[tiles]: a tile whose entry equals the frame number holds a Splat with a NaN or an infinity among its fp16 fields (project.hip stamps,
+    // scan.hip advances the number, raster.hip takes such tiles in the oracle's own forms)
+    u32* nf_stamp;
+    u32 nf_capacity;
     u32* host_stats;  // pinned, device-visible copy of stats[0..3] written by update_stats: the per-step overflow check reads host memory
     u32* splats;
     u32* depths;
@@ -224,6 +228,9 @@ struct wdgs_tiled_forward {
     bool projected;          // K1 of the current frame ran through wdgs_tiled_forward_project_views
     bool projected_columns;  // ... and counted per tile column
 };
+
+constexpr u32 FRAME_WORD = 4u + 64u;   // index of the frame number in wdgs_tiled_forward::stats
+constexpr size_t FORWARD_STATS_BYTES = 16 + 64 * 4 + 16;
 
 struct wdgs_tiled_rasterizer {
     wdgs_device* dev;
@@ -785,6 +792,15 @@ static void forward_set_viewport(wdgs_tiled_forward* op, u32 w, u32 h) {
     op->tile_info.num_tiles_y = ceil_div(h, 16);
     op->tile_info.total_tiles = op->tile_info.num_tiles_x * op->tile_info.num_tiles_y;
 }
+static int forward_alloc_nf_stamp(wdgs_tiled_forward* op) {
+    if (op->tile_info.total_tiles <= op->nf_capacity) return WDGS_OK;
+    free_dev(op->nf_stamp);
+    op->nf_stamp = nullptr;
+    op->nf_capacity = 0;
+    WDGS_TRY(wdgs_alloc((void**)&op->nf_stamp, sizeof(u32) * (size_t)op->tile_info.total_tiles, true, op->dev->stream));
+    op->nf_capacity = op->tile_info.total_tiles;
+    return WDGS_OK;
+}
 
 int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* cfg, wdgs_tiled_forward** out) {
     WDGS_REQUIRE(d && cfg && out, WDGS_E_INVALID, "wdgs_tiled_forward_create: null argument");
@@ -798,6 +814,8 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->cfg = *cfg;
     op->stats = op->splats = op->depths = op->block_counts = op->column_counts = op->column_totals = nullptr;
     op->dc_source = nullptr;
+    op->nf_stamp = nullptr;
+    op->nf_capacity = 0;
     op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;
@@ -814,7 +832,10 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
                                   cfg->max_splat_radius_px != 0.f ? cfg->max_splat_radius_px : 128.0f};
     op->tile_info.max_tile_entries = (u32)cap;
     forward_set_viewport(op, cfg->viewport_width, cfg->viewport_height);
-    int r = wdgs_alloc((void**)&op->stats, 16 + 64 * 4, true, d->stream);
+    int r = wdgs_alloc((void**)&op->stats, FORWARD_STATS_BYTES, true, d->stream);
+    // (frame numbers start at 1: a zeroed stamp table marks nothing)
+    if (r == WDGS_OK && hipMemsetD32Async((hipDeviceptr_t)(op->stats + FRAME_WORD), 1, 1, d->stream) != hipSuccess) { wdgs_set_error("hipMemsetD32Async failed"); r = WDGS_E_HIP; }
+    if (r == WDGS_OK) r = forward_alloc_nf_stamp(op);
     if (r == WDGS_OK && hipHostMalloc((void**)&op->host_stats, 16, hipHostMallocDefault) != hipSuccess) { wdgs_set_error("hipHostMalloc(16) failed"); r = WDGS_E_HIP; }
     if (r == WDGS_OK) std::memset(op->host_stats, 0, 16);
     if (r == WDGS_OK) r = forward_alloc_per_point(op, std::max(n, 1u));
@@ -833,6 +854,7 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
     }
     sync_if_alive(op->dev);
     free_dev(op->stats);
+    free_dev(op->nf_stamp);
     if (op->host_stats) (void)hipHostFree(op->host_stats);
     free_dev(op->splats);
     free_dev(op->depths);
@@ -880,7 +902,7 @@ int wdgs_tiled_forward_resize(wdgs_tiled_forward* op, uint32_t n) {
     }
     op->tile_info.max_tile_entries = (u32)cap;
     op->cfg.num_points = n;
-    WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16 + 64 * 4, d->stream));
+    WDGS_CHECK_HIP(hipMemsetAsync(op->stats, 0, 16 + 64 * 4, d->stream));   // (the frame number behind the shards goes on counting)
     std::memset(op->host_stats, 0, 16);
     op->encoded = false;
     op->ranges_valid = false;
@@ -910,7 +932,7 @@ static int forward_encode_rest(wdgs_tiled_forward* op, int skip_sort, bool colum
     wdgs_device* d = op->dev;
     const u32 n = op->cfg.num_points;
     const TileInfo& ti = op->tile_info;
-    const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries};
+    const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries, op->stats + FRAME_WORD};
     if (columns) {
         WDGS_TRY(forward_scan(d, op->block_counts, ceil_div(n, 256), op->column_counts, op->column_totals, ti.num_tiles_x, ep));
     } else if (n > 0) {
@@ -967,7 +989,7 @@ int wdgs_tiled_forward_encode(wdgs_tiled_forward* op, const void* gaussians, con
     const bool columns = forward_uses_columns(op, skip_sort);
     op->projected = false;  // (K1 overwrites whatever projection the buffers held)
     WDGS_TRY(launch_project_count(d, n, gaussians, sh, camera, op->settings, op->tile_info, op->splats, op->depths, op->scanner->input, op->stats + 4,
-                                  op->block_counts, columns ? op->column_counts : nullptr, op->dc_source));
+                                  op->block_counts, columns ? op->column_counts : nullptr, op->dc_source, op->nf_stamp, op->stats + FRAME_WORD));
     return forward_encode_rest(op, skip_sort, columns);
 }
 
@@ -978,7 +1000,8 @@ int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void*
     WDGS_REQUIRE(f0, WDGS_E_INVALID, "wdgs_tiled_forward_project_views: null pass");
     const bool columns = forward_uses_columns(f0, 0);
     void *splats[WDGS_MAX_BATCH_VIEWS], *depths[WDGS_MAX_BATCH_VIEWS], *counts[WDGS_MAX_BATCH_VIEWS], *shards[WDGS_MAX_BATCH_VIEWS], *blocks[WDGS_MAX_BATCH_VIEWS],
-        *cols[WDGS_MAX_BATCH_VIEWS];
+        *cols[WDGS_MAX_BATCH_VIEWS], *stamps[WDGS_MAX_BATCH_VIEWS];
+    const void* frames[WDGS_MAX_BATCH_VIEWS];
     for (u32 v = 0; v < count; v++) {
         wdgs_tiled_forward* f = ops[v];
         WDGS_REQUIRE(f && cameras[v], WDGS_E_INVALID, "wdgs_tiled_forward_project_views: null pass or camera %u", v);
@@ -988,9 +1011,10 @@ int wdgs_tiled_forward_project_views(wdgs_tiled_forward* const* ops, const void*
                          f->tile_info.num_tiles_y == f0->tile_info.num_tiles_y && f->dc_source == f0->dc_source,
                      WDGS_E_STATE, "wdgs_tiled_forward_project_views: pass %u differs from pass 0 (cloud size, SH degree, viewport, settings or dc source)", v);
         splats[v] = f->splats; depths[v] = f->depths; counts[v] = f->scanner->input; shards[v] = f->stats + 4; blocks[v] = f->block_counts; cols[v] = f->column_counts;
+        stamps[v] = f->nf_stamp; frames[v] = f->stats + FRAME_WORD;
     }
     WDGS_TRY(launch_project_count_views(f0->dev, f0->cfg.num_points, count, gaussians, sh, cameras, f0->settings, f0->tile_info, splats, depths, counts, shards, blocks,
-                                        columns ? cols : nullptr, f0->dc_source));
+                                        columns ? cols : nullptr, f0->dc_source, stamps, frames));
     for (u32 v = 0; v < count; v++) { ops[v]->projected = true; ops[v]->projected_columns = columns; }
     return WDGS_OK;
 }
@@ -1015,7 +1039,9 @@ int wdgs_tiled_forward_is_projected(const wdgs_tiled_forward* op) { return (op &
 int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t h) {
     WDGS_REQUIRE(op && w > 0 && h > 0, WDGS_E_INVALID, "wdgs_tiled_forward_set_viewport: invalid argument");
     WDGS_REQUIRE((uint64_t)ceil_div(w, 16) * ceil_div(h, 16) + 1 <= 0xFFFFu, WDGS_E_CAPACITY, "viewport %ux%u has too many tiles for the 16-bit tile field", w, h);
+    WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_tiled_forward_set_viewport while recording a command buffer");
     forward_set_viewport(op, w, h);
+    if (op->tile_info.total_tiles > op->nf_capacity) { (void)wdgs_sync_lanes(op->dev); WDGS_TRY(forward_alloc_nf_stamp(op)); }
     return WDGS_OK;
 }
 int wdgs_tiled_forward_set_render_mode(wdgs_tiled_forward* op, uint32_t mode) {
@@ -1124,7 +1150,7 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
         op->ranges_used = op->ranges;
     }
     WDGS_TRY(launch_rasterize(d, f->settings, ti, f->splats, f->cfg.num_points, op->ranges_used, keys, vals, f->stats, op->compat_caps ? 32u : 0u, op->rgba8,
-                              op->alpha, op->n_contrib));
+                              op->alpha, op->n_contrib, f->nf_stamp, f->stats + FRAME_WORD));
     op->encoded = true;
     return WDGS_OK;
 }

@@ -90,7 +90,7 @@ WD_DEV int cvt_fixed(float scaled) {
 // SIMD's issue slots (446 ns per iteration alone, 617 ns among four: profiles/r05v_bwr_wave_rate.txt).  The wave therefore sets its issue
 // priority from the entries it still has to walk, once per chunk: longest remaining chain first.  c2 187.0 -> 176.9 us per step, c3 unchanged
 // (profiles/r05x_bwr_issue_priority_sweep.txt; thresholds swept there).  Arbitration only: results cannot depend on it.
-template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false, bool PRIO = true, bool LONGSKIP = false>
+template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false, bool PRIO = true>
 __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         tile_id = k + 8u * (j >> 2);
         sub = j & 3u;
         if (tile_id >= num_tiles) return;
-        if (LONGSKIP && ((long_flags[tile_id] >> sub) & 1u)) return;   // (a long list: the three passes of long_list_* below own this block)
     }
     const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
     const u32 lane = threadIdx.x & 63u;
@@ -158,16 +157,19 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     const u32 range_end = ranges[tile_id + 1u];
     const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
     const u32 n_val = in_bounds ? n_contrib[p] : 0u;
-    const u32 pix_n = min(n_val, tile_entries);
+    float T = 0.0f;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (min(n_val, tile_entries) > 0u) { T = final_T[p]; g = loss_grad[p]; }
+    // A pixel whose final T is a NaN -- the forward pass met a Splat with a NaN alpha inside its extent box: a non-finite Gaussian -- contributes
+    // nothing: T stays a NaN through every division, each of the nine contributions has T or dL/dalpha = (..) * T as a factor, and the fixed-point
+    // conversion of a NaN is 0 (common.wgsl:113-116 as the parity oracle pins it; v_cvt_i32_f32).  Such a pixel leaves the walk here.  Late in a run of the
+    // reference's schedule tile 0 holds thousands of such Gaussians and every one of its pixels is of this kind.
+    const u32 pix_n = (T == T) ? min(n_val, tile_entries) : 0u;
 
     u32 wmax = pix_n;  // wave maximum (uniform)
 #pragma unroll
     for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
     if (wmax == 0u) { leave_timeline(); return; }
-
-    float T = 0.0f;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pix_n > 0u) { T = final_T[p]; g = loss_grad[p]; }
     const f2 pxy = f2{(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
     const f2 g_rg = f2{g.x, g.y};
     const float g_b = g.z;
@@ -202,7 +204,8 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         const bool have = gidx_c != 0xFFFFFFFFu;
         const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
         const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-        const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
+        // (WGSL's min, as the parity oracle evaluates it: a NaN extent stays a NaN and then passes every "outside" test; fminf would make it the cap)
+        const float ex = wd_min(wd_unpack_lo(w01.y), cap), ey = wd_min(wd_unpack_hi(w01.y), cap);
         const bool in_box = have && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
         const bool ok = in_box && block_reaches_min_alpha(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y), blk_x0 - cx,
                                                           blk_x1 - cx, blk_y0 - cy, blk_y1 - cy);
@@ -374,240 +377,6 @@ __global__ __launch_bounds__(256) void acc_clear_if_dirty_kernel(int4* __restric
 }
 
 
-// ================================================================================================ long tile lists (opt-in: WDGS_BWR_LONG=<entries>)
-// A launch lasts as long as its longest wave, and late in a run of the reference's default schedule ONE tile holds a list of 10 600 entries
-// (profiles/r06z_timelines_late_regime.txt: its four waves run 4.0 ms, the other 32 636 are done in 0.22 ms).  What the reference's recurrence
-// serialises per pixel is only T = T / (1 - alpha) and the three accum_rec FMAs; everything else of an iteration depends on those two values alone.
-// Lists longer than the threshold therefore take three passes, each operation with the operands it has in backward_rasterize_kernel (same bits):
-//   long_list_build   the (tile block, chunk) work items of the long lists, and the flags that make backward_rasterize_kernel leave those blocks alone;
-//   long_list_chunk<ALPHA>    per item: the chunk's compacted records, and alpha (0 where the pixel does not contribute) of every (record, pixel);
-//   long_list_recurrence      per block, ONE wave: T and accum_rec along the whole list, back to front, from the stored alphas -- the state BEHIND
-//                             every record goes to scratch;
-//   long_list_chunk<CONTRIBUTIONS>   per item: the nine contributions from the stored state, their wave sums, the atomics.
-struct LongLists {
-    u32* counters;     // [0] items, [1] blocks
-    u32* items;        // [MAX_ITEMS][4]: tile, block (0..3), chunk (0 = rear end), long-block index
-    u32* blocks;       // [MAX_BLOCKS][4]: tile, block, first item, chunks
-    u32* flags;        // [tiles]: bit b = block b of the tile is on the list
-    u32* nlist;        // [MAX_ITEMS]: records the chunk kept
-    float4* cols;      // [MAX_ITEMS * 64]: r, g, b, Gaussian index (bits) of every kept record
-    float* alpha;      // [MAX_ITEMS * 64][64]
-    float4* state;     // [MAX_ITEMS * 64][64]: T after the record's update, accum_rec before it
-    u32 max_items, max_blocks, threshold;
-};
-
-__global__ __launch_bounds__(256) void long_list_build_kernel(u32 num_tiles, const u32* __restrict__ ranges, LongLists ll) {
-    __shared__ u32 s_items, s_blocks;
-    if (threadIdx.x == 0u) { s_items = 0u; s_blocks = 0u; }
-    __syncthreads();
-    for (u32 t = threadIdx.x; t < num_tiles; t += 256u) {
-        // the list's length: an empty tile's entry is 0xFFFFFFFF, so the end is the start of the next tile that is not empty (ranges[tiles] = E ends the walk)
-        const u32 a = ranges[t];
-        u32 b = ranges[t + 1u];
-        for (u32 nx = t + 1u; b == 0xFFFFFFFFu && nx < num_tiles;) { nx++; b = ranges[nx]; }
-        const u32 len = (a != 0xFFFFFFFFu && b != 0xFFFFFFFFu && b > a) ? b - a : 0u;
-        u32 flag = 0u;
-        if (len > ll.threshold) {
-            const u32 chunks = (len + 63u) >> 6;
-            for (u32 blk = 0; blk < 4u; blk++) {
-                const u32 first = atomicAdd(&s_items, chunks);
-                const u32 lb = (first + chunks <= ll.max_items) ? atomicAdd(&s_blocks, 1u) : 0xFFFFFFFFu;
-                if (lb >= ll.max_blocks) {   // no room: this block stays with backward_rasterize_kernel, and what it reserved is void
-                    for (u32 c = 0; c < chunks && first + c < ll.max_items; c++) ll.items[(size_t)(first + c) * 4u] = 0xFFFFFFFFu;
-                    continue;
-                }
-                flag |= 1u << blk;
-                ll.blocks[lb * 4u + 0u] = t; ll.blocks[lb * 4u + 1u] = blk; ll.blocks[lb * 4u + 2u] = first; ll.blocks[lb * 4u + 3u] = chunks;
-                for (u32 c = 0; c < chunks; c++) {
-                    u32* it = ll.items + (size_t)(first + c) * 4u;
-                    it[0] = t; it[1] = blk; it[2] = c; it[3] = lb;
-                }
-            }
-        }
-        ll.flags[t] = flag;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0u) { ll.counters[0] = min(s_items, ll.max_items); ll.counters[1] = min(s_blocks, ll.max_blocks); }
-}
-
-// MODE 0: alphas and records of one chunk; MODE 1: its contributions.
-template <int MODE>
-__global__ __launch_bounds__(64, 8) void long_list_chunk_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges, const u32* __restrict__ instances,
-                                                               const u32* __restrict__ splats, const u32* __restrict__ n_contrib,
-                                                               const float4* __restrict__ loss_grad, int* __restrict__ acc, LongLists ll) {
-    __shared__ float4 s_geo[64], s_con[64], s_col[64];
-    __shared__ int s_sum[8u * 64u];
-    const u32 item = blockIdx.x;
-    if (item >= ll.counters[0]) return;
-    const u32 tile_id = ll.items[(size_t)item * 4u], sub = ll.items[(size_t)item * 4u + 1u], chunk = ll.items[(size_t)item * 4u + 2u];
-    if (tile_id == 0xFFFFFFFFu) return;   // (reserved by a block that found no room)
-    const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
-    const u32 lane = threadIdx.x & 63u;
-    const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
-    const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
-    const float vx = settings.viewport_x, vy = settings.viewport_y;
-    const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
-    const bool in_bounds = pixel_x < W && pixel_y < H;
-    const size_t p = (size_t)pixel_y * W + pixel_x;
-    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
-    const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const u32 sum_q = lane >> 3, sum_first = (sum_q & 1u) * 4u;
-    const int4* const sum_rd0 = reinterpret_cast<const int4*>(s_sum + sum_q * 64u + (lane & 7u) * 8u + sum_first);
-    const int4* const sum_rd1 = reinterpret_cast<const int4*>(s_sum + sum_q * 64u + (lane & 7u) * 8u + (4u - sum_first));
-    const bool sum_lane = (lane & 7u) == 0u;
-    const bool atomic_lane = (lane & 7u) == 0u || (lane & 15u) == 1u;
-    const u32 atomic_slot = sum_lane ? sum_q : 8u + (lane >> 4);
-    const u32 range_start = ranges[tile_id];
-    const u32 range_end = ranges[tile_id + 1u];
-    const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
-    const u32 n_val = in_bounds ? n_contrib[p] : 0u;
-    const u32 pix_n = min(n_val, tile_entries);
-    u32 wmax = pix_n;
-#pragma unroll
-    for (u32 d = 32; d >= 1; d >>= 1) wmax = max(wmax, (u32)__shfl_xor((int)wmax, (int)d, 64));
-    // chunk c of the walk of backward_rasterize_kernel: [max(hi - 64, 0), hi) with hi = wmax - 64 c
-    if (wmax <= 64u * chunk) { if (MODE == 0 && lane == 0u) ll.nlist[item] = 0u; return; }
-    const u32 hi = wmax - 64u * chunk, lo = (hi > 64u) ? hi - 64u : 0u;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 1 && pix_n > 0u) g = loss_grad[p];
-    const f2 pxy = f2{(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
-    const f2 g_rg = f2{g.x, g.y};
-    const float g_b = g.z;
-    // ---- the chunk's entries, compacted as backward_rasterize_kernel compacts them
-    const u32 gidx_c = (lane < hi - lo) ? instances[range_start + lo + lane] : 0xFFFFFFFFu;
-    uint2 w01 = make_uint2(0u, 0u), w23 = w01, w45 = w01;
-    const bool have = gidx_c != 0xFFFFFFFFu;
-    if (have) {
-        const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)gidx_c * 6);
-        w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
-    }
-    const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
-    const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-    const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
-    const bool in_box = have && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
-    const bool ok = in_box && block_reaches_min_alpha(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w45.y), blk_x0 - cx,
-                                                      blk_x1 - cx, blk_y0 - cy, blk_y1 - cy);
-    const unsigned long long m = __ballot(ok);
-    const u32 n_list = (u32)__popcll(m);
-    if (ok) {
-        const u32 slot = (u32)__popcll(m & lt_mask);
-        s_geo[slot] = make_float4(cx, cy, ex, ey);
-        s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -0.5f * wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-        s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(gidx_c));
-    }
-    const u32 rel = (pix_n > lo) ? min(pix_n - lo, 64u) : 0u;
-    const u32 mine = (u32)__popcll(m & ((rel >= 64u) ? ~0ull : ((1ull << rel) - 1ull)));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (MODE == 0 && lane == 0u) ll.nlist[item] = n_list;
-    const size_t rec0 = (size_t)item * 64u;
-    for (u32 i = n_list; i-- > 0u;) {
-        const float4 geo = s_geo[i];
-        const float4 con = s_con[i];
-        const float4 col = s_col[i];
-        const f2 d = pxy - f2{geo.x, geo.y};
-        const bool cand = ((int)(i < mine) & (int)!(fabsf(d.x) > geo.z) & (int)!(fabsf(d.y) > geo.w)) != 0;
-        const float syd = con.y * d.y;
-        const float t1 = __builtin_fmaf(con.x, d.x, syd + syd);
-        const float xe = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
-        float xc;
-        asm("v_max_f32 %0, 0xc2a00000, %1" : "=v"(xc) : "v"(xe));
-        float G = wd_exp_inrange(xc);
-        if (__builtin_expect(__any(!(xe <= 87.0f)), 0)) G = wd_exp(xe);
-        const float og = con.w * G;
-        const float alpha = (og < 0.99f) ? og : 0.99f;
-        const bool act = cand && !(alpha < (1.0f / 255.0f));
-        const float alpha_m = act ? alpha : 0.0f;
-        if (MODE == 0) {
-            ll.alpha[(rec0 + i) * 64u + lane] = alpha_m;
-            if (lane == 0u) ll.cols[rec0 + i] = col;
-            continue;
-        }
-        if (!__any(act)) continue;
-        const float4 st = ll.state[(rec0 + i) * 64u + lane];   // T after this record's update, accum_rec before it (long_list_recurrence_kernel)
-        const float T = st.x;
-        const f2 ar_rg = f2{st.y, st.z};
-        const float ar_b = st.w;
-        const float aT = alpha_m * T;
-        const f2 frg = (aT * g_rg) * FIXED_SCALE;
-        const int f_r = cvt_fixed(frg.x);
-        const int f_g = cvt_fixed(frg.y);
-        const int f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
-        const f2 col_rg = f2{col.x, col.y};
-        const f2 dc_rg = col_rg - ar_rg;
-        const float dL_dalpha_all = __builtin_fmaf(col.z - ar_b, g_b, __builtin_fmaf(dc_rg.y, g_rg.y, dc_rg.x * g_rg.x)) * T;
-        const float dL_dalpha = act ? dL_dalpha_all : 0.0f;
-        const float dL_dG = con.w * dL_dalpha;
-        const int f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
-        const f2 qpow = f2{__builtin_fmaf(con.x, d.x, syd), __builtin_fmaf(con.z, d.y, con.y * d.x)};
-        const float mhG = -0.5f * G;
-        const f2 fm = (dL_dG * (G * qpow)) * (-2.0f * FIXED_SCALE);
-        const int f_mx = cvt_fixed(fm.x);
-        const int f_my = cvt_fixed(fm.y);
-        const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;
-        const int f_cx = cvt_fixed(fc.x);
-        const int f_cz = cvt_fixed(fc.y);
-        const int f_cy = cvt_fixed((dL_dG * ((mhG * d.x) * d.y)) * (2.0f * FIXED_SCALE));
-        s_sum[0u * 64u + lane] = f_mx; s_sum[1u * 64u + lane] = f_my; s_sum[2u * 64u + lane] = f_cx; s_sum[3u * 64u + lane] = f_cy;
-        s_sum[4u * 64u + lane] = f_cz; s_sum[5u * 64u + lane] = f_op; s_sum[6u * 64u + lane] = f_r; s_sum[7u * 64u + lane] = f_g;
-        const int4 h0 = *sum_rd0, h1 = *sum_rd1;
-        unsigned x = ((unsigned)h0.x + (unsigned)h0.y) + ((unsigned)h0.z + (unsigned)h0.w) + (((unsigned)h1.x + (unsigned)h1.y) + ((unsigned)h1.z + (unsigned)h1.w));
-        x += (unsigned)dpp_xor1((int)x);
-        x += (unsigned)dpp_xor2((int)x);
-        x += (unsigned)dpp_half_mirror((int)x);
-        unsigned b = (unsigned)quad_sum(f_b);
-        b += (unsigned)dpp_ror4((int)b);
-        b += (unsigned)dpp_ror8((int)b);
-        const int msum = sum_lane ? (int)x : (int)b;
-        if (atomic_lane) atomicAdd(&acc[(size_t)__float_as_uint(col.w) * ACC_STRIDE + atomic_slot], msum);
-    }
-}
-
-// One wave per long block: the reference's recurrence along the whole list, from the alphas long_list_chunk_kernel<0> stored.
-__global__ __launch_bounds__(64) void long_list_recurrence_kernel(RenderSettings settings, u32 num_tiles_x, const u32* __restrict__ ranges, const float* __restrict__ final_T,
-                                                                   const u32* __restrict__ n_contrib, LongLists ll) {
-    __shared__ float s_alpha[64 * 64];
-    __shared__ float4 s_c[64];
-    const u32 lb = blockIdx.x;
-    if (lb >= ll.counters[1]) return;
-    const u32 tile_id = ll.blocks[lb * 4u], sub = ll.blocks[lb * 4u + 1u], first = ll.blocks[lb * 4u + 2u], chunks = ll.blocks[lb * 4u + 3u];
-    const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
-    const u32 lane = threadIdx.x & 63u;
-    const u32 pixel_x = tile_x * 16u + (sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (sub >> 1) * 8u + (lane >> 3);
-    const u32 W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
-    const bool in_bounds = pixel_x < W && pixel_y < H;
-    const size_t p = (size_t)pixel_y * W + pixel_x;
-    const u32 range_start = ranges[tile_id], range_end = ranges[tile_id + 1u];
-    const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
-    const u32 pix_n = min(in_bounds ? n_contrib[p] : 0u, tile_entries);
-    float T = (pix_n > 0u) ? final_T[p] : 0.0f;
-    f2 ar_rg = f2{0.f, 0.f};
-    float ar_b = 0.f;
-    // (one wave at its own cadence: ~45 instructions, 125 ns per record.  Fetching the next chunk's alphas into registers during the walk, and reading
-    // the next record's operands from LDS ahead of the division, were both tried and changed nothing -- profiles/r07i_long_list_passes.txt)
-    for (u32 c = 0; c < chunks; c++) {   // rear chunk first, as backward_rasterize_kernel walks
-        const u32 item = first + c;
-        const u32 n = ll.nlist[item];
-        const size_t rec0 = (size_t)item * 64u;
-        __builtin_amdgcn_wave_barrier();
-        for (u32 i = 0; i < n; i++) s_alpha[i * 64u + lane] = ll.alpha[(rec0 + i) * 64u + lane];   // (n independent loads in flight)
-        if (lane < n) s_c[lane] = ll.cols[rec0 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (u32 i = n; i-- > 0u;) {
-            const float alpha_m = s_alpha[i * 64u + lane];
-            if (!__any(alpha_m != 0.0f)) continue;   // (no contributing pixel: backward_rasterize_kernel skips the iteration)
-            const float4 col = s_c[i];
-            const float oma = 1.0f - alpha_m;
-            T = wd_div_inrange(T, oma);
-            ll.state[(rec0 + i) * 64u + lane] = make_float4(T, ar_rg.x, ar_rg.y, ar_b);
-            ar_rg = f2{__builtin_fmaf(alpha_m, col.x, oma * ar_rg.x), __builtin_fmaf(alpha_m, col.y, oma * ar_rg.y)};
-            ar_b = __builtin_fmaf(alpha_m, col.z, oma * ar_b);
-        }
-    }
-}
-
 }  // namespace
 
 int launch_acc_clear_if_dirty(wdgs_device* dev, void* acc, u32 n, void* acc_dirty) {
@@ -658,50 +427,6 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
             WDGS_CHECK_HIP(hipGetLastError());
             return WDGS_OK;
         }
-        // WDGS_BWR_LONG=<entries> (opt-in): tile lists longer than that take the three passes of long_list_* above; 1 M records of scratch (1.3 GB)
-        static const u32 long_threshold = std::getenv("WDGS_BWR_LONG") ? (u32)std::atoi(std::getenv("WDGS_BWR_LONG")) : 0u;
-        if (long_threshold && lds_sums && !(timeline_file && !dev->capturing)) {
-            static LongLists ll = {};
-            static u32 flags_capacity = 0u;
-            if (!ll.alpha || flags_capacity < tiles) {
-                if (dev->capturing) goto no_long_lists;   // (first-use allocations do not belong in a recording: the plain path this once)
-                ll.max_items = 16384u; ll.max_blocks = 4096u;
-                if (!ll.alpha) {
-                    WDGS_TRY(wdgs_alloc((void**)&ll.counters, 16, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.items, sizeof(u32) * 4u * ll.max_items, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.blocks, sizeof(u32) * 4u * ll.max_blocks, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.nlist, sizeof(u32) * ll.max_items, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.cols, sizeof(float4) * 64u * (size_t)ll.max_items, false, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.alpha, sizeof(float) * 64u * 64u * (size_t)ll.max_items, false, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.state, sizeof(float4) * 64u * 64u * (size_t)ll.max_items, false, dev->stream));
-                }
-                if (flags_capacity < tiles) {
-                    if (ll.flags) wdgs_free(ll.flags);
-                    flags_capacity = std::max(tiles, 1u << 16);
-                    WDGS_TRY(wdgs_alloc((void**)&ll.flags, sizeof(u32) * flags_capacity, true, dev->stream));
-                }
-            }
-            ll.threshold = long_threshold;
-            WDGS_LAUNCH(dev, "long_list_build", long_list_build_kernel, dim3(1), dim3(256), 0, tiles, (const u32*)ranges, ll);
-            if (prio) {
-                WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, true, true>), dim3(slots), dim3(64), pad_lds, st, num_tiles_x, tiles,
-                            (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc,
-                            (u32*)acc_dirty, (unsigned long long*)nullptr, (const u32*)ll.flags);
-            } else {
-                WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false, true>), dim3(slots), dim3(64), pad_lds, st, num_tiles_x, tiles,
-                            (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc,
-                            (u32*)acc_dirty, (unsigned long long*)nullptr, (const u32*)ll.flags);
-            }
-            WDGS_LAUNCH(dev, "long_list_alpha", (long_list_chunk_kernel<0>), dim3(ll.max_items), dim3(64), 0, st, num_tiles_x, (const u32*)ranges, (const u32*)instances,
-                        (const u32*)splats, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, ll);
-            WDGS_LAUNCH(dev, "long_list_recurrence", long_list_recurrence_kernel, dim3(ll.max_blocks), dim3(64), 0, st, num_tiles_x, (const u32*)ranges, (const float*)final_t,
-                        (const u32*)n_contrib, ll);
-            WDGS_LAUNCH(dev, "long_list_contributions", (long_list_chunk_kernel<1>), dim3(ll.max_items), dim3(64), 0, st, num_tiles_x, (const u32*)ranges, (const u32*)instances,
-                        (const u32*)splats, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, ll);
-            WDGS_CHECK_HIP(hipGetLastError());
-            return WDGS_OK;
-        }
-    no_long_lists:
         if (lds_sums && !prio) {
             WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false>), dim3(slots), dim3(64), pad_lds, st, num_tiles_x, tiles,
                         (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc,

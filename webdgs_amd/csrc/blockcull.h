@@ -25,6 +25,7 @@ WD_DEV bool block_reaches_min_alpha(float A, float B, float C, float opacity, fl
     const float qmin = fminf(fminf(q1, q2), fminf(q3, q4));
     const float mx = fmaxf(fabsf(x0), fabsf(x1)), my = fmaxf(fabsf(y0), fabsf(y1));
     const float M = (A * mx) * mx + (2.0f * fabsf(B) * mx) * my + (C * my) * my;
+    if (!(M <= 3.0e38f)) return true;   // an infinite or NaN conic: q may be a NaN at single pixels (inf * 0), whose alpha the per-pixel test then takes as 0.99
     const float thr = 2.0f * __logf(255.0f * opacity);  // alpha >= 1/255  <=>  q <= 2 ln(255 o)
     return !(qmin > thr + (1e-3f + 1e-5f * M));         // NaN anywhere -> true
 }

@@ -153,7 +153,9 @@ void scan_scratch_destroy(ScanScratch* s);
 // Exclusive u32 scan of `count` (host-known) elements.  If total_out != nullptr, writes the grand total there.
 int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out);
 // Same, with the forward pass's stats epilogue folded into the single-block middle kernel (count must be > 0 for it to run).
-struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u32 capacity; };
+// frame (nullable): the forward pass's frame number, advanced by the scan kernel -- project.hip stamps the tiles of non-finite Splats with the number
+// the frame is ABOUT to get, so a stamp never has to be cleared (raster.hip compares)
+struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u32 capacity; u32* frame = nullptr; };
 int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep);
 
 int scan_block_sums_inplace(wdgs_device* dev, u32* block_sums, u32 num_blocks, const ScanStatsEpilogue& ep);

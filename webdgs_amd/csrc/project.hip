@@ -77,7 +77,8 @@ WD_DEV vec3 covariance2D(const Cov3D& c3, vec4 mean_view, vec2 focal, vec2 viewp
 }
 
 WD_DEV u32 ordered_uint(float x) {
-    const u32 bits = wd_f2bits(x);
+    // (a NaN depth counts as the canonical quiet NaN: which NaN an operation returns -- sign, payload -- differs between machines, and these bits are a sort key)
+    const u32 bits = (x != x) ? 0x7FC00000u : wd_f2bits(x);
     return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
@@ -103,9 +104,16 @@ WD_DEV TileBox tile_box(vec2 ndc_f16, vec2 extents_f16, vec2 viewport, u32 ntx, 
 // K1 for one Gaussian under one camera (tiled-forward.wgsl:161-294): false = culled (nothing is written); true = visible: Splat and depth
 // are written, the tile count and the box come back.  Shared by the per-view kernel and the view-batched one, so both evaluate the same
 // operations in the same order.
+// nf_stamp (nullable) / stamp: a Splat with a NaN or an infinity among its fp16 fields stamps the tiles of its box, so that the compositing kernel
+// takes those tiles in the oracle's own forms (raster.hip: EXACT) -- the fast forms assume ordinary operands.
+WD_DEV bool has_nonfinite_half(u32 a, u32 b, u32 c, u32 d, u32 e, u32 f) {
+    // a half is non-finite when its five exponent bits are all ones: (h & 0x7C00) + 0x0400 reaches bit 15 then, and only then (no carry into the other half)
+    const u32 M = 0x7C007C00u, C = 0x04000400u;
+    return ((((a & M) + C) | ((b & M) + C) | ((c & M) + C) | ((d & M) + C) | ((e & M) + C) | ((f & M) + C)) & 0x80008000u) != 0u;
+}
 WD_DEV bool project_one(u32 idx, const uint2 w01, const uint2 w23, const uint2 w45, const ShRow& sh_row, const float* __restrict__ camera_f,
                         const RenderSettings& settings, const TileInfo& ti, u32* __restrict__ splats, u32* __restrict__ depths, u32& num_tiles_out, u32& box_x0,
-                        u32& box_x1, u32& box_rows) {
+                        u32& box_x1, u32& box_rows, u32* __restrict__ nf_stamp, u32 stamp) {
     const vec4 quaternion = V4(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x), wd_unpack_lo(w23.y), wd_unpack_hi(w23.y));
     const vec3 gaussian_scale = vexp(V3(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y)));
     const vec3 pos = V3(wd_unpack_lo(w01.x), wd_unpack_hi(w01.x), wd_unpack_lo(w01.y));
@@ -163,6 +171,9 @@ WD_DEV bool project_one(u32 idx, const uint2 w01, const uint2 w23, const uint2 w
     *reinterpret_cast<uint2*>(s + 2) = o23;
     *reinterpret_cast<uint2*>(s + 4) = o45;
     depths[idx] = ordered_uint(world_to_view.z);
+    if (nf_stamp && has_nonfinite_half(o01.x, o01.y, o23.x, o23.y, o45.x, o45.y))   // (rare; every writer of a frame stores the same number)
+        for (u32 ty = tb.min_y; ty <= tb.max_y; ty++)
+            for (u32 tx = tb.min_x; tx <= tb.max_x; tx++) nf_stamp[ty * ti.num_tiles_x + tx] = stamp;
     num_tiles_out = num_tiles;
     box_x0 = tb.min_x; box_x1 = tb.max_x; box_rows = tb.max_y - tb.min_y + 1u;
     return true;
@@ -188,9 +199,11 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
                                                              u32* __restrict__ splats, u32* __restrict__ depths,
                                                              u32* __restrict__ tile_counts, u32* __restrict__ visible_shards,
                                                              u32* __restrict__ block_counts, u32* __restrict__ column_counts /*[num_tiles_x][gridDim.x]*/,
-                                                             const u32* __restrict__ dc_words /*nullable: u32[N][2], the trained SH-DC halves (adam.h)*/) {
+                                                             const u32* __restrict__ dc_words /*nullable: u32[N][2], the trained SH-DC halves (adam.h)*/,
+                                                             u32* __restrict__ nf_stamp /*nullable: u32[tiles]*/, const u32* __restrict__ nf_frame) {
     WD_STREAM_PRIO();
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 stamp = nf_stamp ? *nf_frame + 1u : 0u;   // the number the scan kernel gives this frame (scan.hip: stats_epilogue)
     bool visible = false;
     u32 num_tiles_out = 0u;
     // column_counts (nullable): tile entries of this workgroup's Gaussians per tile COLUMN -- the digit counts of the first pass of the
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256) void project_count_kernel(u32 n, const u32* __
         uint2 w01, w23, w45;
         ShRow sh_row;
         load_gaussian_and_sh(idx, gaussians, sh_buffer, dc_words, wd_to_u32(settings.sh_deg), w01, w23, w45, sh_row);
-        visible = project_one(idx, w01, w23, w45, sh_row, camera_f, settings, ti, splats, depths, num_tiles_out, box_x0, box_x1, box_rows);
+        visible = project_one(idx, w01, w23, w45, sh_row, camera_f, settings, ti, splats, depths, num_tiles_out, box_x0, box_x1, box_rows, nf_stamp, stamp);
         tile_counts[idx] = num_tiles_out;
     }
     // visible_gaussians: the reference does one atomicAdd per visible splat on ONE word (tiled-forward.wgsl:292).  Even one
@@ -242,6 +255,8 @@ struct ProjectViews {
     u32* visible_shards[WDGS_MAX_BATCH_VIEWS];
     u32* block_counts[WDGS_MAX_BATCH_VIEWS];
     u32* column_counts[WDGS_MAX_BATCH_VIEWS];   // all null or none null
+    u32* nf_stamp[WDGS_MAX_BATCH_VIEWS];        // (nullable) tiles of non-finite Splats, and each pass's frame number
+    const u32* nf_frame[WDGS_MAX_BATCH_VIEWS];
 };
 // resident waves per SIMD the register allocation of the view-batched K1 aims at (make K1V_WAVES=n: a build-time choice, for same-box comparisons)
 #ifndef WDGS_K1V_WAVES
@@ -263,7 +278,8 @@ __global__ __launch_bounds__(256, WDGS_K1V_WAVES) void project_count_views_kerne
         bool visible = false;
         u32 num_tiles_out = 0u, box_x0 = 1u, box_x1 = 0u, box_rows = 0u;
         if (idx < n) {
-            visible = project_one(idx, w01, w23, w45, sh_row, pv.camera[v], settings, ti, pv.splats[v], pv.depths[v], num_tiles_out, box_x0, box_x1, box_rows);
+            visible = project_one(idx, w01, w23, w45, sh_row, pv.camera[v], settings, ti, pv.splats[v], pv.depths[v], num_tiles_out, box_x0, box_x1, box_rows, pv.nf_stamp[v],
+                                  pv.nf_stamp[v] ? *pv.nf_frame[v] + 1u : 0u);
             pv.tile_counts[v][idx] = num_tiles_out;
         }
         if (columns)
@@ -619,24 +635,25 @@ __global__ __launch_bounds__(256) void emit_scatter_kernel(u32 n, const u32* __r
 
 int launch_project_count(wdgs_device* dev, u32 n, const void* gaussians, const void* sh, const void* camera, const RenderSettings& st,
                          const TileInfo& ti, void* splats, void* depths, void* counts, void* visible_shards, void* block_counts, void* column_counts,
-                         const void* dc_words) {
+                         const void* dc_words, void* nf_stamp, const void* nf_frame) {
     if (n == 0) return WDGS_OK;
     WDGS_LAUNCH(dev, "project_count", project_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh,
                 (const float*)camera, st, ti, (u32*)splats, (u32*)depths, (u32*)counts, (u32*)visible_shards, (u32*)block_counts, (u32*)column_counts,
-                (const u32*)dc_words);
+                (const u32*)dc_words, (u32*)nf_stamp, (const u32*)nf_frame);
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }
 
 int launch_project_count_views(wdgs_device* dev, u32 n, u32 count, const void* gaussians, const void* sh, const void* const* cameras, const RenderSettings& st,
                                const TileInfo& ti, void* const* splats, void* const* depths, void* const* counts, void* const* visible_shards, void* const* block_counts,
-                               void* const* column_counts, const void* dc_words) {
+                               void* const* column_counts, const void* dc_words, void* const* nf_stamp, const void* const* nf_frame) {
     if (n == 0 || count == 0) return WDGS_OK;
     ProjectViews pv{};
     pv.count = count;
     for (u32 v = 0; v < count; v++) {
         pv.camera[v] = (const float*)cameras[v]; pv.splats[v] = (u32*)splats[v]; pv.depths[v] = (u32*)depths[v]; pv.tile_counts[v] = (u32*)counts[v];
         pv.visible_shards[v] = (u32*)visible_shards[v]; pv.block_counts[v] = (u32*)block_counts[v]; pv.column_counts[v] = column_counts ? (u32*)column_counts[v] : nullptr;
+        pv.nf_stamp[v] = nf_stamp ? (u32*)nf_stamp[v] : nullptr; pv.nf_frame[v] = nf_frame ? (const u32*)nf_frame[v] : nullptr;
     }
     WDGS_LAUNCH(dev, "project_count_views", project_count_views_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, n, (const u32*)gaussians, (const u32*)sh, st, ti, pv,
                 (const u32*)dc_words);

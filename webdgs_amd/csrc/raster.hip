@@ -31,31 +31,20 @@ namespace {
 // see backward_raster.hip.
 // TIMELINE (measurement tool, WDGS_FWR_TIMELINE=<file>, eager launches): every wave leaves {start, end} of the 100 MHz wall clock, where it ran and how
 // many records it composited -- the format of backward_raster.hip's, read by scripts/bwr_timeline.py.
-template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE = false, bool LONGSKIP = false>
-__global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
-                                                        const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
-                                                        const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
-                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
-                                                        unsigned long long* __restrict__ timeline, const u32* __restrict__ long_flags) {
+// EXACT: the tile holds a Splat with a NaN or an infinity among its fp16 fields (project.hip marks such tiles).  The fast forms below assume
+// ordinary operands -- hardware min / max / med3 return the operand that is not a NaN, the in-range exp never sees one -- while the parity oracle
+// evaluates WGSL's own formulas (min(e1, e2) = e2 < e1 ? e2 : e1, clamp = min(max(e, lo), hi): a NaN stays a NaN) with the full exp.  EXACT takes
+// every such operation in the oracle's form, so that a tile of non-finite Splats -- what a long run of the reference's schedule collects in tile 0 --
+// composites to the same bits: a NaN alpha makes the pixel's sums NaN for good (it never saturates, n_contrib keeps following the finite alphas).
+template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE, bool LONGSKIP, bool EXACT>
+__device__ __attribute__((always_inline)) void rasterize_body(const RenderSettings& settings, const TileInfo& ti, const u32* __restrict__ splats, u32 num_splats,
+                           const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
+                           const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
+                           u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
+                           unsigned long long* __restrict__ timeline, const u32* __restrict__ long_flags, u32 tile_id, u32 sub,
+                           float4 (*s_geo_all)[65], float4 (*s_con_all)[65], float4 (*s_col_all)[65]) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
-    // (one record more than a chunk holds: the loop below reads one record ahead)
-    __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
-    __shared__ float4 s_con_all[WPW][65];  // -0.5*conic.x, -conic.y, -0.5*conic.z, opacity (Gaussian mode: see the record build below)
-    __shared__ float4 s_col_all[WPW][65];  // r, g, b, position in the tile list + 1 (bits)
-
-    // independent waves (no barrier is ever taken): one per 8x8 block
-    u32 tile_id, sub;
-    if (WPW == 4u) {
-        tile_id = blockIdx.x; sub = threadIdx.x >> 6;
-    } else {
-        // launch slots b, b + 8, ... share an XCD: slot j of XCD k is block (j & 3) of the XCD's tile number j >> 2; XCD k owns tiles k, k + 8, ...
-        const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        tile_id = k + 8u * (j >> 2);
-        sub = j & 3u;
-        if (tile_id >= ti.total_tiles) return;
-    }
-    if (LONGSKIP && ((long_flags[tile_id] >> sub) & 1u)) return;   // (a long list: long_list_* below composite and write this block)
     const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
     const u32 lane = threadIdx.x & 63u;
     const u32 slot = (WPW == 4u) ? sub : 0u;
@@ -115,7 +104,9 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
             //      only if the nearest block pixel already fails the per-pixel test |p - c| > extent, which is monotone in p)
             const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
             const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-            const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
+            // (EXACT: WGSL's min keeps a NaN extent, which then passes every "outside" test -- fminf would turn it into the cap)
+            const float ex = EXACT ? wd_min(wd_unpack_lo(w01.y), cap) : fminf(wd_unpack_lo(w01.y), cap);
+            const float ey = EXACT ? wd_min(wd_unpack_hi(w01.y), cap) : fminf(wd_unpack_hi(w01.y), cap);
             const bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
             const unsigned long long m = __ballot(ok);
             const u32 cnt = (u32)__popcll(m);
@@ -159,8 +150,13 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                         //    WGSL's clamp of a NaN alpha would give 0.
                         // G*opacity >= +0 and never NaN here (opacity in (1/128, 1], G finite), so the hardware min equals WGSL's
                         // select-based clamp, and the lower clamp is the identity and is left out.
-                        const float xc = __builtin_amdgcn_fmed3f(xe, -86.0f, 87.0f);
-                        const float alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
+                        float alpha;
+                        if (EXACT) {
+                            alpha = wd_clamp(wd_exp(xe) * con.w, 0.0f, 0.99f);   // tiled-rasterizer.wgsl:228-233 as the parity oracle evaluates it
+                        } else {
+                            const float xc = __builtin_amdgcn_fmed3f(xe, -86.0f, 87.0f);
+                            alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
+                        }
                         const float w = alpha * (1.0f - A);
                         cr = __builtin_fmaf(col.x, w, cr);
                         cg = __builtin_fmaf(col.y, w, cg);
@@ -172,6 +168,10 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                 // The records of the next iteration are fetched while this one composites: an LDS round trip (~100 cycles) is as long as
                 // an iteration's arithmetic, and read at the top of the iteration that uses them it cost a third of the wave's time in
                 // waiting.  Two iterations per trip through the loop, so that the two record sets swap roles without register copies.
+                if (EXACT) {   // (rare path: the plain loop, fewer live registers)
+#pragma unroll 1
+                    for (u32 i = 0; i < cnt; i++) composite(s_geo[i], s_con[i], s_col[i]);
+                } else {
                 float4 geo_a = s_geo[0], con_a = s_con[0], col_a = s_col[0];  // (cnt == 0: a stale record, never used)
                 for (u32 i = 0; i < cnt; i += 2u) {
                     const float4 geo_b = s_geo[i + 1u], con_b = s_con[i + 1u], col_b = s_col[i + 1u];  // (i + 1 <= 64: the spare record)
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
                     if (i + 1u >= cnt) break;
                     geo_a = s_geo[i + 2u]; con_a = s_con[i + 2u]; col_a = s_col[i + 2u];   // (i + 2 <= 64)
                     composite(geo_b, con_b, col_b);
+                }
                 }
             } else {
                 for (u32 i = 0; i < cnt; i++) {
@@ -222,197 +223,47 @@ __global__ __launch_bounds__(64 * WPW) void rasterize_kernel(RenderSettings sett
 }
 
 
-// ================================================================================================ long tile lists (opt-in: WDGS_FWR_LONG=<entries>)
-// The forward twin of backward_raster.hip's long-list passes: what compositing serialises per pixel is `w = alpha (1 - A); A += w` and the three colour FMAs.
-// Lists longer than the threshold take two passes, every operation with the operands it has in rasterize_kernel:
-//   fwd_long_alpha      per (tile block, chunk of 64 entries): the chunk's records compacted as rasterize_kernel compacts them, alpha of every (record, pixel)
-//                       (-1 where the pixel lies outside the splat's extent or the image);
-//   fwd_long_composite  per block, ONE wave: the front-to-back sums from the stored alphas; writes the block's pixels.
-struct FwdLongLists {
-    u32* counters;   // [0] items, [1] blocks
-    u32* items;      // [MAX_ITEMS][4]: tile, block, chunk (0 = front), long-block index
-    u32* blocks;     // [MAX_BLOCKS][4]: tile, block, first item, chunks
-    u32* flags;      // [tiles]: bit b = block b of the tile is on the list
-    u32* nlist;      // [MAX_ITEMS]
-    float4* cols;    // [MAX_ITEMS * 64]: r, g, b, position in the tile list + 1 (bits)
-    float* alpha;    // [MAX_ITEMS * 64][64]
-    u32 max_items, max_blocks, threshold;
-};
-
-__global__ __launch_bounds__(256) void fwd_long_build_kernel(u32 num_tiles, const u32* __restrict__ ranges, const u32* __restrict__ count_ptr, FwdLongLists ll) {
-    __shared__ u32 s_items, s_blocks;
-    if (threadIdx.x == 0u) { s_items = 0u; s_blocks = 0u; }
-    __syncthreads();
-    const u32 total = *count_ptr;
-    for (u32 t = threadIdx.x; t < num_tiles; t += 256u) {
-        const u32 a = ranges[t];
-        u32 b = ranges[t + 1u];
-        for (u32 nx = t + 1u; b == 0xFFFFFFFFu && nx < num_tiles;) { nx++; b = ranges[nx]; }
-        if (b == 0xFFFFFFFFu || b > total) b = total;
-        const u32 len = (a != 0xFFFFFFFFu && a < total && b > a) ? b - a : 0u;
-        u32 flag = 0u;
-        if (len > ll.threshold) {
-            const u32 chunks = (len + 63u) >> 6;
-            for (u32 blk = 0; blk < 4u; blk++) {
-                const u32 first = atomicAdd(&s_items, chunks);
-                const u32 lb = (first + chunks <= ll.max_items) ? atomicAdd(&s_blocks, 1u) : 0xFFFFFFFFu;
-                if (lb >= ll.max_blocks) {
-                    for (u32 c = 0; c < chunks && first + c < ll.max_items; c++) ll.items[(size_t)(first + c) * 4u] = 0xFFFFFFFFu;
-                    continue;
-                }
-                flag |= 1u << blk;
-                ll.blocks[lb * 4u + 0u] = t; ll.blocks[lb * 4u + 1u] = blk; ll.blocks[lb * 4u + 2u] = first; ll.blocks[lb * 4u + 3u] = chunks;
-                for (u32 c = 0; c < chunks; c++) {
-                    u32* it = ll.items + (size_t)(first + c) * 4u;
-                    it[0] = t; it[1] = blk; it[2] = c; it[3] = lb;
-                }
-            }
-        }
-        ll.flags[t] = flag;
+// The kernel: one wave per 8x8 block; a tile marked as holding a non-finite Splat (nf_stamp[tile] == *nf_frame: project.hip stamps the tiles of such
+// Splats with the number the frame's scan kernel then gives the frame) takes the EXACT body, every other tile the fast one.  nf_stamp == nullptr:
+// nothing is known about the Splats -- every tile takes the EXACT body.
+template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE = false, bool LONGSKIP = false>
+__global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
+                                                        const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
+                                                        const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
+                                                        u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
+                                                        unsigned long long* __restrict__ timeline, const u32* __restrict__ long_flags,
+                                                        const u32* __restrict__ nf_stamp, const u32* __restrict__ nf_frame) {
+    // (one record more than a chunk holds: the loop reads one record ahead)
+    __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
+    __shared__ float4 s_con_all[WPW][65];  // -0.5*conic.x, -conic.y, -0.5*conic.z, opacity (Gaussian mode: see the record build)
+    __shared__ float4 s_col_all[WPW][65];  // r, g, b, position in the tile list + 1 (bits)
+    // independent waves (no barrier is ever taken): one per 8x8 block
+    u32 tile_id, sub;
+    if (WPW == 4u) {
+        tile_id = blockIdx.x; sub = threadIdx.x >> 6;
+    } else {
+        // launch slots b, b + 8, ... share an XCD: slot j of XCD k is block (j & 3) of the XCD's tile number j >> 2; XCD k owns tiles k, k + 8, ...
+        const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        tile_id = k + 8u * (j >> 2);
+        sub = j & 3u;
+        if (tile_id >= ti.total_tiles) return;
     }
-    __syncthreads();
-    if (threadIdx.x == 0u) { ll.counters[0] = min(s_items, ll.max_items); ll.counters[1] = min(s_blocks, ll.max_blocks); }
+    if (LONGSKIP && ((long_flags[tile_id] >> sub) & 1u)) return;   // (a long list: long_list_* below composite and write this block)
+    const bool exact = nf_stamp == nullptr || nf_stamp[tile_id] == *nf_frame;   // (uniform per workgroup)
+    if (exact)
+        rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, LONGSKIP, true>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
+                                                                     out_ncontrib, issue_priority, timeline, long_flags, tile_id, sub, s_geo_all, s_con_all, s_col_all);
+    else
+        rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, LONGSKIP, false>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
+                                                                      out_ncontrib, issue_priority, timeline, long_flags, tile_id, sub, s_geo_all, s_con_all, s_col_all);
 }
 
-__global__ __launch_bounds__(64, 8) void fwd_long_alpha_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats, const u32* __restrict__ ranges,
-                                                              const u32* __restrict__ sorted_keys, const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr,
-                                                              u32 max_entries, FwdLongLists ll) {
-    __shared__ float4 s_geo[64], s_con[64], s_col[64];
-    const u32 item = blockIdx.x;
-    if (item >= ll.counters[0]) return;
-    const u32 tile_id = ll.items[(size_t)item * 4u], sub = ll.items[(size_t)item * 4u + 1u], chunk = ll.items[(size_t)item * 4u + 2u];
-    if (tile_id == 0xFFFFFFFFu) return;
-    const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
-    const u32 lane = threadIdx.x & 63u;
-    const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
-    const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
-    const float vx = settings.viewport_x, vy = settings.viewport_y;
-    const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
-    const bool in_bounds = pixel_x < W && pixel_y < H;
-    const float px = (float)pixel_x + 0.5f, py = (float)pixel_y + 0.5f;
-    const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
-    const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const u32 total = *count_ptr;
-    const u32 start = ranges[tile_id];
-    const u32 want_key = tile_id + 1u;
-    const u32 pos = chunk * 64u + lane, entry = start + pos;
-    const bool in_range = entry < total && (max_entries == 0u || pos < max_entries);
-    const u32 key = in_range ? sorted_keys[entry] : 0u;
-    const u32 val = in_range ? sorted_vals[entry] : 0xFFFFFFFFu;
-    const bool valid = (key >> 16u) == want_key && val < num_splats;
-    uint2 w01 = make_uint2(0u, 0u), w23 = w01, w45 = w01;
-    if (valid) {
-        const uint2* sp = reinterpret_cast<const uint2*>(splats + (size_t)val * 6);
-        w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
-    }
-    const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
-    const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
-    const float ex = fminf(wd_unpack_lo(w01.y), cap), ey = fminf(wd_unpack_hi(w01.y), cap);
-    const bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
-    const unsigned long long m = __ballot(ok);
-    const u32 cnt = (u32)__popcll(m);
-    if (ok) {
-        const u32 slot = (u32)__popcll(m & lt_mask);
-        s_geo[slot] = make_float4(cx, cy, ex, ey);
-        s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-        s_col[slot] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(chunk * 64u + lane + 1u));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0u) ll.nlist[item] = cnt;
-    const size_t rec0 = (size_t)item * 64u;
-    for (u32 i = 0; i < cnt; i++) {
-        const float4 geo = s_geo[i], con = s_con[i];
-        const float dx = px - geo.x, dy = py - geo.y;
-        const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;
-        const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
-        const float xe = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
-        const float xc = __builtin_amdgcn_fmed3f(xe, -86.0f, 87.0f);
-        const float alpha = fminf(wd_exp_inrange(xc) * con.w, 0.99f);
-        ll.alpha[(rec0 + i) * 64u + lane] = inside ? alpha : -1.0f;
-        if (lane == 0u) ll.cols[rec0 + i] = s_col[i];
-    }
-}
-
-__global__ __launch_bounds__(64) void fwd_long_composite_kernel(RenderSettings settings, TileInfo ti, u32* __restrict__ out_rgba8, float* __restrict__ out_alpha,
-                                                                 u32* __restrict__ out_ncontrib, FwdLongLists ll) {
-    __shared__ float s_alpha[64 * 64];
-    __shared__ float4 s_c[64];
-    const u32 lb = blockIdx.x;
-    if (lb >= ll.counters[1]) return;
-    const u32 tile_id = ll.blocks[lb * 4u], sub = ll.blocks[lb * 4u + 1u], first = ll.blocks[lb * 4u + 2u], chunks = ll.blocks[lb * 4u + 3u];
-    const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
-    const u32 lane = threadIdx.x & 63u;
-    const u32 pixel_x = tile_x * 16u + (sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (sub >> 1) * 8u + (lane >> 3);
-    const u32 W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
-    const bool in_bounds = pixel_x < W && pixel_y < H;
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, A = 0.0f;
-    u32 last_contributor = 0u;
-    // the alphas of chunk c + 1 travel to registers while chunk c composites (a chunk's 64 records composite faster than its loads arrive)
-    float nxt[64];
-    float4 col_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    u32 n_next = (chunks > 0u) ? ll.nlist[first] : 0u;
-    auto fetch = [&](u32 item, u32 n) {
-        const size_t r0 = (size_t)item * 64u;
-#pragma unroll
-        for (u32 i = 0; i < 64u; i++) nxt[i] = (i < n) ? ll.alpha[(r0 + i) * 64u + lane] : -1.0f;
-        col_next = (lane < n) ? ll.cols[r0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    if (chunks > 0u) fetch(first, n_next);
-    for (u32 c = 0; c < chunks; c++) {   // front chunk first, as rasterize_kernel walks
-        const u32 item = first + c;
-        const u32 n = n_next;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (u32 i = 0; i < 64u; i++) s_alpha[i * 64u + lane] = nxt[i];
-        s_c[lane] = col_next;
-        if (c + 1u < chunks) { n_next = ll.nlist[item + 1u]; fetch(item + 1u, n_next); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // (no branch, four records' operands read from LDS at once -- one LDS round trip per four records: what is serial is A -> w -> A.  An
-        // inactive pixel keeps its sums by selection, not by adding zeros: the same values whatever the record holds)
-        for (u32 i = 0; i < n; i += 4u) {
-            float a4[4];
-            float4 c4[4];
-#pragma unroll
-            for (u32 k = 0; k < 4u; k++) {
-                const u32 j = min(i + k, n - 1u);
-                a4[k] = s_alpha[j * 64u + lane];
-                c4[k] = s_c[j];
-            }
-#pragma unroll
-            for (u32 k = 0; k < 4u; k++) {
-                const float alpha = a4[k];
-                const float4 col = c4[k];
-                const bool active = (i + k < n) && !(alpha < 0.0f) && !(A > 0.99f);
-                const float w = alpha * (1.0f - A);
-                const float cr2 = __builtin_fmaf(col.x, w, cr), cg2 = __builtin_fmaf(col.y, w, cg), cb2 = __builtin_fmaf(col.z, w, cb), A2 = A + w;
-                cr = active ? cr2 : cr;
-                cg = active ? cg2 : cg;
-                cb = active ? cb2 : cb;
-                A = active ? A2 : A;
-                last_contributor = (active && alpha >= (1.0f / 255.0f)) ? __float_as_uint(col.w) : last_contributor;
-            }
-        }
-        if (!__any(in_bounds && !(A > 0.99f))) break;   // every pixel of the block saturated: nothing later can change an output
-    }
-    if (in_bounds) {
-        const size_t p = (size_t)pixel_y * W + pixel_x;
-        const u32 r8 = wd_to_u32(fminf(fmaxf(cr, 0.0f), 1.0f) * 255.0f + 0.5f);
-        const u32 g8 = wd_to_u32(fminf(fmaxf(cg, 0.0f), 1.0f) * 255.0f + 0.5f);
-        const u32 b8 = wd_to_u32(fminf(fmaxf(cb, 0.0f), 1.0f) * 255.0f + 0.5f);
-        out_rgba8[p] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
-        out_alpha[p] = 1.0f - A;
-        out_ncontrib[p] = last_contributor;
-    }
-}
 
 }  // namespace
 
 int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo& ti, const void* splats, u32 num_splats, const void* ranges,
                      const void* sorted_keys, const void* sorted_vals, const void* count_ptr, u32 max_batches, void* out_rgba8, void* out_alpha,
-                     void* out_ncontrib) {
+                     void* out_ncontrib, const void* nf_stamp, const void* nf_frame) {
     if (ti.total_tiles == 0) return WDGS_OK;
     const u32 max_entries = max_batches * 256u;  // compat cap: 32 batches x 256 splats per tile; 0 = unlimited
     // (one-wave workgroups help backward_rasterize -- 303 -> 295.5 us -- but not this kernel: 119.2 vs 119.8 us, r03m; workgroup = tile stays)
@@ -422,7 +273,7 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
     static const u32 issue_priority = (std::getenv("WDGS_FWR_PRIO") && std::getenv("WDGS_FWR_PRIO")[0] == '0') ? 0u : 1u;
     const u32 issue_priority_now = (issue_priority && slots <= 8192u) ? 1u : 0u;  // launches whose waves (4 per tile in either workgroup shape) are all resident from the start
 #define RASTER_ARGS st, ti, (const u32*)splats, num_splats, (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, \
-                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now, (unsigned long long*)nullptr, (const u32*)nullptr
+                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now, (unsigned long long*)nullptr, (const u32*)nullptr, (const u32*)nf_stamp, (const u32*)nf_frame
     // WDGS_FWR_TIMELINE=<file> (measurement tool; eager launches of the Gaussian mode in its default workgroup shape): per-wave records appended to the file
     static const char* const timeline_file = std::getenv("WDGS_FWR_TIMELINE");
     if (timeline_file && st.gaussian_mode >= 0.5f && !one_wave && !dev->capturing) {
@@ -432,7 +283,7 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
         WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
         hipLaunchKernelGGL((rasterize_kernel<true, 4u, true>), dim3(ti.total_tiles), dim3(256), 0, dev->stream, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
                            (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib,
-                           issue_priority_now, tl, (const u32*)nullptr);
+                           issue_priority_now, tl, (const u32*)nullptr, (const u32*)nf_stamp, (const u32*)nf_frame);
         std::vector<unsigned long long> host((size_t)ti.total_tiles * 16u);
         WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
         WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
@@ -440,44 +291,6 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
         if (FILE* f = std::fopen(timeline_file, "ab")) { const u32 head[2] = {ti.total_tiles * 4u, ti.total_tiles}; std::fwrite(head, 4, 2, f); std::fwrite(host.data(), 8, host.size(), f); std::fclose(f); }
         WDGS_CHECK_HIP(hipGetLastError());
         return WDGS_OK;
-    }
-    // WDGS_FWR_LONG=<entries> (opt-in; Gaussian mode, default workgroup shape): tile lists longer than that take the two passes of fwd_long_* above
-    static const u32 long_threshold = std::getenv("WDGS_FWR_LONG") ? (u32)std::atoi(std::getenv("WDGS_FWR_LONG")) : 0u;
-    if (long_threshold && st.gaussian_mode >= 0.5f && !one_wave) {
-        static FwdLongLists ll = {};
-        static u32 flags_capacity = 0u;
-        bool ready = true;
-        if (!ll.alpha || flags_capacity < ti.total_tiles) {
-            if (dev->capturing) ready = false;   // (first-use allocations do not belong in a recording: the plain path this once)
-            else {
-                ll.max_items = 16384u; ll.max_blocks = 4096u;
-                if (!ll.alpha) {
-                    WDGS_TRY(wdgs_alloc((void**)&ll.counters, 16, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.items, sizeof(u32) * 4u * ll.max_items, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.blocks, sizeof(u32) * 4u * ll.max_blocks, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.nlist, sizeof(u32) * ll.max_items, true, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.cols, sizeof(float4) * 64u * (size_t)ll.max_items, false, dev->stream));
-                    WDGS_TRY(wdgs_alloc((void**)&ll.alpha, sizeof(float) * 64u * 64u * (size_t)ll.max_items, false, dev->stream));
-                }
-                if (flags_capacity < ti.total_tiles) {
-                    if (ll.flags) wdgs_free(ll.flags);
-                    flags_capacity = std::max(ti.total_tiles, 1u << 16);
-                    WDGS_TRY(wdgs_alloc((void**)&ll.flags, sizeof(u32) * flags_capacity, true, dev->stream));
-                }
-            }
-        }
-        if (ready) {
-            ll.threshold = long_threshold;
-            WDGS_LAUNCH(dev, "fwd_long_build", fwd_long_build_kernel, dim3(1), dim3(256), 0, ti.total_tiles, (const u32*)ranges, (const u32*)count_ptr, ll);
-            WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 4u, false, true>), dim3(ti.total_tiles), dim3(256), 0, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
-                        (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib,
-                        issue_priority_now, (unsigned long long*)nullptr, (const u32*)ll.flags);
-            WDGS_LAUNCH(dev, "fwd_long_alpha", fwd_long_alpha_kernel, dim3(ll.max_items), dim3(64), 0, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
-                        (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, ll);
-            WDGS_LAUNCH(dev, "fwd_long_composite", fwd_long_composite_kernel, dim3(ll.max_blocks), dim3(64), 0, st, ti, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, ll);
-            WDGS_CHECK_HIP(hipGetLastError());
-            return WDGS_OK;
-        }
     }
     if (st.gaussian_mode >= 0.5f) {
         if (one_wave) WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);

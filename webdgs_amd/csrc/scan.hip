@@ -102,6 +102,7 @@ __device__ __forceinline__ void stats_epilogue(u32 carry, const ScanStatsEpilogu
     if (threadIdx.x == 0) {
         const u32 entries = min(carry, ep.capacity), overflow = (carry > ep.capacity) ? carry : 0u;  // consumers only touch [0, capacity)
         ep.stats[0] = entries; ep.stats[1] = vis; ep.stats[2] = overflow;
+        if (ep.frame) *ep.frame += 1u;   // the frame that project_count has just stamped its non-finite Splats' tiles with
         if (ep.host_mirror) {  // word 2 is STICKY: set on overflow, cleared only by the host check, so no view of a multi-view step can hide another's overflow
             ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; if (overflow) ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u;
         }
@@ -191,7 +192,7 @@ int forward_scan(wdgs_device* dev, u32* block_sums, u32 num_blocks, u32* column_
 }
 
 int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out) {
-    return scan_exclusive_u32_stats(dev, s, in, out, count, total_out, ScanStatsEpilogue{nullptr, nullptr, nullptr, 0u});
+    return scan_exclusive_u32_stats(dev, s, in, out, count, total_out, ScanStatsEpilogue{nullptr, nullptr, nullptr, 0u, nullptr});
 }
 
 int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep) {
