@@ -57,7 +57,8 @@ def step_differences(orc, dev, cfg, g, sh, cam, target, steps=2, pipeline_factor
             acc = harness.acc_to_reference_layout(pipe.bwd.getAccumulatorsBuffer().read(np.int32), n)
             state = pipe.read_state()
             checks = [(np.array([int(got["stats"][0])]), np.array([e]), "E", None),
-                      (got["splats"], ref["splats"], "splats", np.float16), (got["tile_counts"], ref["tile_counts"], "tile counts", None),
+                      # (a culled Gaussian's Splat is whatever an earlier step left there: only the visible rows are defined)
+                      (got["splats"][ref["tile_counts"] > 0], ref["splats"][ref["tile_counts"] > 0], "splats", np.float16), (got["tile_counts"], ref["tile_counts"], "tile counts", None),
                       (got["sorted_keys"], ref["sorted_keys"][:e], "sorted keys", None), (got["sorted_values"], ref["sorted_values"][:e], "sorted values", None),
                       (got["tile_ranges"], ref["tile_ranges"], "tile ranges", None),
                       (got["rgba8"], ref["rgba8"], "image", None), (got["final_T"], ref["final_T"], "final T", np.float32), (got["n_contrib"], ref["n_contrib"], "n_contrib", None),
@@ -95,6 +96,65 @@ def test_step_with_non_finite_gaussians(hip_device, orc, field, value):
     cfg = harness.small_config("c1", num_points=700, width=64, height=48)
     g, sh, cam = poisoned(cfg, field, value)
     rng = np.random.default_rng(5)
+    target = rng.integers(0, 255, (cfg.height, cfg.width, 4), dtype=np.uint8)
+    diffs = step_differences(orc, hip_device, cfg, g, sh, cam, target, steps=2)
+    assert not diffs, "\n".join(diffs)
+
+
+def _rows(rows):
+    """(x, y, z, opacity_raw, log_sigma) -> packed Gaussians and SH (DC only)."""
+    g = np.zeros((len(rows), 12), np.uint16)
+    sh = np.zeros((len(rows), 48), np.uint16)
+    f16 = lambda v: np.float16(v).view(np.uint16)   # noqa: E731
+    for i, (x, y, z, o, ls) in enumerate(rows):
+        g[i, 0:4] = [f16(x), f16(y), f16(z), f16(o)]
+        g[i, 4] = f16(1.0)
+        g[i, 8:11] = f16(ls)
+        sh[i, 0:3] = [f16(1.5 - (i % 7) * 0.3), f16(0.3), f16(-0.7 + (i % 5) * 0.2)]
+    return g.view(np.uint32).reshape(len(rows), 6), sh.view(np.uint32).reshape(len(rows), 24)
+
+
+def _tile_centre(cfg, tx, ty, z):
+    """World position (identity camera) that projects onto the centre of tile (tx, ty)."""
+    px, py = tx * 16 + 8.0, ty * 16 + 8.0
+    return (px - cfg.width / 2) * z / cfg.fy, (py - cfg.height / 2) * z / cfg.fy
+
+
+@pytest.mark.parametrize("kind", ["sparse", "faint", "pile-up"])
+def test_tile_lists_past_the_reference_cap(hip_device, orc, kind):
+    """One tile with more than 10 000 entries (the reference stages at most 32 x 256 = 8 192 per tile, SURVEY Q3: lifted here), one with 4 097, short
+    neighbours.  "sparse": thousands of small splats scattered over the tile -- a pixel sees few of them and never saturates, the block walks the
+    whole list; "faint": splats that cover the whole tile at an alpha near the 1/255 cut -- the pixels saturate after some hundred; "pile-up": the
+    late regime of a long run (profiles/r08g_long_list_stats.txt): ~60 real splats in front of thousands of Gaussians with NaN positions, which all
+    land in tile 0 behind them.  Two training steps against the oracle, stage by stage."""
+    cfg = harness.small_config("c1", num_points=1, width=96, height=64, fy=90.0, sh_deg=0)
+    rng = np.random.default_rng(17)
+    rows = []
+    for (tx, ty, count) in ((2, 1, 10_400), (4, 2, 4_097)):
+        for i in range(count):
+            z = 2.0 + 6.0 * rng.random()
+            cx, cy = _tile_centre(cfg, tx, ty, z)
+            if kind == "faint":   # ~40 px footprint at an opacity just above the 1/128 cull: covers the tile and its neighbours
+                rows.append((cx + rng.uniform(-2, 2) * z / cfg.fy, cy + rng.uniform(-2, 2) * z / cfg.fy, z, rng.uniform(-4.7, -4.0), np.log(0.12 * z)))
+            else:                 # footprints of a pixel or two (the 0.3 px dilation of the 2D covariance is all of it) at opacities of 1-3 %, anywhere in the tile
+                rows.append((cx + rng.uniform(-7.5, 7.5) * z / cfg.fy, cy + rng.uniform(-7.5, 7.5) * z / cfg.fy, z, rng.uniform(-4.5, -3.5), np.log(0.001 * z)))
+    for i in range(300):          # short lists everywhere
+        z = 2.0 + 6.0 * rng.random()
+        rows.append((rng.uniform(-0.5, 0.5) * z, rng.uniform(-0.33, 0.33) * z, z, rng.uniform(-1.0, 3.0), np.log(rng.uniform(0.01, 0.05) * z)))
+    g, sh = _rows(rows)
+    if kind == "pile-up":
+        gh = g.view(np.uint16).reshape(-1, 12).copy()
+        gh[60:10_400, 0:3] = NAN16       # everything of the first pile but its first 60 Gaussians
+        gh[10_400:10_400 + 4_097:3, 8:11] = NAN16
+        g = gh.view(np.uint32).reshape(-1, 6)
+    cfg = harness.small_config("c1", num_points=len(rows), width=96, height=64, fy=90.0, sh_deg=0)
+    cam = synth.identity_camera(cfg)
+    st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
+    ref = orc.forward(g, sh, cam, st, ti)
+    lens = np.bincount(ref["sorted_keys"][:ref["total_entries"]] >> 16, minlength=ti[2] + 2)[1:]
+    assert lens.max() > 10_000 and (lens > 4_096).sum() >= (1 if kind == "pile-up" else 2), np.sort(lens)[-4:]
+    if kind == "sparse":
+        assert ref["n_contrib"].max() > 8_192, "a pixel whose last contributor lies beyond the reference's 8 192-entry cap"
     target = rng.integers(0, 255, (cfg.height, cfg.width, 4), dtype=np.uint8)
     diffs = step_differences(orc, hip_device, cfg, g, sh, cam, target, steps=2)
     assert not diffs, "\n".join(diffs)
