@@ -158,3 +158,60 @@ def test_tile_lists_past_the_reference_cap(hip_device, orc, kind):
     target = rng.integers(0, 255, (cfg.height, cfg.width, 4), dtype=np.uint8)
     diffs = step_differences(orc, hip_device, cfg, g, sh, cam, target, steps=2)
     assert not diffs, "\n".join(diffs)
+
+
+def test_trainer_trajectory_with_non_finite_gaussians_equals_the_oracle_trainer(hip_device, orc):
+    """The Trainer across two densify / prune rebuilds (metric views at half resolution, decisions, the rebuilt cloud and optimizer state) on a cloud
+    in which every ninth Gaussian has a NaN or an infinity somewhere: the metric passes walk the poisoned tile lists too (K24 counts with the
+    backward's alpha test), a NaN opacity is never pruned, a NaN scale never splits."""
+    from oracle import oracle_trainer
+    from webdgs_amd import ops
+    from webdgs_amd.trainer import Trainer
+    from test_gpu_trainer_oracle import _FixedViews, _dataset, STATE_KEYS
+    dev = hip_device
+    cfg = harness.small_config("c2", num_points=5000, width=128, height=96, s0=0.01)
+    g, sh, _ = harness.scene(cfg)
+    gh = g.view(np.uint16).reshape(-1, 12).copy()
+    for k, (cols, value) in enumerate([([0, 1, 2], NAN16), ([3], NAN16), ([8, 9, 10], INF16), ([9], NAN16), ([4, 5, 6, 7], NAN16), ([2], 0xFC00)]):
+        for c in cols:
+            gh[k * 9 + 4::54, c] = value
+    g = gh.view(np.uint32).reshape(-1, 6)
+    clean, _, _ = harness.scene(cfg)
+    cams, imgs, cameras, images = _dataset(dev, orc, cfg, clean, sh, 4)
+    dens = dict(schedule=dict(enabled=True, warmupIterations=6, interval=5, stopIterations=12), metricViews=3, cloneThresholdCount=5,
+                splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300)
+    steps = 14
+    rng = np.random.default_rng(9)
+    train_views = [int(v) for v in rng.integers(0, 4, steps)]
+    metric_views = {6: [2, 0, 3], 11: [1, 1, 2]}
+    o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, list(cams), imgs, densify=dens)
+    t = Trainer(dev, seed=0)
+    t.setDensifyPruneConfig(dens)
+    t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
+    t.setDataset(cameras, images)
+    t.start()
+
+    def compare(what):
+        n = o.num_points
+        assert t.getPointCount() == n, what
+        out = [differences(t.pointCloud.gaussian_3d_buffer.read(np.uint32).reshape(-1, 6)[:n], o.g, f"{what}: gaussians", np.float16),
+               differences(t.pointCloud.sh_buffer.read(np.uint32).reshape(-1, 24)[:n], o.sh, f"{what}: sh", np.float16)]
+        bufs = t.optimizer.getStateBuffers()
+        out += [differences(bufs[k].read(np.float32).reshape(-1, width)[:n], o.state[ok], f"{what}: optimizer state {k}", np.float32) for k, (ok, width) in STATE_KEYS.items()]
+        out = [d for d in out if d]
+        assert not out, "\n".join(out)
+
+    try:
+        for i in range(steps):
+            it = i + 1
+            draws = [train_views[i]] + metric_views.get(it, [])
+            t._rng = _FixedViews(draws)
+            o.step(train_views[i], metric_view_ids=metric_views.get(it))
+            t.step()
+            compare(f"after iteration {it}")
+            if it in metric_views:
+                assert o.last_densify["rebuilt"], "the cloud was rebuilt"
+        nan_rows = np.isnan(o.g.view(np.float16).reshape(-1, 12)[:, :11].astype(np.float32)).any(axis=1).sum()
+        assert nan_rows > 300, f"non-finite Gaussians survive the rebuilds and spread ({nan_rows})"
+    finally:
+        t.destroy()
