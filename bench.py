@@ -106,10 +106,26 @@ def make_dataset(dev, cfg, tg, tsh, cams):
     return cameras, images
 
 
-def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: int = 1) -> dict:
+def longest_tile_list(trainer, cfg) -> int:
+    """Length of the longest per-tile list of the trainer's last forward pass (host evaluation of the range table)."""
+    e = int(trainer.forwardPass.check()[0])
+    r = trainer.rasterizer.getTileOffsetsBuffer().read(np.uint32, cfg.total_tiles + 1).astype(np.int64)
+    starts = r[:cfg.total_tiles]
+    used = np.flatnonzero(starts != 0xFFFFFFFF)
+    if used.size == 0:
+        return 0
+    ends = np.append(starts[used][1:], e)
+    return int((ends - starts[used]).max())
+
+
+def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: int = 1, full_steps: int = 0) -> tuple:
     """BASELINE config c3 as written -- "full train loop with densify/prune schedule": a fresh Trainer at the reference's densify
-    defaults (warm-up 500, every 100, 10 metric views at half resolution, <= 5000 new points per event), `steps` iterations
-    crossing the first densify events.  Wall clock around every step(), densify events timed separately."""
+    defaults (warm-up 500, every 100, 10 metric views at half resolution, <= 5000 new points per event).  Wall clock around every
+    step(), densify events timed separately.  Two records come out of the ONE run: `sustained`, its first `steps` iterations (620: the
+    first two densify events -- the figure earlier rounds reported), and `full_run`, the whole `full_steps` iterations (the reference's
+    default training length, trainer.ts:73: maxIterations = 10 000) with the rate per window of 1 000 iterations, the point count,
+    the tile entries and the longest tile list at each window's end -- the regime the first 620 iterations do not see (the schedule
+    thins the cloud to a few per cent and collects thousands of non-finite Gaussians in tile 0)."""
     from webdgs_amd import ops
     from webdgs_amd.trainer import Trainer
     t = Trainer(dev, seed=99, pipeline_depth=pipeline_depth)
@@ -124,7 +140,10 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: 
     start_it = t.getIteration()
     plain, events, sizes = [], [], [t.getPointCount()]
     t_all = time.perf_counter()
-    while t.getIteration() < steps:
+    sustained = None
+    windows, w_t0, w_it0, excluded = [], t_all, start_it, 0.0
+    last = max(steps, full_steps)
+    while t.getIteration() < last:
         before = t.getLastDensifyPruneIteration()
         t0 = time.perf_counter()
         t.step()
@@ -134,20 +153,43 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: 
             sizes.append(t.getPointCount())
         else:
             plain.append(dt)
+        it = t.getIteration()
+        if it == steps and sustained is None:
+            t.drain()
+            dev.synchronize()
+            total = time.perf_counter() - t_all - excluded
+            n_steps = it - start_it
+            # the steps right after a rebuild re-record their command buffers: count them with the event that caused them
+            med = float(np.median(plain)) if plain else 0.0
+            rerecord = float(sum(d - med for d in plain if d > 4.0 * med))
+            sustained = dict(steps=n_steps, crosses_iterations=[start_it, it], iters_per_s_overall=round(n_steps / total, 2),
+                             iters_per_s_steady=round(1.0 / med, 2) if med > 0 else None, ms_per_step_median=round(med * 1e3, 4), densify_events=len(events),
+                             ms_per_densify_event=round((sum(events) + rerecord) / max(1, len(events)) * 1e3, 2) if events else None,
+                             ms_per_densify_event_excluding_rerecording=round(float(np.mean(events)) * 1e3, 2) if events else None,
+                             points=list(sizes), pipeline_depth=pipeline_depth,
+                             schedule="reference defaults: warm-up 500, interval 100, 10 metric views at 1/2 resolution, maxNewPointsPerStep 5000")
+        if full_steps and (it % 1000 == 0 or it == last) and it > w_it0:
+            t.drain()
+            dev.synchronize()
+            now = time.perf_counter()
+            tq = time.perf_counter()
+            e_now = int(t.forwardPass.check()[0])
+            windows.append(dict(to_iteration=it, iters_per_s=round((it - w_it0) / (now - w_t0), 1), points=t.getPointCount(), tile_entries_E=e_now,
+                                longest_tile_list=longest_tile_list(t, cfg)))
+            spent = time.perf_counter() - tq   # (the read-backs of the window record are not training time)
+            excluded += spent
+            w_t0, w_it0 = time.perf_counter(), it
     t.drain()
     dev.synchronize()
-    total = time.perf_counter() - t_all
-    n_steps = t.getIteration() - start_it
-    # the steps right after a rebuild re-record their command buffers: count them with the event that caused them
-    med = float(np.median(plain)) if plain else 0.0
-    rerecord = float(sum(d - med for d in plain if d > 4.0 * med))
-    out = dict(steps=n_steps, crosses_iterations=[start_it, t.getIteration()], iters_per_s_overall=round(n_steps / total, 2),
-               iters_per_s_steady=round(1.0 / med, 2) if med > 0 else None, ms_per_step_median=round(med * 1e3, 4), densify_events=len(events),
-               ms_per_densify_event=round((sum(events) + rerecord) / max(1, len(events)) * 1e3, 2) if events else None,
-               ms_per_densify_event_excluding_rerecording=round(float(np.mean(events)) * 1e3, 2) if events else None,
-               points=sizes, pipeline_depth=pipeline_depth, schedule="reference defaults: warm-up 500, interval 100, 10 metric views at 1/2 resolution, maxNewPointsPerStep 5000")
+    full = None
+    if full_steps:
+        total = time.perf_counter() - t_all - excluded
+        med_late = float(np.median(plain[-500:])) if plain else 0.0
+        full = dict(iterations=t.getIteration() - start_it, iters_per_s_overall=round((t.getIteration() - start_it) / total, 2), seconds=round(total, 2),
+                    densify_events=len(events), ms_per_step_median_last_500=round(med_late * 1e3, 4), windows=windows, final_points=t.getPointCount(),
+                    pipeline_depth=pipeline_depth, note="BASELINE c3 as written, for the reference's default training length (trainer.ts:73: maxIterations = 10 000)")
     t.destroy()
-    return out
+    return sustained, full
 
 
 def run_batched_step(dev, cfg, g, sh, tg, tsh, args, views_per_step: int = 8) -> dict:
@@ -191,6 +233,8 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=0, help="device lanes a batched step deals its views to (0 = the Trainer's default; 1 = no overlap)")
     ap.add_argument("--views-per-rank", type=int, default=0, help="views per rank per global step (default: 1 at N = 1, 8 at N > 1)")
     ap.add_argument("--sustained-steps", type=int, default=620, help="N = 1: length of the densify-inclusive leg (0 = skip)")
+    ap.add_argument("--full-run-steps", type=int, default=10_000, help="N = 1: the sustained leg goes on to this many iterations -- the reference's default training "
+                    "length -- and reports the rate per window of 1 000 iterations (`full_run`; 0 = stop at --sustained-steps)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the K-step block is repeated until this much time has been timed; the MEDIAN block is reported (0 = one block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the eager per-kernel pass (roofline becomes null)")
@@ -622,13 +666,14 @@ def main() -> None:
             solo.destroy()
         parallel.barrier()
 
-    sustained = cpu_baseline = batched = None
+    sustained = cpu_baseline = batched = full_run = None
     if rank == 0 and world == 1:
         trainer.destroy()
         if vpr == 1 and not args.no_batched_step and args.config in ("c3", "c3-small", "c2"):
             batched = run_batched_step(dev, cfg, g, sh, tg, tsh, args)
         if args.sustained_steps > 0 and args.config in ("c3", "c3-small", "c2"):
-            sustained = run_sustained(dev, cfg, g, sh, cameras, images, args.sustained_steps, args.pipeline_depth)
+            sustained, full_run = run_sustained(dev, cfg, g, sh, cameras, images, args.sustained_steps, args.pipeline_depth,
+                                                full_steps=args.full_run_steps)
         if not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(cfg, g, sh, cams[0], args.cpu_baseline_points)
 
@@ -653,6 +698,9 @@ def main() -> None:
             "scaling_efficiency": round(value / (world * same_step["views_per_s"]), 4) if same_step else None,
             # BASELINE c3 as written ("full train loop with densify/prune schedule"): the densify-inclusive rate of the `sustained` leg
             "c3_as_written_iters_per_s": sustained["iters_per_s_overall"] if sustained else None,
+            # ... and the same run carried on to the reference's default training length (10 000 iterations): rate per 1 000-iteration window
+            "c3_full_run_iters_per_s": full_run["iters_per_s_overall"] if full_run else None,
+            "full_run": full_run,
             "config": {"workload": f"{cfg.name}: {n} Gaussians, {cfg.width}x{cfg.height}, SH deg {cfg.sh_deg}, fwd+bwd per view, {n_dataset} circle views"
                                    + (" (BASELINE c3: the reference's one-view step)" if views_per_step == 1 else f" (BASELINE c4 shape: {vpr} views per rank per global step)"),
                        "views_per_rank": vpr, "global_batch_views": views_per_step, "lanes": lanes,

@@ -180,6 +180,27 @@ def test_single_gpu_bench_line_carries_the_batched_step_base(tmp_path):
     assert "geometry_backward_adam" in out["kernel_ms_per_view"] and out["kernel_ms_per_step"] == {}, "the one-view step has no per-step kernels"
 
 
+def test_single_gpu_bench_line_carries_the_full_run(tmp_path):
+    """the driver-visible record holds the run BEYOND the first two densify events -- the sustained leg carried on to
+    --full-run-steps (default: the reference's 10 000) with the rate, the point count, the tile entries and the longest tile list per window
+    of 1 000 iterations.  Here c2 for 1 200 iterations (windows end at 1 000 and 1 200)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_BENCH_WATCHDOG="500")
+    root = os.path.dirname(HERE)
+    r = _run_child([sys.executable, os.path.join(root, "bench.py"), "--config", "c2", "--steps", "6", "--warmup", "2", "--min-seconds", "0.05", "--sustained-steps", "620",
+                    "--full-run-steps", "1200", "--no-cpu-baseline", "--no-batched-step"], env, 560)
+    assert r.returncode == 0, _verdict(r)
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    s, f = out["sustained"], out["full_run"]
+    assert s["crosses_iterations"][1] == 620 and s["densify_events"] == 2 and out["c3_as_written_iters_per_s"] == s["iters_per_s_overall"]
+    assert f["iterations"] == 1200 - s["crosses_iterations"][0] and f["densify_events"] == 8 and out["c3_full_run_iters_per_s"] == f["iters_per_s_overall"] > 0
+    assert [w["to_iteration"] for w in f["windows"]] == [1000, 1200]
+    for w in f["windows"]:
+        assert w["iters_per_s"] > 0 and w["points"] > 0 and w["tile_entries_E"] > 0 and 0 < w["longest_tile_list"] <= w["tile_entries_E"]
+    assert f["final_points"] == f["windows"][-1]["points"]
+
+
 def _visible_gpus() -> int:
     import torch
     return torch.cuda.device_count()
