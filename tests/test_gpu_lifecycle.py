@@ -112,3 +112,43 @@ def test_freed_blocks_are_kept_by_size_class_and_handed_out_again(hip_device):
     assert pc not in (pa, pb)
     check(lib.wdgs_buffer_destroy(b)); check(lib.wdgs_buffer_destroy(c))
     dev.synchronize()
+
+
+def test_a_block_freed_with_work_in_flight_is_not_handed_out_before_that_work_completes(hip_device):
+    """VERDICT r4 item 5.  Lane 1 is given ~40 copies of a 256 MB pattern into block A; while they run, A is destroyed and a buffer of the same size
+    class is created and filled with another pattern on lane 0.  The cache hands A's block out again (same pointer) -- but only behind a device-wide
+    wait, because A was freed after the device's last synchronisation: the new buffer must read back ITS pattern.  (Handed out at once, lane 1's
+    remaining copies would land on top of it.)"""
+    import ctypes as C
+    from webdgs_amd._lib import check
+    dev = hip_device
+    lib = dev.lib
+    size = 256 << 20
+
+    def create(nbytes):
+        h = C.c_void_p()
+        check(lib.wdgs_buffer_create(dev.handle, C.c_size_t(nbytes), C.byref(h)))
+        return h, int(lib.wdgs_buffer_ptr(h))
+
+    one = dev.bufferFrom(np.full(size // 4, 0x11111111, np.uint32))
+    two = dev.bufferFrom(np.full(size // 4, 0x22222222, np.uint32))
+    dev.synchronize()
+    a, pa = create(size)
+    try:
+        dev.selectLane(1)
+        for _ in range(40):
+            check(lib.wdgs_copy_buffer_to_buffer(dev.handle, C.c_void_p(pa), C.c_void_p(one.ptr), C.c_size_t(size)))
+        dev.selectLane(0)
+        check(lib.wdgs_buffer_destroy(a))          # lane 1 is still copying into it
+        b, pb = create(size)
+        check(lib.wdgs_copy_buffer_to_buffer(dev.handle, C.c_void_p(pb), C.c_void_p(two.ptr), C.c_size_t(size)))
+        dev.synchronize()
+        back = np.empty(size // 4, np.uint32)
+        check(lib.wdgs_copy_to_host(dev.handle, back.ctypes.data_as(C.c_void_p), C.c_void_p(pb), C.c_size_t(size)))
+        assert pb == pa, "the freed block was handed out again (same size class, nothing else waiting there)"
+        assert (back == 0x22222222).all(), "lane 1's copies into the freed block had finished before the block was handed out"
+        check(lib.wdgs_buffer_destroy(b))
+    finally:
+        dev.selectLane(0)
+        dev.synchronize()
+        one.destroy(); two.destroy()

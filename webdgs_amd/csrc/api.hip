@@ -10,6 +10,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include "alloc_cache.h"
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
 int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*, void*,
@@ -81,36 +82,36 @@ void wdgs_set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- device memory
-// hipFree is not cheap everywhere: with the ROCm 7.2 runtime a host links against (node's addon, a C++ host) one call takes ~100 us on an idle
-// device, with the 7.0 runtime PyTorch brings along ~1 us (profiles/r06s_free_cost.txt) -- and a densify event frees and allocates a cloud, six state
-// arrays and the densify scratch (3.5 ms of a 9 ms event in the node host).  Freed blocks are therefore kept, by size class (eighth-of-a-power-of-two
-// steps: a cloud that changed by a few per cent lands in its old class), and handed out again.  A block may still be in use by queued work when it is
-// freed, so one that has not seen a hipDeviceSynchronize since (`freed_epoch`: every stream of the process, a torch or RCCL side stream included) is only reused behind one.  WDGS_ALLOC_CACHE=0: plain hipMalloc /
-// hipFree.  The cache holds at most a quarter of the device's memory; wdgs_device_destroy empties it.
+// Freed blocks are kept by size class and handed out again (alloc_cache.h: why, and the per-device epochs that say when a freed block is safe).
+// WDGS_ALLOC_CACHE=0: plain hipMalloc / hipFree.  The cache holds at most a quarter of the device's memory; wdgs_device_destroy empties it.
 namespace {
-struct CachedBlock { void* p; int device; unsigned long long freed_epoch; };
-struct LiveBlock { size_t rounded; int device; };
-std::mutex g_alloc_mutex;
-std::unordered_map<void*, LiveBlock> g_live_blocks;
-std::multimap<size_t, CachedBlock> g_cached_blocks;   // by size class
-size_t g_cached_bytes = 0, g_cache_limit = 0;
-unsigned long long g_sync_epoch = 1;   // (guarded by g_alloc_mutex)
+struct HipBackend {
+    void* malloc(int device, size_t bytes) {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+        if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (cur != device) (void)hipSetDevice(cur);
+        if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void free(void* p) { (void)hipFree(p); }
+    bool sync(int device) {   // every stream of the process on that device, a torch or RCCL side stream included
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return false;
+        if (cur != device && hipSetDevice(device) != hipSuccess) return false;
+        const hipError_t e = hipDeviceSynchronize();
+        if (cur != device) (void)hipSetDevice(cur);
+        return e == hipSuccess;
+    }
+};
+wdgs::AllocCache<HipBackend> g_alloc_cache;
+size_t g_cache_limit = 0;
+std::mutex g_cache_limit_mutex;
 bool alloc_cache_enabled() {
     static const bool on = !(std::getenv("WDGS_ALLOC_CACHE") && std::getenv("WDGS_ALLOC_CACHE")[0] == '0');
     return on;
-}
-size_t size_class(size_t bytes) {
-    if (bytes <= 4096) return 4096;
-    size_t pow2 = 4096;
-    while (pow2 * 2 <= bytes) pow2 *= 2;
-    const size_t step = pow2 / 8;
-    return (bytes + step - 1) / step * step;
-}
-void release_cached_blocks(int device) {
-    std::lock_guard<std::mutex> lock(g_alloc_mutex);
-    for (auto it = g_cached_blocks.begin(); it != g_cached_blocks.end();) {
-        if (it->second.device == device) { (void)hipFree(it->second.p); g_cached_bytes -= it->first; it = g_cached_blocks.erase(it); } else ++it;
-    }
 }
 }  // namespace
 
@@ -120,42 +121,13 @@ int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream) {
     if (!alloc_cache_enabled()) {
         WDGS_CHECK_HIP(hipMalloc(p, bytes));
     } else {
-        const size_t rounded = size_class(bytes);
         int device = 0;
         WDGS_CHECK_HIP(hipGetDevice(&device));
-        bool need_sync = false;
         // (an allocation while `stream` records -- relaxed capture allows hipMalloc -- cannot synchronise the device: it only takes blocks that need no wait)
         hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
         const bool recording = stream && hipStreamIsCapturing(stream, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
-        {
-            std::lock_guard<std::mutex> lock(g_alloc_mutex);
-            auto range = g_cached_blocks.equal_range(rounded);
-            for (auto it = range.first; it != range.second; ++it)
-                if (it->second.device == device && !(recording && it->second.freed_epoch == g_sync_epoch)) {
-                    *p = it->second.p;
-                    need_sync = it->second.freed_epoch == g_sync_epoch;
-                    g_cached_bytes -= rounded;
-                    g_cached_blocks.erase(it);
-                    break;
-                }
-        }
-        if (*p && need_sync) {   // freed since the last full synchronisation: queued work may still touch it
-            const hipError_t e = hipDeviceSynchronize();
-            if (e != hipSuccess) { (void)hipFree(*p); *p = nullptr; WDGS_CHECK_HIP(e); }
-            std::lock_guard<std::mutex> lock(g_alloc_mutex);
-            g_sync_epoch++;
-        }
-        if (!*p) {
-            hipError_t e = hipMalloc(p, rounded);
-            if (e != hipSuccess) {   // make room: what the cache holds is this device's memory too
-                (void)hipGetLastError();
-                release_cached_blocks(device);
-                e = hipMalloc(p, rounded);
-            }
-            WDGS_CHECK_HIP(e);
-        }
-        std::lock_guard<std::mutex> lock(g_alloc_mutex);
-        g_live_blocks[*p] = LiveBlock{rounded, device};
+        *p = g_alloc_cache.alloc(device, bytes, !recording);
+        WDGS_REQUIRE(*p, WDGS_E_HIP, "device allocation of %zu bytes failed (device %d)", bytes, device);
     }
     if (zero) WDGS_CHECK_HIP(hipMemsetAsync(*p, 0, bytes, stream));
     return WDGS_OK;
@@ -164,21 +136,16 @@ int wdgs_alloc(void** p, size_t bytes, bool zero, hipStream_t stream) {
 void wdgs_free(void* p) {
     if (!p) return;
     if (alloc_cache_enabled()) {
-        std::lock_guard<std::mutex> lock(g_alloc_mutex);
-        auto it = g_live_blocks.find(p);
-        if (it != g_live_blocks.end()) {
-            const LiveBlock b = it->second;
-            g_live_blocks.erase(it);
+        size_t limit;
+        {
+            std::lock_guard<std::mutex> lock(g_cache_limit_mutex);
             if (g_cache_limit == 0) {
                 size_t free_b = 0, total_b = 0;
                 g_cache_limit = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) ? total_b / 4 : ((size_t)8 << 30);
             }
-            if (g_cached_bytes + b.rounded <= g_cache_limit) {
-                g_cached_blocks.emplace(b.rounded, CachedBlock{p, b.device, g_sync_epoch});
-                g_cached_bytes += b.rounded;
-                return;
-            }
+            limit = g_cache_limit;
         }
+        if (g_alloc_cache.free(p, limit)) return;
     }
     (void)hipFree(p);
 }
@@ -467,12 +434,7 @@ int wdgs_device_memory_info(wdgs_device* d, size_t* free_bytes, size_t* total_by
     WDGS_CHECK_HIP(hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
-    if (cached_bytes) {
-        std::lock_guard<std::mutex> lock(g_alloc_mutex);
-        size_t c = 0;
-        for (const auto& kv : g_cached_blocks) if (kv.second.device == d->ordinal) c += kv.first;
-        *cached_bytes = c;
-    }
+    if (cached_bytes) *cached_bytes = g_alloc_cache.held(d->ordinal);
     return WDGS_OK;
 }
 static void reap_command_buffers(wdgs_device* d, size_t at_most);   // (defined with the command buffers, below)
@@ -492,7 +454,7 @@ int wdgs_device_destroy(wdgs_device* d) {
     (void)wdgs_sync_lanes(d);
     collect_profile(d);
     reap_command_buffers(d, (size_t)-1);
-    release_cached_blocks(d->ordinal);
+    g_alloc_cache.release(d->ordinal);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lane_events) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lane_marks) if (e) (void)hipEventDestroy(e);
@@ -603,8 +565,8 @@ int wdgs_queue_submit(wdgs_device* d, wdgs_command_buffer* cmd) {
                      "wdgs_queue_submit: the command buffer starts at the scan of a projected forward pass (wdgs_tiled_forward_encode_projected), but the pass holds no "
                      "projection: run wdgs_tiled_forward_project_views before every submit, and no other encode of the pass in between");
     }
-    for (wdgs_tiled_forward* f : c->consumes) forward_consume_projection(f);
     WDGS_CHECK_HIP(hipGraphLaunch(c->exec, d->stream));
+    for (wdgs_tiled_forward* f : c->consumes) forward_consume_projection(f);   // (only a replay that was really enqueued uses the projections up)
     reap_command_buffers(d, 1);   // (behind the launch: the device is busy with it while the host pays)
     return WDGS_OK;
 }
