@@ -133,6 +133,13 @@ def test_a_block_freed_with_work_in_flight_is_not_handed_out_before_that_work_co
     one = dev.bufferFrom(np.full(size // 4, 0x11111111, np.uint32))
     two = dev.bufferFrom(np.full(size // 4, 0x22222222, np.uint32))
     dev.synchronize()
+    held = []   # whatever already waits in this size class is taken out of the way, so that the freed block is the only candidate
+    while len(held) < 16:
+        before = dev.memoryInfo()["cached"]
+        h, _ = create(size)
+        held.append(h)
+        if dev.memoryInfo()["cached"] == before:
+            break
     a, pa = create(size)
     try:
         dev.selectLane(1)
@@ -151,4 +158,6 @@ def test_a_block_freed_with_work_in_flight_is_not_handed_out_before_that_work_co
     finally:
         dev.selectLane(0)
         dev.synchronize()
+        for h in held:
+            check(lib.wdgs_buffer_destroy(h))
         one.destroy(); two.destroy()
