@@ -106,16 +106,21 @@ def make_dataset(dev, cfg, tg, tsh, cams):
     return cameras, images
 
 
-def longest_tile_list(trainer, cfg) -> int:
-    """Length of the longest per-tile list of the trainer's last forward pass (host evaluation of the range table)."""
+def probe_tile_lists(trainer, cfg, camera) -> tuple:
+    """(tile entries E, length of the longest per-tile list) of the cloud as it is now under `camera`: one eager forward pass through the trainer's
+    own passes (a preview render, as the reference's API allows between steps) and a host evaluation of its range table.  Not training time."""
+    trainer.flushPointCloud()
+    trainer.cameraBuffer.write(camera)
+    trainer.forwardPass.encode(None)
+    trainer.rasterizer.encode(None, cfg.width, cfg.height)
     e = int(trainer.forwardPass.check()[0])
     r = trainer.rasterizer.getTileOffsetsBuffer().read(np.uint32, cfg.total_tiles + 1).astype(np.int64)
     starts = r[:cfg.total_tiles]
     used = np.flatnonzero(starts != 0xFFFFFFFF)
     if used.size == 0:
-        return 0
+        return e, 0
     ends = np.append(starts[used][1:], e)
-    return int((ends - starts[used]).max())
+    return e, int((ends - starts[used]).max())
 
 
 def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: int = 1, full_steps: int = 0) -> tuple:
@@ -173,9 +178,9 @@ def run_sustained(dev, cfg, g, sh, cameras, images, steps: int, pipeline_depth: 
             dev.synchronize()
             now = time.perf_counter()
             tq = time.perf_counter()
-            e_now = int(t.forwardPass.check()[0])
+            e_now, longest = probe_tile_lists(t, cfg, cameras[0]["camera"])
             windows.append(dict(to_iteration=it, iters_per_s=round((it - w_it0) / (now - w_t0), 1), points=t.getPointCount(), tile_entries_E=e_now,
-                                longest_tile_list=longest_tile_list(t, cfg)))
+                                longest_tile_list=longest))
             spent = time.perf_counter() - tq   # (the read-backs of the window record are not training time)
             excluded += spent
             w_t0, w_it0 = time.perf_counter(), it

@@ -561,6 +561,25 @@ class Trainer {
     this.stateSliced = false;
   }
 
+  /** The capacity report of this rank's metric forward passes (their sticky words are consumed), or null.  Synchronises. */
+  metricOverflow() {
+    let found = null;
+    for (const fw of [this.metricsForwardPass].concat(this.moreMetricSets.map((m) => m[0]))) {
+      if (!fw) continue;
+      try { fw.check(); } catch (e) { if (e && e.code === 'WDGS_E_CAPACITY') found = found || e; else throw e; }
+    }
+    return found;
+  }
+
+  /** true on every rank if `flag` is true on any: one u32 summed over the ranks on the device and read back (only inside a densify event). */
+  agree(flag) {
+    if (this.worldSize <= 1) return !!flag;
+    if (!this.agreeWord) this.agreeWord = this.device.createBuffer({ size: 4, label: 'agreement word' });
+    this.device.queue.writeBuffer(this.agreeWord, 0, new Uint32Array([flag ? 1 : 0]));
+    this.exchange.allreduceCounts(this.agreeWord, 1);
+    return new Uint32Array(this.agreeWord.read(4))[0] !== 0;   // (read: an ArrayBuffer)
+  }
+
   /** trainer.ts:373-497 */
   async runDensifyPruneMultiView() {
     if (!this.pointCloud || !this.optimizer || this.trainCameras.length === 0 || this.images.length === 0) return;
@@ -604,7 +623,18 @@ class Trainer {
       for (let k = 1; k < Math.min(L, taken); k++) dev.laneOrder(0, k);   // join: normalize / prepare / the exchange follow every lane
     }
     if (usedViews === 0) return;
-    if (this.worldSize > 1) this.exchange.allreduceCounts(this.metricsPass.getMetricCountsBuffer(), this.pointCloud.num_points);   // u32 sum, in place
+    if (this.worldSize > 1) {
+      // A metric pass whose tile-entry list overflowed has counted a truncated view: the event is void -- on EVERY rank (the views are sharded, so one
+      // rank alone may overflow; were it to bail out while its peers rebuild the cloud, the replicas would part and the next exchange hang).  Each rank
+      // looks at its own metric passes, the flags are summed over the ranks, all skip the event together before any count has been exchanged; a rank
+      // that overflowed throws on the way out, which makes step() enlarge its lists.
+      const overflow = this.metricOverflow();
+      if (this.agree(overflow !== null)) {
+        if (overflow !== null) throw overflow;
+        return;
+      }
+      this.exchange.allreduceCounts(this.metricsPass.getMetricCountsBuffer(), this.pointCloud.num_points);   // u32 sum, in place
+    }
     this.metricsPass.normalizeMetricCounts(encoder, { divisor: usedViews });
     this.densifyPrune.ensureSize(this.pointCloud.num_points);
     const prepared = this.densifyPrune.encodePrepare(encoder, { pointCloud: this.pointCloud, metricCountsBuffer: this.metricsPass.getMetricCountsBuffer() });
@@ -645,7 +675,7 @@ class Trainer {
     this.cameraBuffers = [];
     for (const t of this.ownedTextures || []) t.destroy();
     this.ownedTextures = [];
-    for (const name of ['dpGrad', 'dpVisible', 'dpRows', 'dpFlag', 'metricsTarget']) { if (this[name]) this[name].destroy(); this[name] = null; }
+    for (const name of ['dpGrad', 'dpVisible', 'dpRows', 'dpFlag', 'metricsTarget', 'agreeWord']) { if (this[name]) this[name].destroy(); this[name] = null; }
     this.metricsCameraBuffer.destroy();
     this.isTraining = false;
   }

@@ -36,14 +36,23 @@ def main():
     else:
         cfg, g, sh, cameras, images = dp_common.dataset(dev)
     t = Trainer(dev, seed=11, world_size=world, rank=rank, views_per_rank=vpr, use_command_buffers=use_cb)
-    t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
+    metric_overflow = os.environ.get("WDGS_DP_TEST_METRIC_OVERFLOW") == "1"
+    if metric_overflow:
+        # densify events at iterations 3 and 6; rank 1 builds its metric passes (first use: the event at 3) around lists of 4 096 entries, which
+        # the half-resolution metric views overflow: the event must be void on BOTH ranks, rank 1 enlarges its lists, the event at 6 rebuilds the cloud
+        import warnings
+        warnings.simplefilter("always")
+        t.setDensifyPruneConfig(dict(schedule=dict(enabled=True, warmupIterations=3, interval=3, stopIterations=100), metricViews=4, cloneThresholdCount=3,
+                                     splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300))
+    else:
+        t.setDensifyPruneConfig(dict(schedule=dict(enabled=False)))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
     t.start()
     import torch
     schedule = [[r % 2 for r in range(world * vpr)] for _ in range(steps)] if overflow else dp_common.view_schedule(steps, world, vpr)
-    grown = []
-    if overflow:
+    grown, events = [], []
+    if overflow or metric_overflow:
         import warnings
         _show = warnings.showwarning
         warnings.showwarning = lambda message, *a, **k: (grown.append(str(message)), _show(message, *a, **k))
@@ -54,7 +63,10 @@ def main():
         if i == 2 and os.environ.get("WDGS_DP_TEST_WARMUP") == "1":
             # by now the ranks have recorded DIFFERENT views; the warm-up must still take the same number of (collective) steps on each
             t.warmupCommandBuffers()
+        if metric_overflow and i == 2 and rank == 1:
+            t._grown_tile_entries = 4096   # what the metric passes, built inside this step's densify event, size their lists with
         t.step(ids)
+        events.append(t.getLastDensifyPruneIteration() or 0)
     dev.synchronize()
     own_first, own_count = parallel.owned_range(t.pointCloud.num_points, world, rank)
     stale = t.optimizer.getStateBuffers()["optPosBuffer"].read(np.uint32).copy()  # before the gather: only the own slice is current
@@ -64,7 +76,7 @@ def main():
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gaussians=t.pointCloud.gaussian_3d_buffer.read(np.uint32),
              sh=t.pointCloud.sh_buffer.read(np.uint32), iteration=np.array([t.optimizer.getIteration()]), own=np.array([own_first, own_count]),
              stale_pos=stale, grown=np.array([sum("tile-entry lists grown" in m for m in grown)]), host_iteration=np.array([t.getIteration()]),
-             cap=np.array([int(t.forwardPass.getResources()["maxTileEntries"])]), **{"state_" + k: v for k, v in st.items()})
+             cap=np.array([int(t.forwardPass.getResources()["maxTileEntries"])]), events=np.array(events), points=np.array([t.getPointCount()]), **{"state_" + k: v for k, v in st.items()})
     parallel.barrier()
     t.destroy()
     dev.destroy()

@@ -180,6 +180,27 @@ def test_single_gpu_bench_line_carries_the_batched_step_base(tmp_path):
     assert "geometry_backward_adam" in out["kernel_ms_per_view"] and out["kernel_ms_per_step"] == {}, "the one-view step has no per-step kernels"
 
 
+def test_a_metric_pass_that_overflows_on_one_rank_voids_the_densify_event_on_every_rank(hip_device, tmp_path):
+    """the metric views of a densify event are sharded over the ranks, so one rank alone may overflow a metric pass's tile-entry list.
+    Its counts are then worthless -- and were that rank to bail out while its peer rebuilds the cloud, the replicas would hold clouds of different
+    sizes and the next exchange would hang.  The ranks agree (one summed word) before any count is exchanged: the event at iteration 3 is void on
+    both, rank 1 enlarges its lists, the event at 6 rebuilds the cloud on both, and the replicas stay identical."""
+    steps = 7
+    env = dict(os.environ, WDGS_DIST_BACKEND="gloo", WDGS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", WDGS_DP_TEST_METRIC_OVERFLOW="1")
+    r = _run_with_fresh_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(HERE, "dp_worker.py"), str(tmp_path), str(steps), "0"], env))
+    assert r.returncode == 0, _verdict(r)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(2)]
+    for k in ranks:
+        assert list(k["events"]) == [0, 0, 0, 0, 0, 6, 6], f"no rebuild at iteration 3, one at 6: {list(k['events'])}"
+    assert int(ranks[0]["grown"][0]) == 0 and int(ranks[1]["grown"][0]) == 1, "only the rank whose metric pass overflowed enlarged its lists"
+    assert int(ranks[0]["points"][0]) == int(ranks[1]["points"][0]) != 6000, "both rebuilt the cloud, to the same size"
+    assert_bits_equal(ranks[0]["gaussians"], ranks[1]["gaussians"], "replica gaussians")
+    assert_bits_equal(ranks[0]["sh"], ranks[1]["sh"], "replica sh")
+    for k in ("optPosBuffer", "optRotBuffer", "optScaleBuffer", "optOpacityBuffer", "paramSH", "stateSH"):
+        assert_bits_equal(ranks[0]["state_" + k], ranks[1]["state_" + k], f"replica state {k}")
+
+
 def test_single_gpu_bench_line_carries_the_full_run(tmp_path):
     """the driver-visible record holds the run BEYOND the first two densify events -- the sustained leg carried on to
     --full-run-steps (default: the reference's 10 000) with the rate, the point count, the tile entries and the longest tile list per window

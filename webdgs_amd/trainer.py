@@ -117,6 +117,7 @@ class Trainer:
         self._dp_visible: Optional[ops.HipBuffer] = None
         self._dp_rows: Optional[ops.HipBuffer] = None
         self._dp_flag: Optional[ops.HipBuffer] = None
+        self._agree_word: Optional[ops.HipBuffer] = None
         self._state_sliced = False  # optimizer state of non-owned slices is stale until syncOptimizerState()
         self.exchange_timing = False  # bracket the collectives with events on the device stream (bench.py)
         self._exchange_events: list = []
@@ -702,6 +703,29 @@ class Trainer:
         self._exchange_events = []
         return float(ms)
 
+    def _metric_overflow(self):
+        """The capacity report of this rank's metric forward passes (their sticky words are consumed), or None.  Synchronises."""
+        found = None
+        for fw in [self.metricsForwardPass] + [more[0] for more in self._more_metric_sets]:
+            if fw is None:
+                continue
+            try:
+                fw.check()
+            except ops.CapacityError as e:
+                found = found or e
+        return found
+
+    def _agree(self, flag: bool) -> bool:
+        """True on every rank if ``flag`` is true on any: one u32 summed over the ranks on the device, read back (a host wait -- only used inside a
+        densify event, which reads the rebuilt cloud's size back anyway)."""
+        if self.world_size <= 1:
+            return bool(flag)
+        if self._agree_word is None:
+            self._agree_word = self.device.createBuffer(4, "agreement word")
+        self._agree_word.write(np.array([1 if flag else 0], np.uint32))
+        self.exchange.allreduce_counts(self._agree_word.ptr, 1)
+        return int(self._agree_word.read(np.uint32, 1)[0]) != 0
+
     def _own_overflow(self, error) -> Optional[list]:
         """The entries needed by THIS trainer's passes among those a capacity report names (csrc/api.hip: deferred_checks names every pass that
         overflowed), ``[]`` if it names only other owners' passes, ``None`` if it names none (a step skipped on every rank)."""
@@ -838,7 +862,17 @@ class Trainer:
                 dev.laneOrder(0, k)   # join: normalize / prepare / the exchange follow every lane
         if usedViews == 0:
             return
-        if self.world_size > 1:  # u32 sum on the device, in place in the pass's own buffer (SURVEY 8(e) "Determinism")
+        if self.world_size > 1:
+            # A metric pass whose tile-entry list overflowed has counted a truncated view: the event is void -- and it has to be void on EVERY rank
+            # (the views are sharded, so one rank alone may overflow; were it to bail out while its peers rebuild the cloud, the replicas
+            # would part and the next exchange hang).  Each rank looks at its own metric passes, the flags are summed over the ranks, and all skip the
+            # event together, before any count has been exchanged; a rank that overflowed raises on the way out, which makes step() enlarge its lists.
+            overflow = self._metric_overflow()
+            if self._agree(overflow is not None):
+                if overflow is not None:
+                    raise overflow
+                return
+            # u32 sum on the device, in place in the pass's own buffer (SURVEY 8(e) "Determinism")
             self.exchange.allreduce_counts(self.metricsPass.getMetricCountsBuffer().ptr, self.pointCloud.num_points)
         self.metricsPass.normalizeMetricCounts(encoder, dict(divisor=usedViews))
         self.densifyPrune.ensureSize(self.pointCloud.num_points)
