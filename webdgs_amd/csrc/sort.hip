@@ -40,7 +40,9 @@ constexpr u32 RADIX = 256;
 // (exact: tile < 2^16, num_tiles_x <= 256).  row_inv = 0 selects the bit field; dmask is the largest digit either way.
 struct DigitOf {
     u32 shift, dmask, row_inv;
-    __device__ __forceinline__ u32 operator()(u32 key) const { return row_inv ? __umulhi((key >> 16u) - 1u, row_inv) : ((key >> shift) & dmask); }
+    // (row mode: a key whose tile field is 0 -- no emitted key has one; a corrupted list could -- would give a row far beyond the grid and index the
+    // digit tables out of range: it is held to the last row, where the bounded range update of sort_scatter ignores it)
+    __device__ __forceinline__ u32 operator()(u32 key) const { return row_inv ? min(__umulhi((key >> 16u) - 1u, row_inv), dmask) : ((key >> shift) & dmask); }
 };
 
 template <u32 ITEMS>
