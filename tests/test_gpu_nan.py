@@ -120,17 +120,12 @@ def _tile_centre(cfg, tx, ty, z):
     return (px - cfg.width / 2) * z / cfg.fy, (py - cfg.height / 2) * z / cfg.fy
 
 
-@pytest.mark.parametrize("kind", ["sparse", "faint", "pile-up"])
-def test_tile_lists_past_the_reference_cap(hip_device, orc, kind):
-    """One tile with more than 10 000 entries (the reference stages at most 32 x 256 = 8 192 per tile, SURVEY Q3: lifted here), one with 4 097, short
-    neighbours.  "sparse": thousands of small splats scattered over the tile -- a pixel sees few of them and never saturates, the block walks the
-    whole list; "faint": splats that cover the whole tile at an alpha near the 1/255 cut -- the pixels saturate after some hundred; "pile-up": the
-    late regime of a long run (profiles/r08g_long_list_stats.txt): ~60 real splats in front of thousands of Gaussians with NaN positions, which all
-    land in tile 0 behind them.  Two training steps against the oracle, stage by stage."""
+def long_list_scene(kind, big=10_400, second=4_097):
+    """Gaussians, SH, camera and config of a 96 x 64 scene with one tile of `big` entries, one of `second`, short lists elsewhere (see the test below)."""
     cfg = harness.small_config("c1", num_points=1, width=96, height=64, fy=90.0, sh_deg=0)
     rng = np.random.default_rng(17)
     rows = []
-    for (tx, ty, count) in ((2, 1, 10_400), (4, 2, 4_097)):
+    for (tx, ty, count) in ((2, 1, big), (4, 2, second)):
         for i in range(count):
             z = 2.0 + 6.0 * rng.random()
             cx, cy = _tile_centre(cfg, tx, ty, z)
@@ -144,11 +139,21 @@ def test_tile_lists_past_the_reference_cap(hip_device, orc, kind):
     g, sh = _rows(rows)
     if kind == "pile-up":
         gh = g.view(np.uint16).reshape(-1, 12).copy()
-        gh[60:10_400, 0:3] = NAN16       # everything of the first pile but its first 60 Gaussians
-        gh[10_400:10_400 + 4_097:3, 8:11] = NAN16
+        gh[60:big, 0:3] = NAN16       # everything of the first pile but its first 60 Gaussians
+        gh[big:big + second:3, 8:11] = NAN16
         g = gh.view(np.uint32).reshape(-1, 6)
     cfg = harness.small_config("c1", num_points=len(rows), width=96, height=64, fy=90.0, sh_deg=0)
-    cam = synth.identity_camera(cfg)
+    return cfg, g, sh, synth.identity_camera(cfg), rng
+
+
+@pytest.mark.parametrize("kind", ["sparse", "faint", "pile-up"])
+def test_tile_lists_past_the_reference_cap(hip_device, orc, kind):
+    """One tile with more than 10 000 entries (the reference stages at most 32 x 256 = 8 192 per tile, SURVEY Q3: lifted here), one with 4 097, short
+    neighbours.  "sparse": thousands of small splats scattered over the tile -- a pixel sees few of them and never saturates, the block walks the
+    whole list; "faint": splats that cover the whole tile at an alpha near the 1/255 cut -- the pixels saturate after some hundred; "pile-up": the
+    late regime of a long run (profiles/r08g_long_list_stats.txt): ~60 real splats in front of thousands of Gaussians with NaN positions, which all
+    land in tile 0 behind them.  Two training steps against the oracle, stage by stage."""
+    cfg, g, sh, cam, rng = long_list_scene(kind)
     st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
     ref = orc.forward(g, sh, cam, st, ti)
     lens = np.bincount(ref["sorted_keys"][:ref["total_entries"]] >> 16, minlength=ti[2] + 2)[1:]
