@@ -267,6 +267,20 @@ static napi_value tiledForwardCheck(napi_env env, napi_callback_info info) {  //
     set_prop(env, o, "visibleCount", make_u32(env, st[1]));
     return o;
 }
+static napi_value tiledForwardSetLongLists(napi_env env, napi_callback_info info) {  // (op, threshold, maxItems, maxRows)
+    ARGS(4);
+    WDGS_OK_OR_THROW(wdgs_tiled_forward_set_long_lists((wdgs_tiled_forward*)get_ptr(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3])));
+    return js_undefined(env);
+}
+static napi_value tiledForwardLongListStats(napi_env env, napi_callback_info info) {  // (op) -> {blocksWanted, itemsWanted, ..., threshold}
+    ARGS(1);
+    uint32_t st[12] = {0};
+    WDGS_OK_OR_THROW(wdgs_tiled_forward_long_list_stats((wdgs_tiled_forward*)get_ptr(env, argv[0]), st));
+    static const char* const keys[12] = {"blocksWanted", "itemsWanted", "forwardQueue", "backwardQueue", "rowsUsed", "rowsWanted", "stalled", nullptr, "maxItems", "maxBlocks", "maxRows", "threshold"};
+    napi_value o; napi_create_object(env, &o);
+    for (int i = 0; i < 12; i++) if (keys[i]) set_prop(env, o, keys[i], make_u32(env, st[i]));
+    return o;
+}
 static napi_value tiledRasterizerBlit(napi_env env, napi_callback_info info) {  // (op, targetPtr, width, height): blitToTexture
     ARGS(4);
     WDGS_OK_OR_THROW(wdgs_tiled_rasterizer_blit((wdgs_tiled_rasterizer*)get_ptr(env, argv[0]), get_ptr(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3])));
@@ -836,7 +850,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT_FN(tiledRasterizerCreate); EXPORT_FN(tiledRasterizerEncode); EXPORT_FN(tiledRasterizerGet); EXPORT_FN(tiledRasterizerDestroy);
     EXPORT_FN(tiledBackwardCreate); EXPORT_FN(tiledBackwardEncode); EXPORT_FN(tiledBackwardGradients); EXPORT_FN(tiledBackwardDestroy);
     EXPORT_FN(optimizerCreate); EXPORT_FN(optimizerStep); EXPORT_FN(optimizerGetIteration); EXPORT_FN(optimizerDestroy);
-    EXPORT_FN(tiledForwardSet); EXPORT_FN(tiledForwardCheck); EXPORT_FN(tiledRasterizerBlit); EXPORT_FN(bufferClear);
+    EXPORT_FN(tiledForwardSet); EXPORT_FN(tiledForwardCheck); EXPORT_FN(tiledForwardSetLongLists); EXPORT_FN(tiledForwardLongListStats); EXPORT_FN(tiledRasterizerBlit); EXPORT_FN(bufferClear);
     EXPORT_FN(encoderBegin); EXPORT_FN(encoderFinish); EXPORT_FN(queueSubmit); EXPORT_FN(commandBufferDestroy); EXPORT_FN(queueOnSubmittedWorkDone);
     EXPORT_FN(tiledBackwardMetric); EXPORT_FN(tiledBackwardGet); EXPORT_FN(downsampleRGBA8); EXPORT_FN(imageSSE);
     EXPORT_FN(optimizerStateSizes); EXPORT_FN(optimizerCreateWithState); EXPORT_FN(optimizerState); EXPORT_FN(optimizerHyperparameters);

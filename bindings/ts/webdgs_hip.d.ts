@@ -97,6 +97,8 @@ export class TiledForwardPass {
   getResources(): TiledForwardResources;
   getSortedIndicesBuffer(): HipBuffer; getSortedKeysBuffer(): HipBuffer; getTileOffsetsBuffer(): HipBuffer; getStatsBuffer(): HipBuffer;
   check(): { totalTileEntries: number; visibleCount: number };
+  setLongLists(threshold: number, maxItems?: number, maxRows?: number): void;
+  longListStats(): { blocksWanted: number; itemsWanted: number; forwardQueue: number; backwardQueue: number; rowsUsed: number; rowsWanted: number; stalled: number; maxItems: number; maxBlocks: number; maxRows: number; threshold: number };
   destroy(): void;
 }
 export class TiledRasterizer {

@@ -187,6 +187,10 @@ class TiledForwardPass {                 // tiled-forward-pass.ts:62
   getStatsBuffer() { return this.getResources().statsBuffer; }
   /** Synchronises; throws (code WDGS_E_CAPACITY) if an encode since the last check overflowed maxTileEntries. */
   check() { return addon.tiledForwardCheck(this.handle); }
+  /** Long tile lists (include/webdgs.h: wdgs_tiled_forward_set_long_lists): tiles with more than `threshold` entries get per-pixel lists (0: off). */
+  setLongLists(threshold, maxItems, maxRows) { addon.tiledForwardSetLongLists(this.handle, threshold, maxItems || 0, maxRows || 0); }
+  /** The last frame's long-list work: what it wanted and what the pass has room for (synchronises). */
+  longListStats() { return addon.tiledForwardLongListStats(this.handle); }
   destroy() { if (this.destroyed) return; this.destroyed = true; addon.tiledForwardDestroy(this.handle); this.handle = null; }   // (a call after destroy meets the library's null check, not freed memory)
 }
 

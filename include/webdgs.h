@@ -226,6 +226,16 @@ int wdgs_tiled_forward_set_gaussian_scale(wdgs_tiled_forward* op, float scale);
 int wdgs_tiled_forward_get_resources(wdgs_tiled_forward* op, wdgs_tiled_forward_resources* out);
 /* Synchronises and returns WDGS_E_CAPACITY if the last encode overflowed max_tile_entries; stats_out (4 x u32) optional. */
 int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out);
+/* Long tile lists.  The reference stages at most 32 x 256 = 8 192 entries of a tile (tiled-rasterizer.wgsl:59-60, 125) and drops the rest; this
+ * library composites every entry, and gives the blocks of a tile with more than `threshold` entries per-PIXEL lists, built and walked by tasks that the
+ * waves of the rasterization kernels work off themselves (csrc/longlist.h) -- no launch, no host decision: the path is part of every recording and taken
+ * on the device.  Results do not depend on it.  A pass is created with threshold 2048, room for 4096 (block, 64-entry chunk) slots and 32768 list rows;
+ * a tile that finds no room is composited the ordinary way (correct, slow).  set_long_lists re-sizes the work (threshold 0: off; items / rows 0: keep);
+ * synchronises, not allowed while recording, command buffers recorded against the pass must be dropped.  long_list_stats (synchronises) returns
+ * {block records wanted, item slots wanted, forward queue position, backward queue position, rows handed out, rows wanted, stall code (0 = none), 0,
+ *  max_items, max_blocks, max_rows, threshold} of the last frame: a host compares wanted with the capacities and enlarges them. */
+int wdgs_tiled_forward_set_long_lists(wdgs_tiled_forward* op, uint32_t threshold, uint32_t max_items, uint32_t max_rows);
+int wdgs_tiled_forward_long_list_stats(wdgs_tiled_forward* op, uint32_t stats_out[12]);
 
 /* ---------------------------------------------------------------- TiledRasterizer
  * Replaces `new TiledRasterizer({device, forwardPass, format})` (renderers/tiled-rasterizer.ts:57), .encode(encoder,w,h)

@@ -187,6 +187,8 @@ SIGNATURES = {
     "wdgs_tiled_forward_set_gaussian_scale": (_I, [_P, _F]),
     "wdgs_tiled_forward_get_resources": (_I, [_P, C.POINTER(TiledForwardResources)]),
     "wdgs_tiled_forward_check": (_I, [_P, C.POINTER(_U)]),
+    "wdgs_tiled_forward_set_long_lists": (_I, [_P, _U, _U, _U]),
+    "wdgs_tiled_forward_long_list_stats": (_I, [_P, C.POINTER(_U)]),
     "wdgs_tiled_rasterizer_create": (_I, [_P, _P, _U, C.POINTER(_P)]),
     "wdgs_tiled_rasterizer_destroy": (_I, [_P]),
     "wdgs_tiled_rasterizer_encode": (_I, [_P, _U, _U]),

@@ -8,24 +8,26 @@
 #include <map>
 #include <set>
 #include <unordered_map>
+#include <vector>
 
 #include "common.h"
 #include "alloc_cache.h"
+#include "longlist.h"
 
 // ---- kernel launchers (project.hip, sort.hip, raster.hip, loss.hip, backward.hip, optimizer.hip)
 int launch_project_count(wdgs_device*, u32, const void*, const void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, void*, void*, void*, void*,
                          const void*, void*, const void*);
 int launch_emit_scatter(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, const void*, const void*, void*, void*, u32);
-int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges);
+int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges, const LongWork* lw);
 extern "C" void sorter_set_final_out_index(wdgs_sorter* s, int i);
 int launch_update_stats(wdgs_device*, u32, const void*, const void*, u32, void*, void*, void*);
 int launch_emit(wdgs_device*, u32, const void*, const void*, const void*, void*, const void*, const RenderSettings&, const TileInfo&, void*, void*, u32);
 int launch_tile_ranges(wdgs_device*, const void*, const void*, u32, void*);
 int launch_rasterize(wdgs_device*, const RenderSettings&, const TileInfo&, const void*, u32, const void*, const void*, const void*, const void*, u32, void*,
-                     void*, void*, const void*, const void*);
+                     void*, void*, const void*, const void*, const LongWork*);
 int launch_loss_grad(wdgs_device*, u32, u32, const void*, const void*, const wdgs_training_config&, void*, void*, u32, const void*);
 int launch_backward_rasterize(wdgs_device*, const RenderSettings&, u32, u32, const void*, const void*, const void*, const void*, const void*, const void*,
-                              void*, void*);
+                              void*, void*, const LongWork*);
 int launch_acc_clear_if_dirty(wdgs_device*, void*, u32, void*);
 int launch_geometry_backward_views(wdgs_device*, u32, u32, const void* const*, const RenderSettings&, const void*, void* const*, void* const*, const void* const*,
                                    const void* const*, void* const*, void*, void*, void*, u32);
@@ -54,7 +56,7 @@ int launch_metric_count(wdgs_device*, const RenderSettings&, u32, u32, const voi
 int launch_metric_normalize(wdgs_device*, u32, u32, void*);
 int launch_downsample(wdgs_device*, const void*, u32, u32, void*, u32, u32);
 
-int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges);
+int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges, const LongWork* lw);
 extern "C" int wdgs_sorter_final_out_index(wdgs_sorter* s);
 extern "C" uint32_t wdgs_sorter_capacity(wdgs_sorter* s);
 
@@ -173,6 +175,10 @@ struct wdgs_tiled_forward {
     // scan.hip advances the number, raster.hip takes such tiles in the oracle's own forms)
     u32* nf_stamp;
     u32 nf_capacity;
+    // Long tile lists (longlist.h): tables, scratch and the per-tile marks; `long_lists.hdr == nullptr`: switched off.  Built by this pass's sort, used by
+    // the rasterizer that composites with this pass's range table and by a backward pass that is handed that table (found through dev->range_tables).
+    LongWork long_lists;
+    u32 long_flags_capacity;
     u32* host_stats;  // pinned, device-visible copy of stats[0..3] written by update_stats: the per-step overflow check reads host memory
     u32* splats;
     u32* depths;
@@ -759,10 +765,49 @@ static int forward_alloc_nf_stamp(wdgs_tiled_forward* op) {
     free_dev(op->nf_stamp);
     op->nf_stamp = nullptr;
     op->nf_capacity = 0;
+    op->long_lists = LongWork{};
+    op->long_flags_capacity = 0;
     WDGS_TRY(wdgs_alloc((void**)&op->nf_stamp, sizeof(u32) * (size_t)op->tile_info.total_tiles, true, op->dev->stream));
     op->nf_capacity = op->tile_info.total_tiles;
     return WDGS_OK;
 }
+
+static void forward_free_long_lists(wdgs_tiled_forward* op) {
+    LongWork& lw = op->long_lists;
+    free_dev(lw.hdr); free_dev(lw.sync); free_dev(lw.flags); free_dev(lw.blocks); free_dev(lw.item_block); free_dev(lw.nlist); free_dev(lw.cnt); free_dev(lw.off);
+    free_dev(lw.total); free_dev(lw.jlast); free_dev(lw.records); free_dev(lw.rows);
+    lw = LongWork{};
+    op->long_flags_capacity = 0;
+}
+// (Re)allocates the long-list work of a pass: `threshold` entries (0 = off), room for `items` (block, chunk) slots and `rows` list rows.
+static int forward_alloc_long_lists(wdgs_tiled_forward* op, u32 threshold, u32 items, u32 rows) {
+    wdgs_device* d = op->dev;
+    forward_free_long_lists(op);
+    if (threshold == 0u) return WDGS_OK;
+    LongWork lw{};
+    lw.threshold = threshold;
+    lw.max_items = std::max(items, 64u);
+    lw.max_blocks = std::max(lw.max_items / 8u, 16u) & ~3u;   // (four per long tile; a tile of `threshold` > 128 entries takes more than 8 items per block)
+    lw.max_rows = std::max(rows, 64u);
+    const u32 tiles = std::max(op->tile_info.total_tiles, 1u);
+    int r = wdgs_alloc((void**)&lw.hdr, sizeof(u32) * LL_HDR_WORDS, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.sync, sizeof(LongSync) * (size_t)lw.max_blocks, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.flags, sizeof(u32) * (size_t)tiles, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.blocks, sizeof(LongBlock) * (size_t)lw.max_blocks, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.item_block, sizeof(u32) * (size_t)lw.max_items, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.nlist, sizeof(u32) * (size_t)lw.max_items, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.cnt, sizeof(u32) * 64u * (size_t)lw.max_items, false, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.off, sizeof(u32) * 64u * (size_t)lw.max_items, false, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.total, sizeof(u32) * 64u * (size_t)lw.max_blocks, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.jlast, sizeof(u32) * 64u * (size_t)lw.max_blocks, true, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.records, sizeof(float4) * 192u * (size_t)lw.max_items, false, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.rows, sizeof(float4) * 64u * (size_t)lw.max_rows, false, d->stream);
+    op->long_lists = lw;   // (what has been allocated is freed with the pass, also after a failure)
+    if (r != WDGS_OK) { forward_free_long_lists(op); return r; }
+    op->long_flags_capacity = tiles;
+    return WDGS_OK;
+}
+constexpr u32 LONG_LIST_THRESHOLD = 2048u, LONG_LIST_ITEMS = 4096u, LONG_LIST_ROWS = 32768u;   // defaults (include/webdgs.h: wdgs_tiled_forward_set_long_lists)
 
 int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* cfg, wdgs_tiled_forward** out) {
     WDGS_REQUIRE(d && cfg && out, WDGS_E_INVALID, "wdgs_tiled_forward_create: null argument");
@@ -798,6 +843,9 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     // (frame numbers start at 1: a zeroed stamp table marks nothing)
     if (r == WDGS_OK && hipMemsetD32Async((hipDeviceptr_t)(op->stats + FRAME_WORD), 1, 1, d->stream) != hipSuccess) { wdgs_set_error("hipMemsetD32Async failed"); r = WDGS_E_HIP; }
     if (r == WDGS_OK) r = forward_alloc_nf_stamp(op);
+    // (WDGS_LONG_LISTS=0: off for every pass of the process; a threshold otherwise -- same-box comparisons)
+    static const char* const ll_env = std::getenv("WDGS_LONG_LISTS");
+    if (r == WDGS_OK && !cfg->compat_caps) r = forward_alloc_long_lists(op, ll_env ? (u32)std::atoi(ll_env) : LONG_LIST_THRESHOLD, LONG_LIST_ITEMS, LONG_LIST_ROWS);
     if (r == WDGS_OK && hipHostMalloc((void**)&op->host_stats, 16, hipHostMallocDefault) != hipSuccess) { wdgs_set_error("hipHostMalloc(16) failed"); r = WDGS_E_HIP; }
     if (r == WDGS_OK) std::memset(op->host_stats, 0, 16);
     if (r == WDGS_OK) r = forward_alloc_per_point(op, std::max(n, 1u));
@@ -815,8 +863,10 @@ int wdgs_tiled_forward_destroy(wdgs_tiled_forward* op) {
         v.erase(std::remove(v.begin(), v.end(), op), v.end());
     }
     sync_if_alive(op->dev);
+    if (op->ranges && wdgs_device_alive(op->dev)) op->dev->range_tables.erase(op->ranges);
     free_dev(op->stats);
     free_dev(op->nf_stamp);
+    forward_free_long_lists(op);
     if (op->host_stats) (void)hipHostFree(op->host_stats);
     free_dev(op->splats);
     free_dev(op->depths);
@@ -894,7 +944,7 @@ static int forward_encode_rest(wdgs_tiled_forward* op, int skip_sort, bool colum
     wdgs_device* d = op->dev;
     const u32 n = op->cfg.num_points;
     const TileInfo& ti = op->tile_info;
-    const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries, op->stats + FRAME_WORD};
+    const ScanStatsEpilogue ep{op->stats, op->stats + 4, op->host_stats, op->tile_info.max_tile_entries, op->stats + FRAME_WORD, op->long_lists.hdr};
     if (columns) {
         WDGS_TRY(forward_scan(d, op->block_counts, ceil_div(n, 256), op->column_counts, op->column_totals, ti.num_tiles_x, ep));
     } else if (n > 0) {
@@ -908,17 +958,19 @@ static int forward_encode_rest(wdgs_tiled_forward* op, int skip_sort, bool colum
         if (tiles + 1 > op->ranges_capacity) {
             WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "TiledForwardPass.encode allocates its range table on first use: run one eager encode before recording");
             (void)wdgs_sync_lanes(d);
+            if (op->ranges) d->range_tables.erase(op->ranges);
             free_dev(op->ranges);
             op->ranges = nullptr;
             WDGS_TRY(wdgs_alloc((void**)&op->ranges, sizeof(u32) * (size_t)(tiles + 1), true, d->stream));
             op->ranges_capacity = tiles + 1;
+            d->range_tables[op->ranges] = op;   // (a backward pass handed this table finds the pass's long-list work through it)
         }
     }
     if (columns) {
         WDGS_TRY(launch_emit_scatter(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->block_counts, op->settings, op->tile_info,
                                      op->column_counts, op->column_totals, wdgs_sorter_keys(op->sorter, 0), wdgs_sorter_values(op->sorter, 0), op->tile_info.max_tile_entries));
         // one stable pass on the tile row (it builds the range table), then the per-tile depth sort: the order of a stable sort of the full key
-        WDGS_TRY(sorter_sort_rows(op->sorter, ti.num_tiles_x, ti.num_tiles_y, op->ranges));
+        WDGS_TRY(sorter_sort_rows(op->sorter, ti.num_tiles_x, ti.num_tiles_y, op->ranges, op->long_lists.hdr ? &op->long_lists : nullptr));
         op->ranges_valid = true;
     } else {
         WDGS_TRY(launch_emit(d, n, op->splats, op->depths, op->scanner->input, op->scanner->output, op->block_counts, op->settings, op->tile_info,
@@ -930,7 +982,7 @@ static int forward_encode_rest(wdgs_tiled_forward* op, int skip_sort, bool colum
                 WDGS_TRY(wdgs_sorter_sort(op->sorter, 32u));  // the reference's four 8-bit passes over the whole key
             } else {
                 // tile passes, range table, per-tile depth sort (sort.hip): the order of a stable sort of the full key
-                WDGS_TRY(sorter_sort_segmented(op->sorter, bits_for(op->tile_info.total_tiles), op->tile_info.total_tiles, op->ranges));
+                WDGS_TRY(sorter_sort_segmented(op->sorter, bits_for(op->tile_info.total_tiles), op->tile_info.total_tiles, op->ranges, op->long_lists.hdr ? &op->long_lists : nullptr));
                 op->ranges_valid = true;
             }
         }
@@ -1004,6 +1056,13 @@ int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t
     WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_tiled_forward_set_viewport while recording a command buffer");
     forward_set_viewport(op, w, h);
     if (op->tile_info.total_tiles > op->nf_capacity) { (void)wdgs_sync_lanes(op->dev); WDGS_TRY(forward_alloc_nf_stamp(op)); }
+    if (op->long_lists.hdr && op->tile_info.total_tiles > op->long_flags_capacity) {
+        (void)wdgs_sync_lanes(op->dev);
+        free_dev(op->long_lists.flags);
+        op->long_lists.flags = nullptr;
+        WDGS_TRY(wdgs_alloc((void**)&op->long_lists.flags, sizeof(u32) * (size_t)op->tile_info.total_tiles, true, op->dev->stream));
+        op->long_flags_capacity = op->tile_info.total_tiles;
+    }
     return WDGS_OK;
 }
 int wdgs_tiled_forward_set_render_mode(wdgs_tiled_forward* op, uint32_t mode) {
@@ -1050,6 +1109,35 @@ int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out) {
     st[2] = __atomic_exchange_n(op->host_stats + 2, 0u, __ATOMIC_ACQ_REL);  // the overflow word is sticky (set by any encode since the last check): consumed here, atomically
     if (stats_out) std::memcpy(stats_out, st, sizeof(st));
     WDGS_REQUIRE(st[2] == 0u, WDGS_E_CAPACITY, "tile entries overflow: %u entries needed, max_tile_entries = %u (forward pass %p)", st[2], op->tile_info.max_tile_entries, (void*)op);
+    return WDGS_OK;
+}
+
+int wdgs_tiled_forward_set_long_lists(wdgs_tiled_forward* op, uint32_t threshold, uint32_t max_items, uint32_t max_rows) {
+    WDGS_REQUIRE(op, WDGS_E_INVALID, "wdgs_tiled_forward_set_long_lists: null op");
+    wdgs_device* d = op->dev;
+    WDGS_REQUIRE(!d->capturing, WDGS_E_STATE, "wdgs_tiled_forward_set_long_lists while recording a command buffer");
+    WDGS_REQUIRE(!op->cfg.compat_caps || threshold == 0u, WDGS_E_STATE, "wdgs_tiled_forward_set_long_lists: a pass with compat_caps truncates its lists as the reference does");
+    WDGS_CHECK_HIP(hipSetDevice(d->ordinal));
+    WDGS_CHECK_HIP(wdgs_sync_lanes(d));
+    const LongWork& now = op->long_lists;
+    return forward_alloc_long_lists(op, threshold, max_items ? max_items : (now.hdr ? now.max_items : LONG_LIST_ITEMS), max_rows ? max_rows : (now.hdr ? now.max_rows : LONG_LIST_ROWS));
+}
+int wdgs_tiled_forward_long_list_stats(wdgs_tiled_forward* op, uint32_t stats_out[12]) {
+    WDGS_REQUIRE(op && stats_out, WDGS_E_INVALID, "wdgs_tiled_forward_long_list_stats: null argument");
+    std::memset(stats_out, 0, sizeof(uint32_t) * 12);
+    const LongWork& lw = op->long_lists;
+    if (!lw.hdr) return WDGS_OK;
+    WDGS_TRY(wdgs_copy_to_host(op->dev, stats_out, lw.hdr, sizeof(u32) * LL_HDR_WORDS));
+    stats_out[8] = lw.max_items; stats_out[9] = lw.max_blocks; stats_out[10] = lw.max_rows; stats_out[11] = lw.threshold;
+    if (std::getenv("WDGS_LL_DEBUG")) {   // (dev aid: the block records of the frame)
+        const u32 nb = std::min(stats_out[0], lw.max_blocks);
+        std::vector<LongBlock> b(nb);
+        std::vector<LongSync> sy(nb);
+        if (nb) { WDGS_TRY(wdgs_copy_to_host(op->dev, b.data(), lw.blocks, sizeof(LongBlock) * nb)); WDGS_TRY(wdgs_copy_to_host(op->dev, sy.data(), lw.sync, sizeof(LongSync) * nb)); }
+        for (u32 i = 0; i < nb; i++)
+            std::fprintf(stderr, "[long lists] block %u: tile %u sub %u first_item %u chunks %u | counted %u row_base %u scanned %u filled %u rows %u walked %u\n", i, b[i].tile, b[i].sub,
+                         b[i].first_item, b[i].chunks, sy[i].counted, sy[i].row_base, sy[i].scanned, sy[i].filled, sy[i].rows, sy[i].walked);
+    }
     return WDGS_OK;
 }
 
@@ -1112,7 +1200,8 @@ int wdgs_tiled_rasterizer_encode(wdgs_tiled_rasterizer* op, uint32_t width, uint
         op->ranges_used = op->ranges;
     }
     WDGS_TRY(launch_rasterize(d, f->settings, ti, f->splats, f->cfg.num_points, op->ranges_used, keys, vals, f->stats, op->compat_caps ? 32u : 0u, op->rgba8,
-                              op->alpha, op->n_contrib, f->nf_stamp, f->stats + FRAME_WORD));
+                              op->alpha, op->n_contrib, f->nf_stamp, f->stats + FRAME_WORD,
+                              (f->ranges_valid && f->long_lists.hdr && !op->compat_caps) ? &f->long_lists : nullptr));   // (the table this pass's sort built and marked)
     op->encoded = true;
     return WDGS_OK;
 }
@@ -1224,8 +1313,12 @@ static int backward_encode_raster(wdgs_tiled_backward* op, const void* pred, con
     // K15 + clearBuffer x4 (tiled-backward-pass.ts:624-627): the clear rides on the loss kernel and is a no-op behind a consuming K17
     if (w > 0 && h > 0) WDGS_TRY(launch_loss_grad(d, w, h, pred, targ, op->cfg.training, op->loss_image, op->acc, std::max(n, 1u), op->acc_dirty));
     else WDGS_TRY(launch_acc_clear_if_dirty(d, op->acc, n, op->acc_dirty));
+    // long tile lists (longlist.h): when the range table is one a forward pass of this device built, that pass's lists serve the backward walk too
+    const LongWork* lw = nullptr;
+    auto owner = d->range_tables.find(res->tile_offsets_buffer);
+    if (owner != d->range_tables.end() && owner->second->ranges_valid && owner->second->long_lists.hdr) lw = &owner->second->long_lists;
     return launch_backward_rasterize(d, op->settings, ceil_div(w, 16), ceil_div(h, 16), res->tile_offsets_buffer, res->tile_indices_buffer, res->splat_buffer,
-                                     res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc, op->acc_dirty);
+                                     res->alpha_texture, res->n_contrib_texture, op->loss_image, op->acc, op->acc_dirty, lw);
 }
 int wdgs_tiled_backward_encode(wdgs_tiled_backward* op, const void* pred, const void* targ, const wdgs_tiled_backward_resources* res,
                                const void* gaussians) {

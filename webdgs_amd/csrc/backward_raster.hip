@@ -30,6 +30,7 @@
 #include "common.h"
 #include "dmath.h"
 #include "blockcull.h"
+#include "longlist.h"
 
 namespace {
 
@@ -90,12 +91,13 @@ WD_DEV int cvt_fixed(float scaled) {
 // SIMD's issue slots (446 ns per iteration alone, 617 ns among four: profiles/r05v_bwr_wave_rate.txt).  The wave therefore sets its issue
 // priority from the entries it still has to walk, once per chunk: longest remaining chain first.  c2 187.0 -> 176.9 us per step, c3 unchanged
 // (profiles/r05x_bwr_issue_priority_sweep.txt; thresholds swept there).  Arbitration only: results cannot depend on it.
-template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false, bool PRIO = true>
-__global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
+template <u32 WPW, bool LDS_SUMS, bool TIMELINE, bool PRIO>
+__device__ __attribute__((always_inline)) void backward_rasterize_body(const RenderSettings& settings, u32 num_tiles_x, const u32* __restrict__ ranges,
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty,
-                                                                 unsigned long long* __restrict__ timeline, const u32* __restrict__ long_flags) {
+                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc,
+                                                                 unsigned long long* __restrict__ timeline, u32 tile_id, u32 sub, float4* s_geo, float4* s_con, float4* s_col,
+                                                                 int* s_sum) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
     auto leave_timeline = [&]() {
@@ -107,32 +109,8 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
             rec[0] = t_start; rec[1] = wall_clock64(); rec[2] = ((unsigned long long)xcc_id << 32) | hw_id; rec[3] = iterations;
         }
     };
-    // the accumulators hold sums from here on (acc_clear_if_dirty below, and the consuming forms of geometry_backward, backward.hip)
-    if (blockIdx.x == 0u && threadIdx.x == 0u) *acc_dirty = 1u;
-    __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y
-    __shared__ float4 s_con_all[WPW][64];  // conic.x, conic.y, conic.z, opacity
-    __shared__ float4 s_col_all[WPW][64];  // r, g, b, gaussian index (bits)
-    __shared__ int s_sum_all[LDS_SUMS ? WPW : 1u][LDS_SUMS ? 8u * 64u : 1u];  // [slot 0..7][pixel lane]: one iteration's contributions
-
-    // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
-    // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
-    u32 tile_id, sub;
-    if (WPW == 4u) {
-        tile_id = blockIdx.x; sub = threadIdx.x >> 6;
-    } else {
-        // launch slots b, b + 8, ... share an XCD: slot j of XCD k is block (j & 3) of the XCD's tile number j >> 2; XCD k owns the tiles
-        // k, k + 8, k + 16, ... (any tile count: the grid is rounded up and surplus slots leave)
-        const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        tile_id = k + 8u * (j >> 2);
-        sub = j & 3u;
-        if (tile_id >= num_tiles) return;
-    }
     const u32 tile_x = tile_id % num_tiles_x, tile_y = tile_id / num_tiles_x;
     const u32 lane = threadIdx.x & 63u;
-    const u32 slot = (WPW == 4u) ? sub : 0u;
-    float4* const s_geo = s_geo_all[slot];  // wave-private record sets
-    float4* const s_con = s_con_all[slot];
-    float4* const s_col = s_col_all[slot];
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -145,7 +123,6 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     const u32 quad_lane = lane & 3u;
     // LDS_SUMS: lane (q, part) = (lane >> 3, lane & 7) adds up the eight contributions [q][8 part .. 8 part + 7] -- two 16-byte reads, the
     // halves taken in opposite order by odd q, which makes both reads conflict-free in ds_read_b128's lane groups
-    int* const s_sum = s_sum_all[LDS_SUMS ? slot : 0u];
     const u32 sum_q = lane >> 3, sum_first = (sum_q & 1u) * 4u;
     const int4* const sum_rd0 = reinterpret_cast<const int4*>(s_sum + (LDS_SUMS ? sum_q * 64u + (lane & 7u) * 8u + sum_first : 0u));
     const int4* const sum_rd1 = reinterpret_cast<const int4*>(s_sum + (LDS_SUMS ? sum_q * 64u + (lane & 7u) * 8u + (4u - sum_first) : 0u));
@@ -364,6 +341,123 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     leave_timeline();
 }
 
+// ---- long tile lists (longlist.h): the backward walk of a block whose pixels the forward pass composited through per-pixel lists.  Lane = pixel: it
+// walks ITS list back to front from its last contributor, fetches each record it meets (the forward tasks left the chunk's unpacked entries), evaluates
+// what backward_rasterize_body evaluates for a (pixel, splat) pair -- the same operations on the same operands, in the parity oracle's forms (full exp,
+// IEEE division) -- and adds its nine fixed-point contributions itself: integer sums do not care who adds them.  As many trips as the longest
+// per-pixel list has elements in front of its last contributor -- not as the tile list has entries.
+__device__ __attribute__((always_inline)) void long_backward_help(const RenderSettings& settings, u32 num_tiles_x, const float* __restrict__ final_T,
+                                                                  const u32* __restrict__ n_contrib, const float4* __restrict__ loss_grad, int* __restrict__ acc, const LongWork lw) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 n_blocks = min(lw.hdr[LL_BLOCKS], lw.max_blocks);
+    const u32 W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
+    __builtin_amdgcn_s_setprio(3);
+    // block records are dealt to the launch's waves in turn (wave w takes records w, w + waves, ...: the first waves of the grid start at once; no
+    // queue, so the pass may be encoded any number of times against one forward pass)
+    for (u32 lb = blockIdx.x; lb < n_blocks; lb += gridDim.x) {
+        const LongBlock blk = lw.blocks[lb];
+        const LongSync sy = lw.sync[lb];
+        if (blk.chunks == 0u || sy.walked == 0u) continue;   // (no room, or walked the plain way: the block's main wave does the backward walk too)
+        const u32 tile_x = blk.tile % num_tiles_x, tile_y = blk.tile / num_tiles_x;
+        const u32 pixel_x = tile_x * 16u + (blk.sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (blk.sub >> 1) * 8u + (lane >> 3);
+        const bool in_bounds = pixel_x < W && pixel_y < H;
+        const size_t p = (size_t)pixel_y * W + pixel_x;
+        u32 left = lw.jlast[(size_t)lb * 64u + lane];   // elements [0, left) of the list lie at positions below the pixel's n_contrib
+        float T = 0.0f;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_bounds && left > 0u) { T = final_T[p]; g = loss_grad[p]; }
+        if (!(T == T)) left = 0u;   // (a NaN final T: nothing to add, backward_rasterize_body)
+        const f2 pxy = f2{(float)pixel_x + 0.5f, (float)pixel_y + 0.5f};
+        const f2 g_rg = f2{g.x, g.y};
+        const float g_b = g.z;
+        f2 ar_rg = f2{0.f, 0.f};
+        float ar_b = 0.f;
+        const float4* const rows = lw.rows + (size_t)sy.row_base * 64u + lane;
+        const float4* const recs = lw.records + (size_t)blk.first_item * 192u;
+        u32 trips = left;
+#pragma unroll
+        for (u32 d = 32; d >= 1; d >>= 1) trips = max(trips, (u32)__shfl_xor((int)trips, (int)d, 64));
+        for (u32 tr = 0; tr < trips; tr++) {
+            if (tr >= left) continue;   // (this lane's list is done; others go on)
+            const u32 j = left - 1u - tr;
+            const u32 pos = __float_as_uint(rows[(size_t)j * 64u].w) - 1u;   // position of the element's entry in the tile list
+            const float4* const r = recs + (size_t)pos * 3u;                   // (chunk pos >> 6, entry pos & 63 of the block's items: 64 x 3 per item)
+            const float4 geo = r[0], con = r[1], col = r[2];
+            const f2 d = pxy - f2{geo.x, geo.y};
+            const float syd = con.y * d.y;
+            const float t1 = __builtin_fmaf(con.x, d.x, syd + syd);
+            const float xe = __builtin_fmaf(t1, d.x, (con.z * d.y) * d.y);
+            const float G = wd_exp(xe);
+            const float og = con.w * G;
+            const float alpha = (og < 0.99f) ? og : 0.99f;
+            if (alpha < (1.0f / 255.0f)) continue;   // (tiled-backward-rasterize.wgsl:116-118)
+            const float oma = 1.0f - alpha;
+            T = wd_div(T, oma);
+            const float aT = alpha * T;
+            const f2 frg = (aT * g_rg) * FIXED_SCALE;
+            const int f_r = cvt_fixed(frg.x);
+            const int f_g = cvt_fixed(frg.y);
+            const int f_b = cvt_fixed((aT * g_b) * FIXED_SCALE);
+            const f2 col_rg = f2{col.x, col.y};
+            const f2 dc_rg = col_rg - ar_rg;
+            const float dL_dalpha = __builtin_fmaf(col.z - ar_b, g_b, __builtin_fmaf(dc_rg.y, g_rg.y, dc_rg.x * g_rg.x)) * T;
+            ar_rg = f2{__builtin_fmaf(alpha, col_rg.x, oma * ar_rg.x), __builtin_fmaf(alpha, col_rg.y, oma * ar_rg.y)};
+            ar_b = __builtin_fmaf(alpha, col.z, oma * ar_b);
+            const float dL_dG = con.w * dL_dalpha;
+            const int f_op = cvt_fixed((G * dL_dalpha) * FIXED_SCALE);
+            const f2 qpow = f2{__builtin_fmaf(con.x, d.x, syd), __builtin_fmaf(con.z, d.y, con.y * d.x)};
+            const float mhG = -0.5f * G;
+            const f2 fm = (dL_dG * (G * qpow)) * (-2.0f * FIXED_SCALE);
+            const f2 fc = (dL_dG * ((mhG * d) * d)) * FIXED_SCALE;
+            const int f_cy = cvt_fixed((dL_dG * ((mhG * d.x) * d.y)) * (2.0f * FIXED_SCALE));
+            int* const a = acc + (size_t)__float_as_uint(col.w) * ACC_STRIDE;
+            // accumulator slots: 0 mean.x 1 mean.y 2 conic.x 3 conic.y 4 conic.z 5 opacity 6 r 7 g 8.. b (four partial sums; geometry_backward adds them up)
+            const int v[9] = {cvt_fixed(fm.x), cvt_fixed(fm.y), cvt_fixed(fc.x), f_cy, cvt_fixed(fc.y), f_op, f_r, f_g, f_b};
+#pragma unroll
+            for (u32 s = 0; s < 9u; s++)
+                if (v[s] != 0) atomicAdd(a + s, v[s]);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// The kernel.  HELP (one-wave workgroups, LDS sums): blocks whose pixels the forward pass composited through per-pixel lists (lw.flags bit 4 + block,
+// longlist.h) are left to long_backward_help, which every wave runs once its own block is done.
+template <u32 WPW, bool LDS_SUMS, bool TIMELINE = false, bool PRIO = true, bool HELP = false>
+__global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderSettings settings, u32 num_tiles_x, u32 num_tiles, const u32* __restrict__ ranges,
+                                                                 const u32* __restrict__ instances, const u32* __restrict__ splats,
+                                                                 const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
+                                                                 const float4* __restrict__ loss_grad, int* __restrict__ acc, u32* __restrict__ acc_dirty,
+                                                                 unsigned long long* __restrict__ timeline, LongWork lw) {
+    // the accumulators hold sums from here on (acc_clear_if_dirty below, and the consuming forms of geometry_backward, backward.hip)
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *acc_dirty = 1u;
+    __shared__ float4 s_geo_all[WPW][64];  // centre.x, centre.y, extent.x, extent.y
+    __shared__ float4 s_con_all[WPW][64];  // conic.x, conic.y, conic.z, opacity
+    __shared__ float4 s_col_all[WPW][64];  // r, g, b, gaussian index (bits)
+    __shared__ int s_sum_all[LDS_SUMS ? WPW : 1u][LDS_SUMS ? 8u * 64u : 1u];  // [slot 0..7][pixel lane]: one iteration's contributions
+    const u32 long_blocks = HELP ? lw.hdr[LL_BLOCKS] : 0u;   // (requested now, looked at when the wave's own block is done)
+    // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
+    // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
+    u32 tile_id, sub;
+    bool mine = true;
+    if (WPW == 4u) {
+        tile_id = blockIdx.x; sub = threadIdx.x >> 6;
+    } else {
+        // launch slots b, b + 8, ... share an XCD: slot j of XCD k is block (j & 3) of the XCD's tile number j >> 2; XCD k owns the tiles
+        // k, k + 8, k + 16, ... (any tile count: the grid is rounded up and surplus slots leave)
+        const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        tile_id = k + 8u * (j >> 2);
+        sub = j & 3u;
+        mine = tile_id < num_tiles;
+    }
+    if (HELP && mine && long_blocks != 0u && ((lw.flags[tile_id] >> (4u + sub)) & 1u)) mine = false;
+    const u32 slot = (WPW == 4u) ? sub : 0u;
+    if (mine)
+        backward_rasterize_body<WPW, LDS_SUMS, TIMELINE, PRIO>(settings, num_tiles_x, ranges, instances, splats, final_T, n_contrib, loss_grad, acc, timeline, tile_id, sub, s_geo_all[slot],
+                                                               s_con_all[slot], s_col_all[slot], s_sum_all[LDS_SUMS ? slot : 0u]);
+    if (HELP && long_blocks != 0u) long_backward_help(settings, num_tiles_x, final_T, n_contrib, loss_grad, acc, lw);
+}
+
 // clearBuffer x4 (tiled-backward-pass.ts:624-627) as a kernel that first looks at the accumulators' state word: the Trainer's forms of
 // K17 (geometry_backward_accumulate / geometry_backward_adam) put every row they have read back to zero -- only the ~18 % of rows a view
 // touches are non-zero -- and mark the buffer clean, so the next view's clear finds nothing to do (it used to be a 48 MB memset per view at
@@ -387,7 +481,7 @@ int launch_acc_clear_if_dirty(wdgs_device* dev, void* acc, u32 n, void* acc_dirt
 }
 
 int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 num_tiles_x, u32 num_tiles_y, const void* ranges, const void* instances,
-                              const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc, void* acc_dirty) {
+                              const void* splats, const void* final_t, const void* n_contrib, const void* loss_grad, void* acc, void* acc_dirty, const LongWork* long_work) {
     const u32 tiles = num_tiles_x * num_tiles_y;
     if (tiles == 0) return WDGS_OK;
     // one 8x8 block (one wave) per workgroup: nothing is shared inside a tile's workgroup but cache lines, and single-wave workgroups are
@@ -397,10 +491,9 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
     static const bool lds_sums = !(std::getenv("WDGS_BWR_SUMS") && std::getenv("WDGS_BWR_SUMS")[0] == 'b');
     // WDGS_BWR_PAD_LDS=<bytes>: unused dynamic LDS per workgroup -- an occupancy experiment (fewer resident waves of this kernel per CU)
     static const u32 pad_lds = std::getenv("WDGS_BWR_PAD_LDS") ? (u32)std::atoi(std::getenv("WDGS_BWR_PAD_LDS")) : 0u;
-#define WDGS_BWR_LAUNCH(WPW_, LDS_, GRID_, BLOCK_)                                                                                                 \
-    WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<WPW_, LDS_>), dim3(GRID_), dim3(BLOCK_), pad_lds, st, num_tiles_x, tiles, (const u32*)ranges, \
-                (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, \
-                (unsigned long long*)nullptr, (const u32*)nullptr)
+    const LongWork lw = long_work ? *long_work : LongWork{};
+#define WDGS_BWR_ARGS st, num_tiles_x, tiles, (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, \
+                      (int*)acc, (u32*)acc_dirty
     if (one_wave) {
         const u32 slots = ceil_div(tiles, 8u) * 8u * 4u;   // 4 blocks per tile, tiles rounded up to a multiple of the 8 XCDs
         // WDGS_BWR_PRIO=0: the form without issue priorities (same-box A/B)
@@ -413,12 +506,8 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
             const size_t bytes = (size_t)slots * 4u * sizeof(unsigned long long);
             WDGS_CHECK_HIP(hipMalloc((void**)&tl, bytes));
             WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
-            if (prio)
-                hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, true>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
-                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl, (const u32*)nullptr);
-            else
-                hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, false>), dim3(slots), dim3(64), pad_lds, dev->stream, st, num_tiles_x, tiles, (const u32*)ranges,
-                                   (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc, (u32*)acc_dirty, tl, (const u32*)nullptr);
+            if (prio) hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, true>), dim3(slots), dim3(64), pad_lds, dev->stream, WDGS_BWR_ARGS, tl, LongWork{});
+            else hipLaunchKernelGGL((backward_rasterize_kernel<1u, true, true, false>), dim3(slots), dim3(64), pad_lds, dev->stream, WDGS_BWR_ARGS, tl, LongWork{});
             std::vector<unsigned long long> host((size_t)slots * 4u);
             WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
             WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
@@ -427,15 +516,23 @@ int launch_backward_rasterize(wdgs_device* dev, const RenderSettings& st, u32 nu
             WDGS_CHECK_HIP(hipGetLastError());
             return WDGS_OK;
         }
-        if (lds_sums && !prio) {
-            WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false>), dim3(slots), dim3(64), pad_lds, st, num_tiles_x, tiles,
-                        (const u32*)ranges, (const u32*)instances, (const u32*)splats, (const float*)final_t, (const u32*)n_contrib, (const float4*)loss_grad, (int*)acc,
-                        (u32*)acc_dirty, (unsigned long long*)nullptr, (const u32*)nullptr);
-        } else if (lds_sums) { WDGS_BWR_LAUNCH(1u, true, slots, 64); } else { WDGS_BWR_LAUNCH(1u, false, slots, 64); }
+        unsigned long long* const no_tl = nullptr;
+        if (lds_sums && lw.hdr && lw.threshold) {   // (long tile lists, longlist.h)
+            if (prio) WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, true, true>), dim3(slots), dim3(64), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
+            else WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false, true>), dim3(slots), dim3(64), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
+        } else if (lds_sums && !prio) {
+            WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true, false, false>), dim3(slots), dim3(64), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
+        } else if (lds_sums) {
+            WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, true>), dim3(slots), dim3(64), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
+        } else {
+            WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<1u, false>), dim3(slots), dim3(64), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
+        }
     } else {
-        if (lds_sums) { WDGS_BWR_LAUNCH(4u, true, tiles, 256); } else { WDGS_BWR_LAUNCH(4u, false, tiles, 256); }
+        unsigned long long* const no_tl = nullptr;
+        if (lds_sums) WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<4u, true>), dim3(tiles), dim3(256), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
+        else WDGS_LAUNCH(dev, "backward_rasterize", (backward_rasterize_kernel<4u, false>), dim3(tiles), dim3(256), pad_lds, WDGS_BWR_ARGS, no_tl, lw);
     }
-#undef WDGS_BWR_LAUNCH
+#undef WDGS_BWR_ARGS
     WDGS_CHECK_HIP(hipGetLastError());
     return WDGS_OK;
 }

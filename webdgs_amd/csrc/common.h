@@ -62,6 +62,8 @@ struct wdgs_device {
     struct Total { u32 launches = 0; float ms = 0.f; };
     std::map<std::string, Total> totals;
     std::vector<wdgs_tiled_forward*> forwards;  // live forward passes, for deferred overflow checks
+    // per-tile range tables of live forward passes -> the pass (api.hip: a backward pass that is handed such a table finds the pass's long-list work)
+    std::map<const void*, wdgs_tiled_forward*> range_tables;
     // forward passes whose PROJECTION the open recording consumes (wdgs_tiled_forward_encode_projected while capturing): handed to the
     // command buffer by wdgs_encoder_finish, checked and consumed by every wdgs_queue_submit of it
     std::vector<wdgs_tiled_forward*> capture_consumes;
@@ -155,7 +157,8 @@ int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out
 // Same, with the forward pass's stats epilogue folded into the single-block middle kernel (count must be > 0 for it to run).
 // frame (nullable): the forward pass's frame number, advanced by the scan kernel -- project.hip stamps the tiles of non-finite Splats with the number
 // the frame is ABOUT to get, so a stamp never has to be cleared (raster.hip compares)
-struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u32 capacity; u32* frame = nullptr; };
+// long_hdr (nullable): the header of the pass's long-list work (longlist.h), zeroed for the frame by the same kernel
+struct ScanStatsEpilogue { u32* stats; u32* visible_shards; u32* host_mirror; u32 capacity; u32* frame = nullptr; u32* long_hdr = nullptr; };
 int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep);
 
 int scan_block_sums_inplace(wdgs_device* dev, u32* block_sums, u32 num_blocks, const ScanStatsEpilogue& ep);

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "dmath.h"
+#include "longlist.h"
 
 namespace {
 
@@ -36,21 +37,16 @@ namespace {
 // evaluates WGSL's own formulas (min(e1, e2) = e2 < e1 ? e2 : e1, clamp = min(max(e, lo), hi): a NaN stays a NaN) with the full exp.  EXACT takes
 // every such operation in the oracle's form, so that a tile of non-finite Splats -- what a long run of the reference's schedule collects in tile 0 --
 // composites to the same bits: a NaN alpha makes the pixel's sums NaN for good (it never saturates, n_contrib keeps following the finite alphas).
-template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE, bool LONGSKIP, bool EXACT>
+template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE, bool EXACT>
 __device__ __attribute__((always_inline)) void rasterize_body(const RenderSettings& settings, const TileInfo& ti, const u32* __restrict__ splats, u32 num_splats,
                            const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                            const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
                            u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
-                           unsigned long long* __restrict__ timeline, const u32* __restrict__ long_flags, u32 tile_id, u32 sub,
-                           float4 (*s_geo_all)[65], float4 (*s_con_all)[65], float4 (*s_col_all)[65]) {
+                           unsigned long long* __restrict__ timeline, u32 tile_id, u32 sub, float4* s_geo, float4* s_con, float4* s_col) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
     const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
     const u32 lane = threadIdx.x & 63u;
-    const u32 slot = (WPW == 4u) ? sub : 0u;
-    float4* const s_geo = s_geo_all[slot];  // wave-private record sets
-    float4* const s_con = s_con_all[slot];
-    float4* const s_col = s_col_all[slot];
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;  // block origin
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -235,22 +231,219 @@ __device__ __attribute__((always_inline)) void rasterize_body(const RenderSettin
 }
 
 
+// ================================================================================================ long tile lists (longlist.h): the forward tasks
+// Shared by the count and the fill task of an item (block, chunk): the chunk's 64 entries, unpacked, and the records that overlap the block compacted
+// into the wave's record set -- exactly what the wave-per-block walk builds (EXACT forms: the tasks serve non-finite tiles too).  Returns the number
+// of records kept; *have / *g_idx: this lane's own entry.
+struct LongCtx {
+    RenderSettings settings; TileInfo ti;
+    const u32 *splats, *ranges, *sorted_keys, *sorted_vals, *count_ptr;
+    u32 num_splats;
+    u32 *out_rgba8; float* out_alpha; u32* out_ncontrib;
+};
+WD_DEV u32 long_chunk_records(const LongCtx& c, const LongBlock& blk, u32 chunk, u32 lane, float4* s_geo, float4* s_con, float4* s_col, float4* rec_out /*nullable: [64][3]*/) {
+    const float vx = c.settings.viewport_x, vy = c.settings.viewport_y;
+    const float cap = (c.settings.max_splat_radius_px > 0.0f) ? c.settings.max_splat_radius_px : 1e9f;
+    const u32 tile_x = blk.tile % c.ti.num_tiles_x, tile_y = blk.tile / c.ti.num_tiles_x;
+    const u32 bx = tile_x * 16u + (blk.sub & 1u) * 8u, by = tile_y * 16u + (blk.sub >> 1) * 8u;
+    const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
+    const u32 total = *c.count_ptr, start = c.ranges[blk.tile];
+    const u32 pos = chunk * 64u + lane, entry = start + pos;
+    const bool in_range = entry < total;
+    const u32 key = in_range ? c.sorted_keys[entry] : 0u;
+    const u32 val = in_range ? c.sorted_vals[entry] : 0xFFFFFFFFu;
+    const bool valid = (key >> 16u) == blk.tile + 1u && val < c.num_splats;
+    uint2 w01 = make_uint2(0u, 0u), w23 = w01, w45 = w01;
+    if (valid) {
+        const uint2* sp = reinterpret_cast<const uint2*>(c.splats + (size_t)val * 6);
+        w01 = sp[0]; w23 = sp[1]; w45 = sp[2];
+    }
+    const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
+    const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
+    const float ex = wd_min(wd_unpack_lo(w01.y), cap), ey = wd_min(wd_unpack_hi(w01.y), cap);
+    const bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+        const u32 slot = (u32)__popcll(m & ((1ull << lane) - 1ull));
+        s_geo[slot] = make_float4(cx, cy, ex, ey);
+        s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+        s_col[slot] = make_float4(__uint_as_float(w45.x), __uint_as_float(w45.y & 0xFFFFu), 0.0f, __uint_as_float(pos + 1u));   // r | g and b as the Splat's fp16 bits
+    }
+    if (rec_out && valid) {   // the entry as the backward walk wants it (backward_raster.hip: -conic / 2 throughout, the Gaussian's index)
+        float4* r = rec_out + (size_t)lane * 3u;
+        r[0] = make_float4(cx, cy, ex, ey);
+        r[1] = make_float4(-0.5f * wd_unpack_lo(w23.x), -0.5f * wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+        r[2] = make_float4(wd_unpack_lo(w45.x), wd_unpack_hi(w45.x), wd_unpack_lo(w45.y), __uint_as_float(val));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return (u32)__popcll(m);
+}
+
+// ---- the four kinds of task.  Everything a task decides on is uniform across the wave; no lane-number branches (longlist.h).
+// count / fill of item (block, chunk): the chunk's records; per pixel the records whose box holds it -- counted, or (fill) appended to the pixel's list
+WD_DEV void long_task_item(const LongCtx& c, const LongWork& lw, u32 item, bool fill, u32 lane, float4* s_geo, float4* s_con, float4* s_col) {
+    const u32 lb = lw.item_block[item];
+    if (lb == 0xFFFFFFFFu) return;   // (a slot of a tile that found no room)
+    const LongBlock blk = lw.blocks[lb];
+    LongSync* const sy = lw.sync + lb;
+    u32 row_base = 0u;
+    if (fill) {
+        const bool ready = ll_wait(&sy->scanned, 1u, lw.hdr, 0x201u);
+        row_base = ready ? (u32)__builtin_amdgcn_readfirstlane((int)sy->row_base) : LL_NO_ROWS;
+    }
+    if (row_base != LL_NO_ROWS) {
+        const u32 chunk = item - blk.first_item;
+        const u32 cnt = long_chunk_records(c, blk, chunk, lane, s_geo, s_con, s_col, fill ? nullptr : lw.records + (size_t)item * 192u);
+        const u32 W = wd_to_u32(c.settings.viewport_x), H = wd_to_u32(c.settings.viewport_y);
+        const u32 tile_x = blk.tile % c.ti.num_tiles_x, tile_y = blk.tile / c.ti.num_tiles_x;
+        const u32 pixel_x = tile_x * 16u + (blk.sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (blk.sub >> 1) * 8u + (lane >> 3);
+        const bool in_bounds = pixel_x < W && pixel_y < H;
+        const float px = (float)pixel_x + 0.5f, py = (float)pixel_y + 0.5f;
+        u32 k = fill ? lw.off[(size_t)item * 64u + lane] : 0u;
+        for (u32 i = 0; i < cnt; i++) {
+            const float4 geo = s_geo[i];
+            const float dx = px - geo.x, dy = py - geo.y;
+            const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;   // (tiled-rasterizer.wgsl:205-207)
+            if (inside && fill) {
+                const float4 con = s_con[i], col = s_col[i];
+                const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
+                const float xe = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
+                const float alpha = wd_clamp(wd_exp(xe) * con.w, 0.0f, 0.99f);
+                lw.rows[((size_t)row_base + k) * 64u + lane] = make_float4(alpha, col.x, col.y, col.w);
+            }
+            k += inside ? 1u : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();   // (the record set is rewritten by the wave's next task)
+        if (!fill) lw.cnt[(size_t)item * 64u + lane] = k;
+    }
+    ll_signal(fill ? &sy->filled : &sy->counted, lane);
+}
+
+// scan of block lb: where each chunk's part of every pixel's list starts; the block's rows
+WD_DEV void long_task_scan(const LongWork& lw, u32 lb, u32 lane) {
+    const LongBlock blk = lw.blocks[lb];
+    LongSync* const sy = lw.sync + lb;
+    if (blk.chunks == 0u) return;   // (a block record of a tile that found no room)
+    u32 base = LL_NO_ROWS, rows = 0u;
+    if (ll_wait(&sy->counted, blk.chunks, lw.hdr, 0x101u)) {
+        u32 run = 0u;
+        for (u32 ch = 0; ch < blk.chunks; ch++) {
+            const size_t at = (size_t)(blk.first_item + ch) * 64u + lane;
+            const u32 v = lw.cnt[at];
+            lw.off[at] = run;
+            run += v;
+        }
+        lw.total[(size_t)lb * 64u + lane] = run;
+        rows = run;
+#pragma unroll
+        for (u32 d = 32; d >= 1; d >>= 1) rows = max(rows, (u32)__shfl_xor((int)rows, (int)d, 64));
+        rows = (u32)__builtin_amdgcn_readfirstlane((int)rows);
+        // (lists nearly as long as the tile's: nothing to gain over the wave-per-block walk, which needs no rows)
+        const bool worth = rows <= (blk.chunks * 64u / 4u) * 3u;
+        const u32 want = (worth && lane == 0u) ? rows : 0u;   // (one lane asks for the rows, the others for none)
+        atomicAdd(&lw.hdr[LL_ROWS_WANTED], want);
+        const u32 b0 = (u32)__builtin_amdgcn_readfirstlane((int)atomicAdd(&lw.hdr[LL_ROWS], want));
+        if (worth && b0 + rows <= lw.max_rows && b0 + rows >= b0) base = b0;
+    }
+    sy->row_base = base;   // (uniform values, stored by every lane)
+    sy->rows = rows;
+    ll_signal(&sy->scanned, lane);
+}
+
+// walk of block lb: lane = pixel, trip j = element j of every pixel's list
+WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lane, float4* s_geo, float4* s_con, float4* s_col) {
+    const LongBlock blk = lw.blocks[lb];
+    LongSync* const sy = lw.sync + lb;
+    if (blk.chunks == 0u) return;
+    const bool filled = ll_wait(&sy->filled, blk.chunks, lw.hdr, 0x301u);
+    const u32 row_base = filled ? (u32)__builtin_amdgcn_readfirstlane((int)sy->row_base) : LL_NO_ROWS;
+    if (row_base == LL_NO_ROWS) {   // no rows: the wave-per-block walk, here (the block's main wave has left it alone)
+        rasterize_body<true, 4u, false, true>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
+                                              c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, s_geo, s_con, s_col);
+        return;
+    }
+    const u32 W = wd_to_u32(c.settings.viewport_x), H = wd_to_u32(c.settings.viewport_y);
+    const u32 tile_x = blk.tile % c.ti.num_tiles_x, tile_y = blk.tile / c.ti.num_tiles_x;
+    const u32 pixel_x = tile_x * 16u + (blk.sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (blk.sub >> 1) * 8u + (lane >> 3);
+    const bool in_bounds = pixel_x < W && pixel_y < H;
+    const u32 tot = lw.total[(size_t)lb * 64u + lane];
+    const u32 trips = min((u32)__builtin_amdgcn_readfirstlane((int)sy->rows), blk.chunks * 64u);
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f, A = 0.0f;
+    u32 last_contributor = 0u, jl = 0u;
+    const float4* const rows = lw.rows + (size_t)row_base * 64u + lane;
+    // rows arrive four trips ahead of their use (what is serial per pixel is A -> w -> A and the three colour FMAs)
+    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 e0 = (0u < tot) ? rows[0] : none, e1 = (1u < tot) ? rows[64] : none, e2 = (2u < tot) ? rows[128] : none, e3 = (3u < tot) ? rows[192] : none;
+    for (u32 j = 0; j < trips; j++) {
+        const float4 e = e0;
+        e0 = e1; e1 = e2; e2 = e3;
+        e3 = (j + 4u < tot) ? rows[(size_t)(j + 4u) * 64u] : none;
+        const bool active = j < tot && !(A > 0.99f);   // (tiled-rasterizer.wgsl:224-226: a saturated pixel skips the record)
+        if (active) {
+            const float alpha = e.x;
+            const float w = alpha * (1.0f - A);
+            cr = __builtin_fmaf(wd_unpack_lo(__float_as_uint(e.y)), w, cr);
+            cg = __builtin_fmaf(wd_unpack_hi(__float_as_uint(e.y)), w, cg);
+            cb = __builtin_fmaf(wd_unpack_lo(__float_as_uint(e.z)), w, cb);
+            A = A + w;
+            const bool contributes = alpha >= (1.0f / 255.0f);
+            last_contributor = contributes ? __float_as_uint(e.w) : last_contributor;
+            jl = contributes ? j + 1u : jl;
+        }
+        if ((j & 15u) == 15u && !__any(j + 1u < tot && !(A > 0.99f))) break;   // nothing left that could change a sum
+    }
+    if (in_bounds) {
+        const size_t p = (size_t)pixel_y * W + pixel_x;
+        const u32 r8 = wd_to_u32(fminf(fmaxf(cr, 0.0f), 1.0f) * 255.0f + 0.5f);
+        const u32 g8 = wd_to_u32(fminf(fmaxf(cg, 0.0f), 1.0f) * 255.0f + 0.5f);
+        const u32 b8 = wd_to_u32(fminf(fmaxf(cb, 0.0f), 1.0f) * 255.0f + 0.5f);
+        c.out_rgba8[p] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
+        c.out_alpha[p] = 1.0f - A;
+        c.out_ncontrib[p] = last_contributor;
+    }
+    lw.jlast[(size_t)lb * 64u + lane] = jl;
+    sy->walked = 1u;   // (uniform; the backward kernel -- a later launch -- reads it and the tile's mark)
+    atomicOr(&lw.flags[blk.tile], lane == 0u ? (16u << blk.sub) : 0u);
+}
+
+// One wave works the forward queue off: [count tasks][scan tasks][fill tasks][walk tasks] (longlist.h).  s_geo / s_con / s_col: the wave's own record set.
+__device__ __attribute__((always_inline)) void long_forward_help(const LongCtx c, const LongWork lw, float4* s_geo, float4* s_con, float4* s_col) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 n_items = min(lw.hdr[LL_ITEMS], lw.max_items), n_blocks = min(lw.hdr[LL_BLOCKS], lw.max_blocks);
+    const u32 n_tasks = 2u * (n_items + n_blocks);
+    __builtin_amdgcn_s_setprio(3);   // the long lists are the frame's longest chains: first in line for the issue slots
+    for (u32 t = ll_pull(&lw.hdr[LL_FWD_HEAD], n_tasks, lane); t != 0xFFFFFFFFu; t = ll_pull(&lw.hdr[LL_FWD_HEAD], n_tasks, lane)) {
+        if (t < n_items) long_task_item(c, lw, t, false, lane, s_geo, s_con, s_col);
+        else if (t < n_items + n_blocks) long_task_scan(lw, t - n_items, lane);
+        else if (t < 2u * n_items + n_blocks) long_task_item(c, lw, t - n_items - n_blocks, true, lane, s_geo, s_con, s_col);
+        else long_task_walk(c, lw, t - 2u * n_items - n_blocks, lane, s_geo, s_con, s_col);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
 // The kernel: one wave per 8x8 block; a tile marked as holding a non-finite Splat (nf_stamp[tile] == *nf_frame: project.hip stamps the tiles of such
 // Splats with the number the frame's scan kernel then gives the frame) takes the EXACT body, every other tile the fast one.  nf_stamp == nullptr:
-// nothing is known about the Splats -- every tile takes the EXACT body.
-template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE = false, bool LONGSKIP = false>
+// nothing is known about the Splats -- every tile takes the EXACT body.  HELP: the blocks of long tiles (lw.flags) are left to the tasks of longlist.h,
+// which every wave helps to work off once its own block is done.
+template <bool GAUSSIAN_MODE, u32 WPW, bool TIMELINE = false, bool HELP = false>
 __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings settings, TileInfo ti, const u32* __restrict__ splats, u32 num_splats,
                                                         const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                                                         const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
                                                         u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
-                                                        unsigned long long* __restrict__ timeline, const u32* __restrict__ long_flags,
-                                                        const u32* __restrict__ nf_stamp, const u32* __restrict__ nf_frame) {
+                                                        unsigned long long* __restrict__ timeline, const u32* __restrict__ nf_stamp, const u32* __restrict__ nf_frame, LongWork lw) {
     // (one record more than a chunk holds: the loop reads one record ahead)
     __shared__ float4 s_geo_all[WPW][65];  // centre.x, centre.y, extent.x, extent.y   (pixels)
     __shared__ float4 s_con_all[WPW][65];  // -0.5*conic.x, -conic.y, -0.5*conic.z, opacity (Gaussian mode: see the record build)
     __shared__ float4 s_col_all[WPW][65];  // r, g, b, position in the tile list + 1 (bits)
+    const u32 slot = (WPW == 4u) ? (threadIdx.x >> 6) : 0u;
+    float4* const s_geo = s_geo_all[slot];  // wave-private record sets
+    float4* const s_con = s_con_all[slot];
+    float4* const s_col = s_col_all[slot];
+    const u32 long_blocks = HELP ? lw.hdr[LL_BLOCKS] : 0u;   // (requested now, looked at when the wave's own block is done)
     // independent waves (no barrier is ever taken): one per 8x8 block
     u32 tile_id, sub;
+    bool mine = true;
     if (WPW == 4u) {
         tile_id = blockIdx.x; sub = threadIdx.x >> 6;
     } else {
@@ -258,24 +451,27 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
         const u32 k = blockIdx.x & 7u, j = blockIdx.x >> 3;
         tile_id = k + 8u * (j >> 2);
         sub = j & 3u;
-        if (tile_id >= ti.total_tiles) return;
+        mine = tile_id < ti.total_tiles;
     }
-    if (LONGSKIP && ((long_flags[tile_id] >> sub) & 1u)) return;   // (a long list: long_list_* below composite and write this block)
-    const bool exact = nf_stamp == nullptr || nf_stamp[tile_id] == *nf_frame;   // (uniform per workgroup)
-    if (exact)
-        rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, LONGSKIP, true>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
-                                                                     out_ncontrib, issue_priority, timeline, long_flags, tile_id, sub, s_geo_all, s_con_all, s_col_all);
-    else
-        rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, LONGSKIP, false>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
-                                                                      out_ncontrib, issue_priority, timeline, long_flags, tile_id, sub, s_geo_all, s_con_all, s_col_all);
+    if (HELP && mine && long_blocks != 0u && ((lw.flags[tile_id] >> sub) & 1u)) mine = false;   // (a long list: the tasks composite and write this block)
+    if (mine) {
+        const bool exact = nf_stamp == nullptr || nf_stamp[tile_id] == *nf_frame;   // (uniform per workgroup)
+        if (exact)
+            rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, true>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
+                                                               out_ncontrib, issue_priority, timeline, tile_id, sub, s_geo, s_con, s_col);
+        else
+            rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, false>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
+                                                                out_ncontrib, issue_priority, timeline, tile_id, sub, s_geo, s_con, s_col);
+    }
+    if (HELP && long_blocks != 0u)
+        long_forward_help(LongCtx{settings, ti, splats, ranges, sorted_keys, sorted_vals, count_ptr, num_splats, out_rgba8, out_alpha, out_ncontrib}, lw, s_geo, s_con, s_col);
 }
-
 
 }  // namespace
 
 int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo& ti, const void* splats, u32 num_splats, const void* ranges,
                      const void* sorted_keys, const void* sorted_vals, const void* count_ptr, u32 max_batches, void* out_rgba8, void* out_alpha,
-                     void* out_ncontrib, const void* nf_stamp, const void* nf_frame) {
+                     void* out_ncontrib, const void* nf_stamp, const void* nf_frame, const LongWork* long_work) {
     if (ti.total_tiles == 0) return WDGS_OK;
     const u32 max_entries = max_batches * 256u;  // compat cap: 32 batches x 256 splats per tile; 0 = unlimited
     // (one-wave workgroups help backward_rasterize -- 303 -> 295.5 us -- but not this kernel: 119.2 vs 119.8 us, r03m; workgroup = tile stays)
@@ -284,8 +480,9 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
     // WDGS_FWR_PRIO=0: no issue priorities (same-box A/B)
     static const u32 issue_priority = (std::getenv("WDGS_FWR_PRIO") && std::getenv("WDGS_FWR_PRIO")[0] == '0') ? 0u : 1u;
     const u32 issue_priority_now = (issue_priority && slots <= 8192u) ? 1u : 0u;  // launches whose waves (4 per tile in either workgroup shape) are all resident from the start
+    const LongWork lw = long_work ? *long_work : LongWork{};
 #define RASTER_ARGS st, ti, (const u32*)splats, num_splats, (const u32*)ranges, (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, \
-                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now, (unsigned long long*)nullptr, (const u32*)nullptr, (const u32*)nf_stamp, (const u32*)nf_frame
+                    (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib, issue_priority_now, (unsigned long long*)nullptr, (const u32*)nf_stamp, (const u32*)nf_frame, lw
     // WDGS_FWR_TIMELINE=<file> (measurement tool; eager launches of the Gaussian mode in its default workgroup shape): per-wave records appended to the file
     static const char* const timeline_file = std::getenv("WDGS_FWR_TIMELINE");
     if (timeline_file && st.gaussian_mode >= 0.5f && !one_wave && !dev->capturing) {
@@ -295,7 +492,7 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
         WDGS_CHECK_HIP(hipMemsetAsync(tl, 0, bytes, dev->stream));
         hipLaunchKernelGGL((rasterize_kernel<true, 4u, true>), dim3(ti.total_tiles), dim3(256), 0, dev->stream, st, ti, (const u32*)splats, num_splats, (const u32*)ranges,
                            (const u32*)sorted_keys, (const u32*)sorted_vals, (const u32*)count_ptr, max_entries, (u32*)out_rgba8, (float*)out_alpha, (u32*)out_ncontrib,
-                           issue_priority_now, tl, (const u32*)nullptr, (const u32*)nf_stamp, (const u32*)nf_frame);
+                           issue_priority_now, tl, (const u32*)nf_stamp, (const u32*)nf_frame, LongWork{});
         std::vector<unsigned long long> host((size_t)ti.total_tiles * 16u);
         WDGS_CHECK_HIP(hipMemcpyAsync(host.data(), tl, bytes, hipMemcpyDeviceToHost, dev->stream));
         WDGS_CHECK_HIP(hipStreamSynchronize(dev->stream));
@@ -305,7 +502,9 @@ int launch_rasterize(wdgs_device* dev, const RenderSettings& st, const TileInfo&
         return WDGS_OK;
     }
     if (st.gaussian_mode >= 0.5f) {
+        // (long tile lists, longlist.h: Gaussian mode, uncapped lists, the default workgroup shape)
         if (one_wave) WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);
+        else if (lw.hdr && lw.threshold && max_entries == 0u) WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 4u, false, true>), dim3(ti.total_tiles), dim3(256), 0, RASTER_ARGS);
         else WDGS_LAUNCH(dev, "rasterize", (rasterize_kernel<true, 4u>), dim3(ti.total_tiles), dim3(256), 0, RASTER_ARGS);
     } else {
         if (one_wave) WDGS_LAUNCH(dev, "rasterize_points", (rasterize_kernel<false, 1u>), dim3(slots), dim3(64), 0, RASTER_ARGS);

@@ -107,6 +107,7 @@ __device__ __forceinline__ void stats_epilogue(u32 carry, const ScanStatsEpilogu
             ep.host_mirror[0] = entries; ep.host_mirror[1] = vis; if (overflow) ep.host_mirror[2] = overflow; ep.host_mirror[3] = 0u;
         }
     }
+    if (ep.long_hdr && threadIdx.x < 8u) ep.long_hdr[threadIdx.x] = 0u;   // (longlist.h: LL_HDR_WORDS; segment_sort counts the frame's long tiles up from here)
 }
 
 // One block scans the block sums in place (exclusive), 256 x 16 at a time with a running carry (the forward pass hands over N/256 of
@@ -192,7 +193,7 @@ int forward_scan(wdgs_device* dev, u32* block_sums, u32 num_blocks, u32* column_
 }
 
 int scan_exclusive_u32(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out) {
-    return scan_exclusive_u32_stats(dev, s, in, out, count, total_out, ScanStatsEpilogue{nullptr, nullptr, nullptr, 0u, nullptr});
+    return scan_exclusive_u32_stats(dev, s, in, out, count, total_out, ScanStatsEpilogue{nullptr, nullptr, nullptr, 0u, nullptr, nullptr});
 }
 
 int scan_exclusive_u32_stats(wdgs_device* dev, ScanScratch* s, const u32* in, u32* out, u32 count, u32* total_out, const ScanStatsEpilogue& ep) {

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "longlist.h"
 
 namespace {
 
@@ -473,8 +474,36 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 
 // One workgroup per segment (= tile): stable sort of [start, end) by the low 16 key bits.  keys/vals `cur` hold the data (and receive
 // the result); `alt` is the other ping-pong pair, used as scratch by oversized segments only.
+// Long tile lists (longlist.h): the workgroup of a tile with more than lw.threshold entries reserves the tile's four block records and
+// 4 * ceil(n / 64) item slots and marks the tile; every other tile's mark is cleared.  (A tile that finds no room stays with the main waves.)
+__device__ void long_list_build(const LongWork& lw, u32 t, u32 n) {
+    __shared__ u32 s_first, s_lb;
+    const bool want = lw.threshold != 0u && n > lw.threshold;
+    if (!want) {   // (uniform per workgroup)
+        if (threadIdx.x == 0u) lw.flags[t] = 0u;
+        return;
+    }
+    const u32 chunks = (n + 63u) >> 6, need = 4u * chunks;
+    if (threadIdx.x == 0u) {
+        s_first = atomicAdd(&lw.hdr[LL_ITEMS], need);
+        s_lb = atomicAdd(&lw.hdr[LL_BLOCKS], 4u);
+    }
+    __syncthreads();
+    const u32 first = s_first, lb = s_lb;
+    const bool items_fit = first + need <= lw.max_items && first + need >= first, blocks_fit = lb + 4u <= lw.max_blocks;
+    const bool ok = items_fit && blocks_fit;
+    // item slots below the capacity belong to this tile either way: they name their block, or say that there is none
+    for (u32 i = threadIdx.x; i < need && first + i < lw.max_items && first + i >= first; i += SEG_THREADS) lw.item_block[first + i] = ok ? lb + i / chunks : 0xFFFFFFFFu;
+    if (threadIdx.x < 4u && lb + threadIdx.x < lw.max_blocks) {
+        const u32 b = lb + threadIdx.x;
+        lw.blocks[b] = LongBlock{t, threadIdx.x, first + threadIdx.x * chunks, ok ? chunks : 0u};
+        lw.sync[b] = LongSync{0u, LL_NO_ROWS, 0u, 0u, 0u, 0u, 0u, 0u};
+    }
+    if (threadIdx.x == 0u) lw.flags[t] = ok ? 0xFu : 0u;
+}
+
 __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
-                                                                    u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles) {
+                                                                    u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles, LongWork lw) {
     WD_STREAM_PRIO();
     __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP];  // one pair: every pass reads its input into registers before anyone scatters
     __shared__ seg_hist_t whist[SEG_THREADS / 64][SEG_BINS];
@@ -484,10 +513,14 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
     const u32 t = blockIdx.x;
     const u32 start = ranges[t];
     u32 end = ranges[t + 1u];          // (requested together with `start`: one round trip)
-    if (start == 0xFFFFFFFFu) return;  // empty tile (uniform per workgroup)
+    if (start == 0xFFFFFFFFu) {  // empty tile (uniform per workgroup)
+        if (lw.flags && threadIdx.x == 0u) lw.flags[t] = 0u;
+        return;
+    }
     // end of the segment = start of the next non-empty tile (ranges[T] = E ends the walk): the successor itself unless it is empty, in
     // which case every thread walks on (uniform addresses: the same few loads for the whole workgroup, no barrier)
     for (u32 nx = t + 1u; end == 0xFFFFFFFFu && nx < total_tiles;) { nx++; end = ranges[nx]; }
+    if (lw.flags) long_list_build(lw, t, (end != 0xFFFFFFFFu && end > start) ? end - start : 0u);
     if (end <= start + 1u || end == 0xFFFFFFFFu) return;
     const u32 n = end - start;
     if (n <= SEG_CAP) {
@@ -610,7 +643,7 @@ uint32_t wdgs_sorter_capacity(wdgs_sorter* s) { return s ? s->capacity : 0; }
 
 // Stable sort of keys laid out as (segment id << 16 | 16-bit minor key): LSD passes over the segment bits, the range table of
 // the segments, then one workgroup per segment for the minor key.  `ranges` = u32[num_segments + 1], written here.
-int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges) {
+int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u32* ranges, const LongWork* lw) {
     wdgs_device* dev = s->dev;
     const u32 bits = std::min(segment_bits, 16u);
     const u32 passes = (bits + 7u) / 8u;
@@ -650,7 +683,7 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
         WDGS_LAUNCH(dev, "tile_ranges", tile_ranges_kernel, dim3(ceil_div(num_segments + 1, 4)), dim3(256), 0, s->keys[src], s->count_ptr, num_segments, ranges);
     if (num_segments > 0)
         WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(num_segments), dim3(SEG_THREADS), 0, s->keys[src], s->vals[src], s->keys[src ^ 1],
-                    s->vals[src ^ 1], ranges, num_segments);
+                    s->vals[src ^ 1], ranges, num_segments, lw ? *lw : LongWork{});
     WDGS_CHECK_HIP(hipGetLastError());
     s->final_out_index = src;
     return WDGS_OK;
@@ -660,7 +693,7 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
 // pass, on tx): ONE stable pass on the tile ROW (ty = tile / num_tiles_x <= 255), which also builds the per-tile range table -- its
 // histogram kernel initialises the table, its scatter lowers ranges[tile] to the first position it writes for the tile -- then the per-tile
 // depth sort.  Input in ping-pong 0, result in ping-pong 1.  4E + 16E + 16E bytes.
-int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges) {
+int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* ranges, const LongWork* lw) {
     wdgs_device* dev = s->dev;
     const u32 tiles = num_tiles_x * num_tiles_y;
     const DigitOf rows{0u, num_tiles_y - 1u, 0xFFFFFFFFu / num_tiles_x + 1u};  // (num_tiles_x >= 2)
@@ -681,7 +714,7 @@ int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* rang
         WDGS_LAUNCH(dev, "sort_scatter", sort_scatter_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->vals[0], s->keys[1], s->vals[1], s->count_ptr, rows,
                     s->num_parts, s->counts, s->totals, ranges, 2u, tiles);
     }
-    WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(tiles), dim3(SEG_THREADS), 0, s->keys[1], s->vals[1], s->keys[0], s->vals[0], ranges, tiles);
+    WDGS_LAUNCH(dev, "sort_segments", segment_sort_kernel, dim3(tiles), dim3(SEG_THREADS), 0, s->keys[1], s->vals[1], s->keys[0], s->vals[0], ranges, tiles, lw ? *lw : LongWork{});
     WDGS_CHECK_HIP(hipGetLastError());
     s->final_out_index = 1;
     return WDGS_OK;

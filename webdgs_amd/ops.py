@@ -443,6 +443,18 @@ class TiledForwardPass:
         check(self.device.lib.wdgs_tiled_forward_check(self.handle, st))
         return np.array(list(st), np.uint32)
 
+    def setLongLists(self, threshold: int, maxItems: int = 0, maxRows: int = 0) -> None:
+        """Long tile lists (``include/webdgs.h``: wdgs_tiled_forward_set_long_lists): tiles with more than ``threshold`` entries get per-pixel lists
+        (0: off); ``maxItems`` / ``maxRows`` size the work (0: keep).  Synchronises; drop command buffers recorded against the pass."""
+        check(self.device.lib.wdgs_tiled_forward_set_long_lists(self.handle, int(threshold), int(maxItems), int(maxRows)))
+
+    def longListStats(self) -> dict:
+        """The last frame's long-list work: what it wanted and what the pass has room for (synchronises)."""
+        st = (C.c_uint32 * 12)()
+        check(self.device.lib.wdgs_tiled_forward_long_list_stats(self.handle, st))
+        keys = ("blocksWanted", "itemsWanted", "forwardQueue", "backwardQueue", "rowsUsed", "rowsWanted", "stalled", "_", "maxItems", "maxBlocks", "maxRows", "threshold")
+        return {k: int(v) for k, v in zip(keys, st) if k != "_"}
+
     def destroy(self) -> None:
         if self.destroyed:
             return
