@@ -240,6 +240,7 @@ struct LongCtx {
     const u32 *splats, *ranges, *sorted_keys, *sorted_vals, *count_ptr;
     u32 num_splats;
     u32 *out_rgba8; float* out_alpha; u32* out_ncontrib;
+    const u32 *nf_stamp, *nf_frame;
 };
 WD_DEV u32 long_chunk_records(const LongCtx& c, const LongBlock& blk, u32 chunk, u32 lane, float4* s_geo, float4* s_con, float4* s_col, float4* rec_out /*nullable: [64][3]*/) {
     const float vx = c.settings.viewport_x, vy = c.settings.viewport_y;
@@ -267,7 +268,10 @@ WD_DEV u32 long_chunk_records(const LongCtx& c, const LongBlock& blk, u32 chunk,
         const u32 slot = (u32)__popcll(m & ((1ull << lane) - 1ull));
         s_geo[slot] = make_float4(cx, cy, ex, ey);
         s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-        s_col[slot] = make_float4(__uint_as_float(w45.x), __uint_as_float(w45.y & 0xFFFFu), 0.0f, __uint_as_float(pos + 1u));   // r | g and b as the Splat's fp16 bits
+        // r | g and b as the Splat's fp16 bits; z: 1 = a NaN centre, conic or opacity -- the record's alpha is a NaN at EVERY pixel (the NaN reaches the
+        // exponent's argument through either FMA, or the product with the opacity)
+        const bool nan_rec = __builtin_isunordered(cx, cy) | __builtin_isunordered(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x)) | __builtin_isunordered(wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+        s_col[slot] = make_float4(__uint_as_float(w45.x), __uint_as_float(w45.y & 0xFFFFu), nan_rec ? 1.0f : 0.0f, __uint_as_float(pos + 1u));
     }
     if (rec_out && valid) {   // the entry as the backward walk wants it (backward_raster.hip: -conic / 2 throughout, the Gaussian's index)
         float4* r = rec_out + (size_t)lane * 3u;
@@ -301,12 +305,20 @@ WD_DEV void long_task_item(const LongCtx& c, const LongWork& lw, u32 item, bool 
         const bool in_bounds = pixel_x < W && pixel_y < H;
         const float px = (float)pixel_x + 0.5f, py = (float)pixel_y + 0.5f;
         u32 k = fill ? lw.off[(size_t)item * 64u + lane] : 0u;
+        // A pixel that has met a record with a NaN alpha holds NaN sums from then on: a further such record leaves it exactly as it is (w = NaN again,
+        // n_contrib follows numbers only).  Of the NaN records of a chunk a pixel's list therefore keeps the first one only -- which is what keeps the lists
+        // of the late regime's tile 0 short: ~60 real records and one element per chunk of the thousands of non-finite Gaussians piled up behind them.
+        bool poisoned = false;
         for (u32 i = 0; i < cnt; i++) {
             const float4 geo = s_geo[i];
+            const float4 col = s_col[i];
             const float dx = px - geo.x, dy = py - geo.y;
-            const bool inside = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;   // (tiled-rasterizer.wgsl:205-207)
+            const bool in_box = ((int)in_bounds & (int)!(fabsf(dx) > geo.z) & (int)!(fabsf(dy) > geo.w)) != 0;   // (tiled-rasterizer.wgsl:205-207)
+            const bool nan_rec = col.z != 0.0f;
+            const bool inside = in_box && !(nan_rec && poisoned);
+            poisoned = poisoned || (in_box && nan_rec);
             if (inside && fill) {
-                const float4 con = s_con[i], col = s_col[i];
+                const float4 con = s_con[i];
                 const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
                 const float xe = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
                 const float alpha = wd_clamp(wd_exp(xe) * con.w, 0.0f, 0.99f);
@@ -339,8 +351,9 @@ WD_DEV void long_task_scan(const LongWork& lw, u32 lb, u32 lane) {
 #pragma unroll
         for (u32 d = 32; d >= 1; d >>= 1) rows = max(rows, (u32)__shfl_xor((int)rows, (int)d, 64));
         rows = (u32)__builtin_amdgcn_readfirstlane((int)rows);
-        // (lists nearly as long as the tile's: nothing to gain over the wave-per-block walk, which needs no rows)
-        const bool worth = rows <= (blk.chunks * 64u / 4u) * 3u;
+        // (per-pixel lists pay when they are much shorter than the tile's: a trip of the per-pixel backward walk fetches its record from memory and
+        // adds its contributions itself -- several times the cost of a record of the wave-per-block walk)
+        const bool worth = rows * 6u <= blk.chunks * 64u;
         const u32 want = (worth && lane == 0u) ? rows : 0u;   // (one lane asks for the rows, the others for none)
         atomicAdd(&lw.hdr[LL_ROWS_WANTED], want);
         const u32 b0 = (u32)__builtin_amdgcn_readfirstlane((int)atomicAdd(&lw.hdr[LL_ROWS], want));
@@ -359,8 +372,12 @@ WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lan
     const bool filled = ll_wait(&sy->filled, blk.chunks, lw.hdr, 0x301u);
     const u32 row_base = filled ? (u32)__builtin_amdgcn_readfirstlane((int)sy->row_base) : LL_NO_ROWS;
     if (row_base == LL_NO_ROWS) {   // no rows: the wave-per-block walk, here (the block's main wave has left it alone)
-        rasterize_body<true, 4u, false, true>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
-                                              c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, s_geo, s_con, s_col);
+        if (c.nf_stamp == nullptr || c.nf_stamp[blk.tile] == *c.nf_frame)
+            rasterize_body<true, 4u, false, true>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
+                                                  c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, s_geo, s_con, s_col);
+        else
+            rasterize_body<true, 4u, false, false>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
+                                                   c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, s_geo, s_con, s_col);
         return;
     }
     const u32 W = wd_to_u32(c.settings.viewport_x), H = wd_to_u32(c.settings.viewport_y);
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
                                                                 out_ncontrib, issue_priority, timeline, tile_id, sub, s_geo, s_con, s_col);
     }
     if (HELP && long_blocks != 0u)
-        long_forward_help(LongCtx{settings, ti, splats, ranges, sorted_keys, sorted_vals, count_ptr, num_splats, out_rgba8, out_alpha, out_ncontrib}, lw, s_geo, s_con, s_col);
+        long_forward_help(LongCtx{settings, ti, splats, ranges, sorted_keys, sorted_vals, count_ptr, num_splats, out_rgba8, out_alpha, out_ncontrib, nf_stamp, nf_frame}, lw, s_geo, s_con, s_col);
 }
 
 }  // namespace
