@@ -52,3 +52,4 @@ for k, (n, ms) in sorted(dev.kernelTimes().items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:24s} launches/step={n / steps:5.1f}  ms/step={ms / steps:8.4f}")
     tot += ms / steps
 print(f"  kernel sum ms/step = {tot:.4f}")
+print("  long-list work of the last frame:", t.forwardPass.longListStats())

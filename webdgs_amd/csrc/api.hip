@@ -801,7 +801,9 @@ static int forward_alloc_long_lists(wdgs_tiled_forward* op, u32 threshold, u32 i
     if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.total, sizeof(u32) * 64u * (size_t)lw.max_blocks, true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.jlast, sizeof(u32) * 64u * (size_t)lw.max_blocks, true, d->stream);
     if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.records, sizeof(float4) * 192u * (size_t)lw.max_items, false, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.rows, sizeof(float4) * 64u * (size_t)lw.max_rows, false, d->stream);
+    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.rows, sizeof(u32) * 256u * (size_t)lw.max_rows, false, d->stream);
+    lw.nf_stamp = op->nf_stamp;
+    lw.nf_frame = op->stats + FRAME_WORD;
     op->long_lists = lw;   // (what has been allocated is freed with the pass, also after a failure)
     if (r != WDGS_OK) { forward_free_long_lists(op); return r; }
     op->long_flags_capacity = tiles;
@@ -1055,7 +1057,7 @@ int wdgs_tiled_forward_set_viewport(wdgs_tiled_forward* op, uint32_t w, uint32_t
     WDGS_REQUIRE((uint64_t)ceil_div(w, 16) * ceil_div(h, 16) + 1 <= 0xFFFFu, WDGS_E_CAPACITY, "viewport %ux%u has too many tiles for the 16-bit tile field", w, h);
     WDGS_REQUIRE(!op->dev->capturing, WDGS_E_STATE, "wdgs_tiled_forward_set_viewport while recording a command buffer");
     forward_set_viewport(op, w, h);
-    if (op->tile_info.total_tiles > op->nf_capacity) { (void)wdgs_sync_lanes(op->dev); WDGS_TRY(forward_alloc_nf_stamp(op)); }
+    if (op->tile_info.total_tiles > op->nf_capacity) { (void)wdgs_sync_lanes(op->dev); WDGS_TRY(forward_alloc_nf_stamp(op)); op->long_lists.nf_stamp = op->long_lists.hdr ? op->nf_stamp : nullptr; }
     if (op->long_lists.hdr && op->tile_info.total_tiles > op->long_flags_capacity) {
         (void)wdgs_sync_lanes(op->dev);
         free_dev(op->long_lists.flags);

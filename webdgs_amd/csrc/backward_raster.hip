@@ -372,17 +372,22 @@ __device__ __attribute__((always_inline)) void long_backward_help(const RenderSe
         const float g_b = g.z;
         f2 ar_rg = f2{0.f, 0.f};
         float ar_b = 0.f;
-        const float4* const rows = lw.rows + (size_t)sy.row_base * 64u + lane;
+        const u32* const rows = lw.rows + ((size_t)sy.row_base * 64u + lane) * 4u + 3u;   // (the element's fourth word: the position)
         const float4* const recs = lw.records + (size_t)blk.first_item * 192u;
         u32 trips = left;
 #pragma unroll
         for (u32 d = 32; d >= 1; d >>= 1) trips = max(trips, (u32)__shfl_xor((int)trips, (int)d, 64));
+        // the position of trip tr + 2 and the record of trip tr + 1 are requested while trip tr computes (two dependent fetches per element otherwise)
+        auto position = [&](u32 tr) -> u32 { return (tr < left) ? rows[(size_t)(left - 1u - tr) * 256u] - 1u : 0u; };
+        u32 pos_next = position(0u);
+        float4 geo_n = make_float4(0.f, 0.f, 0.f, 0.f), con_n = geo_n, col_n = geo_n;
+        if (0u < left) { const float4* const r = recs + (size_t)pos_next * 3u; geo_n = r[0]; con_n = r[1]; col_n = r[2]; }
+        pos_next = position(1u);
         for (u32 tr = 0; tr < trips; tr++) {
+            const float4 geo = geo_n, con = con_n, col = col_n;
+            if (tr + 1u < left) { const float4* const r = recs + (size_t)pos_next * 3u; geo_n = r[0]; con_n = r[1]; col_n = r[2]; }   // (chunk pos >> 6, entry pos & 63 of the block's items: 64 x 3 per item)
+            pos_next = position(tr + 2u);
             if (tr >= left) continue;   // (this lane's list is done; others go on)
-            const u32 j = left - 1u - tr;
-            const u32 pos = __float_as_uint(rows[(size_t)j * 64u].w) - 1u;   // position of the element's entry in the tile list
-            const float4* const r = recs + (size_t)pos * 3u;                   // (chunk pos >> 6, entry pos & 63 of the block's items: 64 x 3 per item)
-            const float4 geo = r[0], con = r[1], col = r[2];
             const f2 d = pxy - f2{geo.x, geo.y};
             const float syd = con.y * d.y;
             const float t1 = __builtin_fmaf(con.x, d.x, syd + syd);

@@ -60,21 +60,33 @@ struct LongWork {
     u32* total;           // [max_blocks][64]: length of the pixel's list
     u32* jlast;           // [max_blocks][64]: list index of the pixel's last contributor + 1 (0: none) -- where the backward walk starts
     float4* records;      // [max_items][64][3]: geo, con, col of the chunk's kept records (per block)
-    float4* rows;         // [max_rows][64]: {alpha, r | g (fp16 x 2), b (fp16), position in the tile list + 1}
+    u32* rows;            // [max_rows][64][4]: per pixel {alpha, r | g (fp16 x 2), b (fp16), position in the tile list + 1}
     u32 max_blocks, max_items, max_rows, threshold;
+    // (nullable) the forward pass's marks of tiles that hold a non-finite Splat (project.hip): such a tile is NOT given per-pixel lists -- what makes it
+    // long is, in every run seen, a pile of NaN Gaussians behind a few real ones, which the EXACT body of raster.hip drops by the chunk
+    const u32 *nf_stamp, *nf_frame;
 };
 
 // The primitives below are written WITHOUT lane-0 branches: every lane of the wave executes every operation (the one lane that counts adds 1, the
 // others 0; uniform values are stored by all lanes).  A branch on the lane number inside the task loop, followed by a read of "the first lane", relies
 // on the lanes having reconverged at that read -- which the compiler does not promise in a loop with many exits: the first version of this file hung
 // there, lane 0 parked at a join the others never reached.
-WD_DEV u32 ll_load_acquire(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+//
+// Memory.  A task's results are read by tasks on other CUs and other XCDs of the same launch.  Made visible the textbook way -- plain stores, a release
+// fence at agent scope, an acquire fence at the reader -- every task writes back and every reader invalidates a whole L2 (buffer_wbl2 / buffer_inv sc1:
+// the XCDs' L2s are not coherent with each other for ordinary memory), which on a frame whose L2s are full of freshly written image data took longer
+// than the work: 1.9 ms for the 1 400 tasks of the late regime's one long tile (profiles/r08o_*).  So everything that crosses between tasks of ONE launch
+// is written and read with relaxed agent-scope atomic accesses of 32 bits (ll_st / ll_ld: sc1 loads and stores, coherent across the XCDs location by
+// location, no cache maintenance), a writer waits for its stores to complete before it counts itself as done (ll_signal), and a reader does not
+// load before it has seen the count (ll_wait).  What only the NEXT launch reads (records, jlast, the marks) is stored plainly.
+WD_DEV void ll_st(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WD_DEV u32 ll_ld(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // The wave waits until *p >= target (a counter of tasks in front of this one in the queue: their waves are running).  The wait is bounded -- a wave
 // must be able to leave whatever happens: after ~0.1 s it notes the stall in the header (code, for the host to report) and returns false.
 WD_DEV bool ll_wait(const u32* p, u32 target, u32* hdr, u32 code) {
     for (u32 spins = 0; spins < (1u << 19); spins++) {
-        if ((u32)__builtin_amdgcn_readfirstlane((int)ll_load_acquire(p)) >= target) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if ((u32)__builtin_amdgcn_readfirstlane((int)ll_ld(p)) >= target) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (orders the loads that follow behind this one; no cache maintenance)
             return true;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -82,13 +94,16 @@ WD_DEV bool ll_wait(const u32* p, u32 target, u32* hdr, u32 code) {
     atomicMax(&hdr[LL_STALLED], code);
     return false;
 }
-// The wave's stores so far become visible to whoever acquires *p afterwards; then the task counts as done (one lane adds 1, the others 0).
+// The wave's ll_st stores have completed (s_waitcnt); then the task counts as done (one lane adds 1, the others 0).
 WD_DEV void ll_signal(u32* p, u32 lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(p, lane == 0u ? 1u : 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_fetch_add(p, lane == 0u ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Next task of a queue (uniform), or 0xFFFFFFFF when it is exhausted.
 WD_DEV u32 ll_pull(u32* head, u32 n_tasks, u32 lane) {
+    // (a look before the ticket: every wave of the launch comes here once its own block is done, and 32 000 read-modify-writes of ONE word take a
+    // millisecond between them -- profiles/r08p_*; once the queue has run out the word is only read)
+    if ((u32)__builtin_amdgcn_readfirstlane((int)ll_ld(head)) >= n_tasks) return 0xFFFFFFFFu;
     const u32 t = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_fetch_add(head, lane == 0u ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (lane 0: the value before its own 1)
     return t < n_tasks ? t : 0xFFFFFFFFu;
 }

@@ -262,15 +262,21 @@ WD_DEV u32 long_chunk_records(const LongCtx& c, const LongBlock& blk, u32 chunk,
     const float cx = (wd_unpack_lo(w01.x) * 0.5f + 0.5f) * vx;
     const float cy = (wd_unpack_hi(w01.x) * -0.5f + 0.5f) * vy;
     const float ex = wd_min(wd_unpack_lo(w01.y), cap), ey = wd_min(wd_unpack_hi(w01.y), cap);
-    const bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+    bool ok = valid && !((blk_x0 - cx) > ex || (cx - blk_x1) > ex || (blk_y0 - cy) > ey || (cy - blk_y1) > ey);
+    // nan_rec: a NaN centre, conic or opacity -- the record's alpha is a NaN at EVERY pixel (the NaN reaches the exponent's argument through either FMA,
+    // or the product with the opacity).  A pixel that has met such a record inside its box holds NaN sums from then on, and a further one leaves it
+    // exactly as it is (w = NaN again; n_contrib follows numbers only).  If such a record's centre or extent is a NaN, EVERY pixel of the block is inside
+    // its box (the box tests are comparisons): behind the first such record of the chunk every nan_rec of the chunk is dropped here -- the late
+    // regime's tile 0, thousands of non-finite Gaussians behind ~60 real ones, keeps one record per chunk.
+    const bool nan_rec = ok && (__builtin_isunordered(cx, cy) | __builtin_isunordered(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x)) | __builtin_isunordered(wd_unpack_lo(w23.y), wd_unpack_hi(w45.y)));
+    const unsigned long long universal = __ballot(nan_rec && (__builtin_isunordered(cx, cy) | __builtin_isunordered(ex, ey)));   // (NaN alpha AND inside at every pixel)
+    if (universal != 0ull) ok = ok && !(nan_rec && lane > (u32)__builtin_ctzll(universal));
     const unsigned long long m = __ballot(ok);
     if (ok) {
         const u32 slot = (u32)__popcll(m & ((1ull << lane) - 1ull));
         s_geo[slot] = make_float4(cx, cy, ex, ey);
         s_con[slot] = make_float4(-0.5f * wd_unpack_lo(w23.x), -wd_unpack_hi(w23.x), -0.5f * wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
-        // r | g and b as the Splat's fp16 bits; z: 1 = a NaN centre, conic or opacity -- the record's alpha is a NaN at EVERY pixel (the NaN reaches the
-        // exponent's argument through either FMA, or the product with the opacity)
-        const bool nan_rec = __builtin_isunordered(cx, cy) | __builtin_isunordered(wd_unpack_lo(w23.x), wd_unpack_hi(w23.x)) | __builtin_isunordered(wd_unpack_lo(w23.y), wd_unpack_hi(w45.y));
+        // r | g and b as the Splat's fp16 bits; z: 1 = nan_rec
         s_col[slot] = make_float4(__uint_as_float(w45.x), __uint_as_float(w45.y & 0xFFFFu), nan_rec ? 1.0f : 0.0f, __uint_as_float(pos + 1u));
     }
     if (rec_out && valid) {   // the entry as the backward walk wants it (backward_raster.hip: -conic / 2 throughout, the Gaussian's index)
@@ -294,7 +300,7 @@ WD_DEV void long_task_item(const LongCtx& c, const LongWork& lw, u32 item, bool 
     u32 row_base = 0u;
     if (fill) {
         const bool ready = ll_wait(&sy->scanned, 1u, lw.hdr, 0x201u);
-        row_base = ready ? (u32)__builtin_amdgcn_readfirstlane((int)sy->row_base) : LL_NO_ROWS;
+        row_base = ready ? (u32)__builtin_amdgcn_readfirstlane((int)ll_ld(&sy->row_base)) : LL_NO_ROWS;
     }
     if (row_base != LL_NO_ROWS) {
         const u32 chunk = item - blk.first_item;
@@ -304,7 +310,7 @@ WD_DEV void long_task_item(const LongCtx& c, const LongWork& lw, u32 item, bool 
         const u32 pixel_x = tile_x * 16u + (blk.sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (blk.sub >> 1) * 8u + (lane >> 3);
         const bool in_bounds = pixel_x < W && pixel_y < H;
         const float px = (float)pixel_x + 0.5f, py = (float)pixel_y + 0.5f;
-        u32 k = fill ? lw.off[(size_t)item * 64u + lane] : 0u;
+        u32 k = fill ? ll_ld(&lw.off[(size_t)item * 64u + lane]) : 0u;
         // A pixel that has met a record with a NaN alpha holds NaN sums from then on: a further such record leaves it exactly as it is (w = NaN again,
         // n_contrib follows numbers only).  Of the NaN records of a chunk a pixel's list therefore keeps the first one only -- which is what keeps the lists
         // of the late regime's tile 0 short: ~60 real records and one element per chunk of the thousands of non-finite Gaussians piled up behind them.
@@ -322,12 +328,13 @@ WD_DEV void long_task_item(const LongCtx& c, const LongWork& lw, u32 item, bool 
                 const float t1 = __builtin_fmaf(con.x, dx, con.y * dy);
                 const float xe = __builtin_fmaf(t1, dx, (con.z * dy) * dy);
                 const float alpha = wd_clamp(wd_exp(xe) * con.w, 0.0f, 0.99f);
-                lw.rows[((size_t)row_base + k) * 64u + lane] = make_float4(alpha, col.x, col.y, col.w);
+                u32* const e = lw.rows + (((size_t)row_base + k) * 64u + lane) * 4u;
+                ll_st(e, __float_as_uint(alpha)); ll_st(e + 1, __float_as_uint(col.x)); ll_st(e + 2, __float_as_uint(col.y)); ll_st(e + 3, __float_as_uint(col.w));
             }
             k += inside ? 1u : 0u;
         }
         __builtin_amdgcn_wave_barrier();   // (the record set is rewritten by the wave's next task)
-        if (!fill) lw.cnt[(size_t)item * 64u + lane] = k;
+        if (!fill) ll_st(&lw.cnt[(size_t)item * 64u + lane], k);
     }
     ll_signal(fill ? &sy->filled : &sy->counted, lane);
 }
@@ -339,14 +346,23 @@ WD_DEV void long_task_scan(const LongWork& lw, u32 lb, u32 lane) {
     if (blk.chunks == 0u) return;   // (a block record of a tile that found no room)
     u32 base = LL_NO_ROWS, rows = 0u;
     if (ll_wait(&sy->counted, blk.chunks, lw.hdr, 0x101u)) {
+        // (the counts were stored through to memory, ll_st; ONE invalidation of this XCD's caches here lets the loop read them with ordinary loads,
+        // eight in flight -- read one by one with coherent loads the 177 chunks of the late regime's tile cost 177 memory round trips)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         u32 run = 0u;
-        for (u32 ch = 0; ch < blk.chunks; ch++) {
-            const size_t at = (size_t)(blk.first_item + ch) * 64u + lane;
-            const u32 v = lw.cnt[at];
-            lw.off[at] = run;
-            run += v;
+        const u32* const cnt0 = lw.cnt + (size_t)blk.first_item * 64u + lane;
+        u32* const off0 = lw.off + (size_t)blk.first_item * 64u + lane;
+        for (u32 ch = 0; ch < blk.chunks; ch += 8u) {
+            u32 v[8];
+#pragma unroll
+            for (u32 q = 0; q < 8u; q++) v[q] = (ch + q < blk.chunks) ? cnt0[(size_t)(ch + q) * 64u] : 0u;
+#pragma unroll
+            for (u32 q = 0; q < 8u; q++) {
+                if (ch + q < blk.chunks) ll_st(off0 + (size_t)(ch + q) * 64u, run);
+                run += v[q];
+            }
         }
-        lw.total[(size_t)lb * 64u + lane] = run;
+        ll_st(&lw.total[(size_t)lb * 64u + lane], run);
         rows = run;
 #pragma unroll
         for (u32 d = 32; d >= 1; d >>= 1) rows = max(rows, (u32)__shfl_xor((int)rows, (int)d, 64));
@@ -359,8 +375,8 @@ WD_DEV void long_task_scan(const LongWork& lw, u32 lb, u32 lane) {
         const u32 b0 = (u32)__builtin_amdgcn_readfirstlane((int)atomicAdd(&lw.hdr[LL_ROWS], want));
         if (worth && b0 + rows <= lw.max_rows && b0 + rows >= b0) base = b0;
     }
-    sy->row_base = base;   // (uniform values, stored by every lane)
-    sy->rows = rows;
+    ll_st(&sy->row_base, base);   // (uniform values, stored by every lane)
+    ll_st(&sy->rows, rows);
     ll_signal(&sy->scanned, lane);
 }
 
@@ -370,7 +386,7 @@ WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lan
     LongSync* const sy = lw.sync + lb;
     if (blk.chunks == 0u) return;
     const bool filled = ll_wait(&sy->filled, blk.chunks, lw.hdr, 0x301u);
-    const u32 row_base = filled ? (u32)__builtin_amdgcn_readfirstlane((int)sy->row_base) : LL_NO_ROWS;
+    const u32 row_base = filled ? (u32)__builtin_amdgcn_readfirstlane((int)ll_ld(&sy->row_base)) : LL_NO_ROWS;
     if (row_base == LL_NO_ROWS) {   // no rows: the wave-per-block walk, here (the block's main wave has left it alone)
         if (c.nf_stamp == nullptr || c.nf_stamp[blk.tile] == *c.nf_frame)
             rasterize_body<true, 4u, false, true>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
@@ -384,31 +400,39 @@ WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lan
     const u32 tile_x = blk.tile % c.ti.num_tiles_x, tile_y = blk.tile / c.ti.num_tiles_x;
     const u32 pixel_x = tile_x * 16u + (blk.sub & 1u) * 8u + (lane & 7u), pixel_y = tile_y * 16u + (blk.sub >> 1) * 8u + (lane >> 3);
     const bool in_bounds = pixel_x < W && pixel_y < H;
-    const u32 tot = lw.total[(size_t)lb * 64u + lane];
-    const u32 trips = min((u32)__builtin_amdgcn_readfirstlane((int)sy->rows), blk.chunks * 64u);
+    const u32 tot = ll_ld(&lw.total[(size_t)lb * 64u + lane]);
+    const u32 trips = min((u32)__builtin_amdgcn_readfirstlane((int)ll_ld(&sy->rows)), blk.chunks * 64u);
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, A = 0.0f;
     u32 last_contributor = 0u, jl = 0u;
-    const float4* const rows = lw.rows + (size_t)row_base * 64u + lane;
-    // rows arrive four trips ahead of their use (what is serial per pixel is A -> w -> A and the three colour FMAs)
-    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 e0 = (0u < tot) ? rows[0] : none, e1 = (1u < tot) ? rows[64] : none, e2 = (2u < tot) ? rows[128] : none, e3 = (3u < tot) ? rows[192] : none;
-    for (u32 j = 0; j < trips; j++) {
-        const float4 e = e0;
-        e0 = e1; e1 = e2; e2 = e3;
-        e3 = (j + 4u < tot) ? rows[(size_t)(j + 4u) * 64u] : none;
-        const bool active = j < tot && !(A > 0.99f);   // (tiled-rasterizer.wgsl:224-226: a saturated pixel skips the record)
-        if (active) {
-            const float alpha = e.x;
-            const float w = alpha * (1.0f - A);
-            cr = __builtin_fmaf(wd_unpack_lo(__float_as_uint(e.y)), w, cr);
-            cg = __builtin_fmaf(wd_unpack_hi(__float_as_uint(e.y)), w, cg);
-            cb = __builtin_fmaf(wd_unpack_lo(__float_as_uint(e.z)), w, cb);
-            A = A + w;
-            const bool contributes = alpha >= (1.0f / 255.0f);
-            last_contributor = contributes ? __float_as_uint(e.w) : last_contributor;
-            jl = contributes ? j + 1u : jl;
+    // (the rows were stored through to memory by the fill tasks, ll_st: one invalidation of this XCD's caches, then ordinary 16-byte loads, eight
+    // trips ahead of their use -- what is serial per pixel is A -> w -> A and the three colour FMAs)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const float4* const rows = reinterpret_cast<const float4*>(lw.rows) + (size_t)row_base * 64u + lane;
+    auto row = [&](u32 j) -> float4 { return (j < tot) ? rows[(size_t)j * 64u] : make_float4(0.f, 0.f, 0.f, 0.f); };
+    float4 ring[8];
+#pragma unroll
+    for (u32 q = 0; q < 8u; q++) ring[q] = row(q);
+    bool done = false;
+    for (u32 j0 = 0; j0 < trips && !done; j0 += 8u) {
+#pragma unroll
+        for (u32 q = 0; q < 8u; q++) {
+            const u32 j = j0 + q;
+            const float4 e = ring[q];
+            ring[q] = row(j + 8u);
+            const bool active = j < tot && !(A > 0.99f);   // (tiled-rasterizer.wgsl:224-226: a saturated pixel skips the record)
+            if (active) {
+                const float alpha = e.x;
+                const float w = alpha * (1.0f - A);
+                cr = __builtin_fmaf(wd_unpack_lo(__float_as_uint(e.y)), w, cr);
+                cg = __builtin_fmaf(wd_unpack_hi(__float_as_uint(e.y)), w, cg);
+                cb = __builtin_fmaf(wd_unpack_lo(__float_as_uint(e.z)), w, cb);
+                A = A + w;
+                const bool contributes = alpha >= (1.0f / 255.0f);
+                last_contributor = contributes ? __float_as_uint(e.w) : last_contributor;
+                jl = contributes ? j + 1u : jl;
+            }
         }
-        if ((j & 15u) == 15u && !__any(j + 1u < tot && !(A > 0.99f))) break;   // nothing left that could change a sum
+        done = !__any(j0 + 8u < tot && !(A > 0.99f));   // nothing left that could change a sum
     }
     if (in_bounds) {
         const size_t p = (size_t)pixel_y * W + pixel_x;

@@ -478,7 +478,7 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 // 4 * ceil(n / 64) item slots and marks the tile; every other tile's mark is cleared.  (A tile that finds no room stays with the main waves.)
 __device__ void long_list_build(const LongWork& lw, u32 t, u32 n) {
     __shared__ u32 s_first, s_lb;
-    const bool want = lw.threshold != 0u && n > lw.threshold;
+    const bool want = lw.threshold != 0u && n > lw.threshold && !(lw.nf_stamp && lw.nf_stamp[t] == *lw.nf_frame);
     if (!want) {   // (uniform per workgroup)
         if (threadIdx.x == 0u) lw.flags[t] = 0u;
         return;
