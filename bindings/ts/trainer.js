@@ -68,6 +68,7 @@ class Trainer {
     // The metric views of a densify event are independent until normalizeMetricCounts (integer atomics: any order gives the same bits): they are
     // dealt to `metricLanes` op sets, each on a device lane of its own, all adding into set 0's counts (TiledBackwardPass.setMetricCountsTarget).
     this.metricLanes = Math.max(1, Math.min(Math.floor(o.metricLanes || Trainer.DEFAULT_LANES), hip.MAX_LANES));
+    this.longLists = null;      // long tile lists (csrc/longlist.h): null = the library's defaults; { threshold, maxItems, maxRows } for the passes this trainer builds
     this.moreMetricSets = [];   // [forwardPass, rasterizer, metricsPass, target, cameraBuffer] of metric lanes 1..
     this.dpGrad = null; this.dpVisible = null; this.dpRows = null; this.dpFlag = null; this.stateSliced = false;
     this.dcWords = null;
@@ -207,10 +208,35 @@ class Trainer {
     if (deferred) throw deferred;
   }
 
-  newOpSet(w, h) {
-    const fw = new hip.TiledForwardPass(this.device, this.pointCloud, this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer,
-      { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
+  /** A forward pass of this trainer: the deferred SH-DC source, and the long-list settings if any were given (this.longLists; null = the library's defaults). */
+  newForwardPass(cam, w, h) {
+    const fw = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
     fw.setDcSource(this.dcWords);
+    if (this.longLists) fw.setLongLists(this.longLists.threshold === undefined ? 2048 : this.longLists.threshold, this.longLists.maxItems || 0, this.longLists.maxRows || 0);
+    return fw;
+  }
+
+  /** Long tile lists (csrc/longlist.h) work in scratch of a fixed size; a tile that finds no room is composited the ordinary way -- correct, but as slow
+   *  as its list is long.  The work's header says what the last frame wanted: looked at where the host waits anyway (a densify event), and every pass is
+   *  given room for 1.5 x that (command buffers recorded against the old scratch are dropped). */
+  growLongLists() {
+    let needItems = 0, needRows = 0;
+    for (const fw of this.forwardPasses()) {
+      const st = fw.longListStats();
+      if (st.threshold && st.stalled) console.warn('a long-list task gave up waiting (code 0x' + st.stalled.toString(16) + '): the frame\'s long tiles are not to be trusted');
+      if (st.threshold && (st.itemsWanted > st.maxItems || st.rowsWanted > st.maxRows)) {
+        needItems = Math.max(needItems, st.itemsWanted, st.maxItems); needRows = Math.max(needRows, st.rowsWanted, st.maxRows);
+      }
+    }
+    if (!needItems) return;
+    this.longLists = Object.assign({}, this.longLists || {}, { maxItems: Math.floor(needItems * 1.5), maxRows: Math.floor(needRows * 1.5) });
+    console.warn('long-list scratch enlarged to ' + this.longLists.maxItems + ' chunk slots and ' + this.longLists.maxRows + ' rows');
+    this.invalidateCommandBuffers();
+    for (const fw of this.forwardPasses()) fw.setLongLists(this.longLists.threshold === undefined ? 2048 : this.longLists.threshold, this.longLists.maxItems, this.longLists.maxRows);
+  }
+
+  newOpSet(w, h) {
+    const fw = this.newForwardPass(this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer, w, h);
     return [fw, new hip.TiledRasterizer({ device: this.device, forwardPass: fw, format: 'rgba8unorm' }),
       new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig })];
   }
@@ -221,8 +247,7 @@ class Trainer {
     this.lastViewportWidth = w; this.lastViewportHeight = h;
     const cam = this.cameraBuffers.length ? this.cameraBuffers[0] : this.metricsCameraBuffer;
     if (!this.forwardPass) {
-      this.forwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
-      this.forwardPass.setDcSource(this.dcWords);
+      this.forwardPass = this.newForwardPass(cam, w, h);
     } else this.forwardPass.setViewport(w, h);
     if (!this.rasterizer) this.rasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.forwardPass, format: 'rgba8unorm' });
     if (!this.backwardPass || this.recreateBackward) {
@@ -245,8 +270,7 @@ class Trainer {
     this.destroyMoreMetricSets();
     if (this.metricsTarget) this.metricsTarget.destroy();
     this.metricsViewportWidth = w; this.metricsViewportHeight = h;
-    this.metricsForwardPass = new hip.TiledForwardPass(this.device, this.pointCloud, this.metricsCameraBuffer, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
-    this.metricsForwardPass.setDcSource(this.dcWords);
+    this.metricsForwardPass = this.newForwardPass(this.metricsCameraBuffer, w, h);
     this.metricsRasterizer = new hip.TiledRasterizer({ device: this.device, forwardPass: this.metricsForwardPass, format: 'rgba8unorm' });
     this.metricsPass = new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig });
     this.metricsTarget = this.device.createBuffer({ size: 4 * w * h, label: 'metrics-gt-downsampled' });
@@ -259,8 +283,7 @@ class Trainer {
     const w = this.metricsViewportWidth, h = this.metricsViewportHeight;
     while (this.moreMetricSets.length < k) {
       const cam = this.device.createBuffer({ size: 272, label: 'metrics camera uniform' });
-      const fw = new hip.TiledForwardPass(this.device, this.pointCloud, cam, { viewportWidth: w, viewportHeight: h, renderMode: 'gaussian', maxTileEntries: this.tileEntries() });
-      fw.setDcSource(this.dcWords);
+      const fw = this.newForwardPass(cam, w, h);
       this.moreMetricSets.push([fw, new hip.TiledRasterizer({ device: this.device, forwardPass: fw, format: 'rgba8unorm' }),
         new hip.TiledBackwardPass(this.device, this.pointCloud, { viewportWidth: w, viewportHeight: h, trainingConfig: this.trainingConfig }),
         this.device.createBuffer({ size: 4 * w * h, label: 'metrics-gt-downsampled' }), cam]);
@@ -398,6 +421,7 @@ class Trainer {
     this.stepItersPerSec = this.stepItersPerSec === 0 ? inst : this.stepItersPerSec * 0.9 + inst * 0.1;   // trainer.ts:647-651
     if (shouldDensify) {
       this.drain();
+      this.growLongLists();
       await this.runDensifyPruneMultiView();
       const req = this.consumePointCloudSwapRequest();
       if (req) this.applyPointCloudSwap(req);

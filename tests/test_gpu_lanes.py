@@ -15,9 +15,10 @@ from harness import assert_bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _train(dev, overlap, steps, vpr, densify_at=None, batch_views=None):
+def _train(dev, overlap, steps, vpr, densify_at=None, batch_views=None, long_lists=None):
     cfg, g, sh, cameras, images = dp_common.dataset(dev)
     t = Trainer(dev, seed=5, world_size=1, rank=0, views_per_rank=vpr, overlap_views=overlap, batch_views=batch_views)
+    t.longLists = long_lists
     sched = dict(enabled=False) if densify_at is None else dict(enabled=True, warmupIterations=densify_at, interval=1000, stopIterations=10 ** 6)
     t.setDensifyPruneConfig(dict(schedule=sched, metricViews=3, cloneThresholdCount=5, splitScaleThreshold=0.03, pruneOpacity=0.2, maxNewPointsPerStep=300))
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
@@ -53,6 +54,20 @@ def test_overlapped_views_leave_the_same_bits(hip_device, vpr, lanes, batch_view
     assert_bits_equal(a["sh"], b["sh"], f"sh, {vpr} views per step: two lanes vs one")
     for k in a["state"]:
         assert_bits_equal(a["state"][k], b["state"][k], f"optimizer state {k}: two lanes vs one")
+
+
+def test_long_tile_lists_on_three_lanes(hip_device):
+    """the long-list passes of round 4 kept their scratch in function-local statics, which views running on different lanes would have
+    shared.  The scratch now belongs to the forward pass (one per view of the batch): five views per step on three lanes with per-pixel lists for
+    every tile above 40 entries -- in recorded command buffers, across a densify rebuild -- leave the bits of the one-lane run with the lists off."""
+    steps, vpr = 8, 5
+    a = _train(hip_device, 3, steps, vpr, densify_at=9, long_lists=dict(threshold=40, maxItems=8192, maxRows=65536))
+    b = _train(hip_device, False, steps, vpr, densify_at=9, long_lists=dict(threshold=0))
+    assert a["on_lanes"] > 0 and a["n"] == b["n"] != 6000
+    assert_bits_equal(a["g"], b["g"], "gaussians: long lists on three lanes vs none on one")
+    assert_bits_equal(a["sh"], b["sh"], "sh: long lists on three lanes vs none on one")
+    for k in a["state"]:
+        assert_bits_equal(a["state"][k], b["state"][k], f"optimizer state {k}: long lists on three lanes vs none on one")
 
 
 def test_overlap_survives_a_densify_rebuild(hip_device):

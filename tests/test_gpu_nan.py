@@ -38,7 +38,7 @@ def differences(a, b, what, fp=None):
     return ""
 
 
-def step_differences(orc, dev, cfg, g, sh, cam, target, steps=2, pipeline_factory=None):
+def step_differences(orc, dev, cfg, g, sh, cam, target, steps=2, pipeline_factory=None, keep=False):
     """Runs `steps` training steps through the operator classes and through the oracle; returns the list of stages that differ (all of them, in order)."""
     st, ti = synth.render_settings(cfg), synth.tile_info(cfg.width, cfg.height, 0)
     ref_g, ref_sh = g.copy(), sh.copy()
@@ -74,7 +74,8 @@ def step_differences(orc, dev, cfg, g, sh, cam, target, steps=2, pipeline_factor
                     out.append(d)
         return out
     finally:
-        pipe.destroy()
+        if not keep:
+            pipe.destroy()
 
 
 def poisoned(cfg, field, value, every=7):
@@ -220,3 +221,43 @@ def test_trainer_trajectory_with_non_finite_gaussians_equals_the_oracle_trainer(
         assert nan_rows > 300, f"non-finite Gaussians survive the rebuilds and spread ({nan_rows})"
     finally:
         t.destroy()
+
+
+def _pipeline_with_long_lists(threshold, items=0, rows=0, seen=None):
+    def make(dev, cfg, g, sh, cam):
+        p = harness.HipPipeline(dev, cfg, g, sh, cam)
+        p.fwd.setLongLists(threshold, items, rows)
+        if seen is not None:
+            seen.append(p)
+        return p
+    return make
+
+
+@pytest.mark.parametrize("case", ["every-tile", "no-item-slots", "no-rows", "off"])
+def test_long_list_tasks_and_their_fallbacks(hip_device, orc, case):
+    """The per-pixel lists of long tiles (csrc/longlist.h) at a threshold of 48 entries, so that most tiles of an ordinary scene take them: built by the
+    sort, counted / scanned / filled / walked by tasks inside the rasterization kernel, walked backwards by the backward kernel's helpers.  With room
+    for everything; with item slots for a few tiles only (the others stay with the wave-per-block walk: the no-room branch of the build); with a row
+    pool that runs out (the blocks that find it empty are walked the plain way by their walk task); and switched off.  Two steps against the oracle."""
+    cfg = harness.small_config("c1", num_points=9000, width=160, height=112, s0=0.004, fy=140.0)
+    g, sh, cam = harness.scene(cfg)
+    rng = np.random.default_rng(23)
+    target = rng.integers(0, 255, (cfg.height, cfg.width, 4), dtype=np.uint8)
+    threshold, items, rows = dict([("every-tile", (48, 8192, 65536)), ("no-item-slots", (48, 64, 65536)), ("no-rows", (48, 8192, 96)), ("off", (0, 0, 0))])[case]
+    seen = []
+    diffs = step_differences(orc, hip_device, cfg, g, sh, cam, target, steps=2, pipeline_factory=_pipeline_with_long_lists(threshold, items, rows, seen), keep=True)
+    try:
+        st = seen[0].fwd.longListStats()
+        assert st["stalled"] == 0, st
+        if case == "every-tile":
+            assert st["blocksWanted"] >= 100 and st["itemsWanted"] <= st["maxItems"] and st["rowsWanted"] == st["rowsUsed"] > 0, st
+            assert st["forwardQueue"] >= 2 * (st["itemsWanted"] + st["blocksWanted"]), st
+        elif case == "no-item-slots":
+            assert st["itemsWanted"] > st["maxItems"], st
+        elif case == "no-rows":
+            assert st["rowsUsed"] > st["maxRows"], ("blocks asked a pool that had run out", st)
+        else:
+            assert st["threshold"] == 0 and st["blocksWanted"] == 0, st
+    finally:
+        seen[0].destroy()
+    assert not diffs, "\n".join(diffs)

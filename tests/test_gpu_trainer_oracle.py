@@ -51,8 +51,8 @@ def _compare(t, o, what):
     assert t.getIteration() == o.iteration and t.optimizer.getIteration() == o.optimizer_iteration, what
 
 
-@pytest.mark.parametrize("use_cb", [True, False])
-def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb):
+@pytest.mark.parametrize("use_cb,long_lists", [(True, None), (False, None), (True, 40)], ids=["recorded", "eager", "recorded-long-lists"])
+def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb, long_lists):
     from oracle import oracle_trainer
     dev = hip_device
     cfg = harness.small_config("c2", num_points=5000, width=128, height=96, s0=0.01)
@@ -67,6 +67,8 @@ def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb):
 
     o = oracle_trainer.OracleTrainer(g, sh, cfg.sh_deg, list(cams), imgs, densify=dens)
     t = Trainer(dev, seed=0, use_command_buffers=use_cb)
+    if long_lists:   # per-pixel lists (csrc/longlist.h) for every tile above 40 entries: most tiles, in the training and the metric passes, in recorded command buffers
+        t.longLists = dict(threshold=long_lists, maxItems=8192, maxRows=65536)
     t.setDensifyPruneConfig(dens)
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset(cameras, images)
@@ -90,6 +92,11 @@ def test_trainer_trajectory_equals_the_oracle_trainer(hip_device, orc, use_cb):
                 assert int(d["counts_raw"].max()) >= 3, "counts were accumulated over the views (divisor > 1 matters)"
                 assert t.getLastDensifyPruneIteration() == o.last_densify_iteration == it
         _compare(t, o, "end of run")
+        if long_lists:
+            st = t.forwardPass.longListStats()
+            # (whether a block's pixels got lists of their own or its walk task took the plain walk -- lists pay only when 6 x shorter than the tile's --
+            # is the scan task's decision; tests/test_gpu_nan.py::test_long_list_tasks_and_their_fallbacks pins scenes of either kind)
+            assert st["threshold"] == long_lists and st["blocksWanted"] >= 40 and st["stalled"] == 0 and st["forwardQueue"] >= 2 * (st["itemsWanted"] + st["blocksWanted"]), st
         assert sizes[12] != sizes[11] and sizes[22] != sizes[21], sizes
         assert t.getNextDensifyPruneIteration() is None
     finally:

@@ -765,8 +765,6 @@ static int forward_alloc_nf_stamp(wdgs_tiled_forward* op) {
     free_dev(op->nf_stamp);
     op->nf_stamp = nullptr;
     op->nf_capacity = 0;
-    op->long_lists = LongWork{};
-    op->long_flags_capacity = 0;
     WDGS_TRY(wdgs_alloc((void**)&op->nf_stamp, sizeof(u32) * (size_t)op->tile_info.total_tiles, true, op->dev->stream));
     op->nf_capacity = op->tile_info.total_tiles;
     return WDGS_OK;
@@ -825,6 +823,8 @@ int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* c
     op->dc_source = nullptr;
     op->nf_stamp = nullptr;
     op->nf_capacity = 0;
+    op->long_lists = LongWork{};
+    op->long_flags_capacity = 0;
     op->host_stats = nullptr;
     op->scanner = nullptr;
     op->sorter = nullptr;

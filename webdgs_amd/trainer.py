@@ -118,6 +118,8 @@ class Trainer:
         self._dp_rows: Optional[ops.HipBuffer] = None
         self._dp_flag: Optional[ops.HipBuffer] = None
         self._agree_word: Optional[ops.HipBuffer] = None
+        # long tile lists (csrc/longlist.h): None = the library's defaults; dict(threshold=, maxItems=, maxRows=) for the passes this trainer builds
+        self.longLists: Optional[dict] = None
         self._state_sliced = False  # optimizer state of non-owned slices is stale until syncOptimizerState()
         self.exchange_timing = False  # bracket the collectives with events on the device stream (bench.py)
         self._exchange_events: list = []
@@ -311,15 +313,40 @@ class Trainer:
         return nxt if nxt <= stop else None
 
     # ------------------------------------------------------------------ pipelines
+    def _new_forward_pass(self, cameraBuffer, w: int, h: int) -> ops.TiledForwardPass:
+        fw = ops.TiledForwardPass(self.device, self.pointCloud, cameraBuffer, dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
+        fw.setDcSource(self._dc_words)
+        if self.longLists is not None:   # (None: the library's defaults -- threshold 2048, room for 4096 chunk slots and 32768 rows)
+            fw.setLongLists(int(self.longLists.get("threshold", 2048)), int(self.longLists.get("maxItems", 0)), int(self.longLists.get("maxRows", 0)))
+        return fw
+
+    def _grow_long_lists(self) -> None:
+        """Long tile lists (csrc/longlist.h) work in scratch of a fixed size; a tile that finds no room is composited the ordinary way -- correct, but as
+        slow as its list is long.  The work's header says what the last frame wanted: looked at where the host waits anyway (a densify event), and every
+        pass is given room for 1.5 x that (command buffers recorded against the old scratch are dropped)."""
+        import warnings
+        need_items = need_rows = 0
+        for fw in self._forward_passes():
+            st = fw.longListStats()
+            if st["threshold"] and st["stalled"]:
+                warnings.warn(f"a long-list task gave up waiting (code {st['stalled']:#x}): the frame's long tiles are not to be trusted", RuntimeWarning, stacklevel=3)
+            if st["threshold"] and (st["itemsWanted"] > st["maxItems"] or st["rowsWanted"] > st["maxRows"]):
+                need_items, need_rows = max(need_items, st["itemsWanted"], st["maxItems"]), max(need_rows, st["rowsWanted"], st["maxRows"])
+        if not need_items:
+            return
+        self.longLists = dict(self.longLists or {}, maxItems=int(need_items * 1.5), maxRows=int(need_rows * 1.5))
+        warnings.warn(f"long-list scratch enlarged to {self.longLists['maxItems']} chunk slots and {self.longLists['maxRows']} rows", RuntimeWarning, stacklevel=3)
+        self._invalidate_command_buffers()
+        for fw in self._forward_passes():
+            fw.setLongLists(int(self.longLists.get("threshold", 2048)), self.longLists["maxItems"], self.longLists["maxRows"])
+
     def ensurePipelines(self, width: int, height: int) -> None:
         if (max(1, int(width)), max(1, int(height))) != (self.lastViewportWidth, self.lastViewportHeight):
             self._invalidate_command_buffers()
         self.lastViewportWidth, self.lastViewportHeight = max(1, int(width)), max(1, int(height))
         w, h = self.lastViewportWidth, self.lastViewportHeight
         if self.forwardPass is None:
-            self.forwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
-                                                    dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
-            self.forwardPass.setDcSource(self._dc_words)
+            self.forwardPass = self._new_forward_pass(self.cameraBuffer, w, h)
         else:
             self.forwardPass.setViewport(w, h)
         if self.rasterizer is None:
@@ -333,9 +360,7 @@ class Trainer:
             more[0].setViewport(w, h)
             more[2].setViewport(w, h)
         while len(self._more_op_sets) < self._op_sets - 1:
-            fw = ops.TiledForwardPass(self.device, self.pointCloud, self.cameraBuffer,
-                                      dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
-            fw.setDcSource(self._dc_words)
+            fw = self._new_forward_pass(self.cameraBuffer, w, h)
             self._more_op_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
                                        ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))])
         if self.optimizer is not None and self.world_size * self.views_per_rank == 1:
@@ -354,9 +379,7 @@ class Trainer:
             setattr(self, name, None)
         self._destroy_more_metric_sets()
         self.metricsViewportWidth, self.metricsViewportHeight = w, h
-        self.metricsForwardPass = ops.TiledForwardPass(self.device, self.pointCloud, self.metricsCameraBuffer,
-                                                       dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
-        self.metricsForwardPass.setDcSource(self._dc_words)
+        self.metricsForwardPass = self._new_forward_pass(self.metricsCameraBuffer, w, h)
         self.metricsRasterizer = ops.TiledRasterizer(dict(device=self.device, forwardPass=self.metricsForwardPass, format="rgba8unorm"))
         self.metricsPass = ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig))
         self.metricsTarget = self.device.createBuffer(4 * w * h, "metrics-gt-downsampled")
@@ -369,8 +392,7 @@ class Trainer:
         w, h = self.metricsViewportWidth, self.metricsViewportHeight
         while len(self._more_metric_sets) < k:
             cam = self.device.createBuffer(272, "metrics camera uniform")
-            fw = ops.TiledForwardPass(self.device, self.pointCloud, cam, dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
-            fw.setDcSource(self._dc_words)
+            fw = self._new_forward_pass(cam, w, h)
             self._more_metric_sets.append([fw, ops.TiledRasterizer(dict(device=self.device, forwardPass=fw, format="rgba8unorm")),
                                            ops.TiledBackwardPass(self.device, self.pointCloud, dict(viewportWidth=w, viewportHeight=h, trainingConfig=self.trainingConfig)),
                                            self.device.createBuffer(4 * w * h, "metrics-gt-downsampled"), cam])
@@ -532,6 +554,7 @@ class Trainer:
         self.stepItersPerSec = inst if self.stepItersPerSec == 0 else self.stepItersPerSec * 0.9 + inst * 0.1
         if shouldDensify:
             self.drain()
+            self._grow_long_lists()
             self.runDensifyPruneMultiView()
             req = self.consumePointCloudSwapRequest()
             if req is not None:
