@@ -51,7 +51,7 @@ export class Trainer {
   syncOptimizerState(): void;
   pipelineDepth: number; keepGradients: boolean; fuseGeometryAdam: boolean; useCommandBuffers: boolean;
   /** Long tile lists (csrc/longlist.h): null = the library's defaults; set before the first step to give the passes this trainer builds other sizes. */
-  longLists: { threshold?: number; maxItems?: number; maxRows?: number } | null;
+  longLists: { threshold?: number; maxItems?: number; maxRows?: number; maxItemsCap?: number; maxRowsCap?: number } | null;
   /** Enlarges the long-list scratch of every pass when the last frame wanted more than there is room for (called at densify events). */
   growLongLists(): void;
   readonly lanes: number; readonly viewsPerRank: number; readonly worldSize: number; readonly rank: number;

@@ -174,6 +174,9 @@ class Trainer {
   start() {   // trainer.ts:499-511
     if (!this.pointCloud || this.trainCameras.length === 0) { console.log('Cannot start training: Missing point cloud or dataset.'); return; }
     this.isTraining = true; this.iteration = 0; this.stepItersPerSec = 0; this.stepMs = 0; this.lastDensifyPruneIteration = null;
+    // the lanes this trainer will use come into being now (the library creates a lane's stream and event at its first use, ~5 ms each: otherwise
+    // the first densify event, which is the first to touch the metric lanes, pays for them)
+    for (let k = 1; k < Math.max(this.lanes, this.metricLanes); k++) { this.device.laneOrder(k, 0); this.device.laneOrder(0, k); }
   }
   stop() { this.isTraining = false; if (this.device.handle !== null && this.tickets.length) this.drain(); }
   getIsTraining() { return this.isTraining; }
@@ -216,20 +219,26 @@ class Trainer {
     return fw;
   }
 
-  /** Long tile lists (csrc/longlist.h) work in scratch of a fixed size; a tile that finds no room is composited the ordinary way -- correct, but as slow
-   *  as its list is long.  The work's header says what the last frame wanted: looked at where the host waits anyway (a densify event), and every pass is
-   *  given room for 1.5 x that (command buffers recorded against the old scratch are dropped). */
+  /** Long tile lists (csrc/longlist.h) work in scratch of a fixed size; a frame whose long tiles find no room is composited the ordinary way -- correct, but
+   *  as slow as its longest list.  The work's header says what the last frame wanted: looked at where the host waits anyway (a densify event), and every
+   *  pass is given room for 1.5 x that -- up to longLists.maxItemsCap / maxRowsCap (8 192 chunk slots: 33 000 entries of long tiles; 65 536 rows).  A
+   *  frame that wants more than the caps is FULL of long tiles (a dense cloud at a small viewport): the path is not for it (longlist.h: ll_frame_on) and
+   *  the scratch is left alone.  (Command buffers recorded against the old scratch are dropped.) */
   growLongLists() {
-    let needItems = 0, needRows = 0;
+    const ll = this.longLists || {};
+    const capItems = ll.maxItemsCap === undefined ? 8192 : ll.maxItemsCap, capRows = ll.maxRowsCap === undefined ? 65536 : ll.maxRowsCap;
+    let haveItems = 0, haveRows = 0, needItems = 0, needRows = 0;
     for (const fw of this.forwardPasses()) {
       const st = fw.longListStats();
-      if (st.threshold && st.stalled) console.warn('a long-list task gave up waiting (code 0x' + st.stalled.toString(16) + '): the frame\'s long tiles are not to be trusted');
-      if (st.threshold && (st.itemsWanted > st.maxItems || st.rowsWanted > st.maxRows)) {
-        needItems = Math.max(needItems, st.itemsWanted, st.maxItems); needRows = Math.max(needRows, st.rowsWanted, st.maxRows);
-      }
+      if (!st.threshold) continue;
+      if (st.stalled) console.warn('a long-list task gave up waiting (code 0x' + st.stalled.toString(16) + '): the frame\'s long tiles are not to be trusted');
+      haveItems = Math.max(haveItems, st.maxItems); haveRows = Math.max(haveRows, st.maxRows);
+      if (st.itemsWanted <= capItems) { needItems = Math.max(needItems, st.itemsWanted); needRows = Math.max(needRows, st.rowsWanted); }
     }
-    if (!needItems) return;
-    this.longLists = Object.assign({}, this.longLists || {}, { maxItems: Math.floor(needItems * 1.5), maxRows: Math.floor(needRows * 1.5) });
+    const items = needItems > haveItems ? Math.max(haveItems, Math.min(Math.floor(needItems * 1.5), capItems)) : haveItems;
+    const rows = needRows > haveRows ? Math.max(haveRows, Math.min(Math.floor(needRows * 1.5), capRows)) : haveRows;
+    if (items === haveItems && rows === haveRows) return;
+    this.longLists = Object.assign({}, ll, { maxItems: items, maxRows: rows });
     console.warn('long-list scratch enlarged to ' + this.longLists.maxItems + ' chunk slots and ' + this.longLists.maxRows + ' rows');
     this.invalidateCommandBuffers();
     for (const fw of this.forwardPasses()) fw.setLongLists(this.longLists.threshold === undefined ? 2048 : this.longLists.threshold, this.longLists.maxItems, this.longLists.maxRows);

@@ -229,7 +229,7 @@ int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out);
 /* Long tile lists.  The reference stages at most 32 x 256 = 8 192 entries of a tile (tiled-rasterizer.wgsl:59-60, 125) and drops the rest; this
  * library composites every entry, and gives the blocks of a tile with more than `threshold` entries per-PIXEL lists, built and walked by tasks that the
  * waves of the rasterization kernels work off themselves (csrc/longlist.h) -- no launch, no host decision: the path is part of every recording and taken
- * on the device.  Results do not depend on it.  A pass is created with threshold 2048, room for 4096 (block, 64-entry chunk) slots and 32768 list rows;
+ * on the device.  Results do not depend on it.  A pass is created with threshold 2048, room for 1024 (block, 64-entry chunk) slots and 8192 list rows (13 MB);
  * a tile that finds no room is composited the ordinary way (correct, slow).  set_long_lists re-sizes the work (threshold 0: off; items / rows 0: keep);
  * synchronises, not allowed while recording, command buffers recorded against the pass must be dropped.  long_list_stats (synchronises) returns
  * {block records wanted, item slots wanted, forward queue position, backward queue position, rows handed out, rows wanted, stall code (0 = none), 0,

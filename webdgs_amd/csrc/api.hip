@@ -770,10 +770,12 @@ static int forward_alloc_nf_stamp(wdgs_tiled_forward* op) {
     return WDGS_OK;
 }
 
+// The long-list work of a pass lives in ONE device allocation (twelve tables carved out of it: a pass is built inside a densify event, where every
+// hipMalloc counts) plus the per-tile marks, which follow the viewport.
 static void forward_free_long_lists(wdgs_tiled_forward* op) {
     LongWork& lw = op->long_lists;
-    free_dev(lw.hdr); free_dev(lw.sync); free_dev(lw.flags); free_dev(lw.blocks); free_dev(lw.item_block); free_dev(lw.nlist); free_dev(lw.cnt); free_dev(lw.off);
-    free_dev(lw.total); free_dev(lw.jlast); free_dev(lw.records); free_dev(lw.rows);
+    free_dev(lw.hdr);     // (the base of the allocation)
+    free_dev(lw.flags);
     lw = LongWork{};
     op->long_flags_capacity = 0;
 }
@@ -788,26 +790,27 @@ static int forward_alloc_long_lists(wdgs_tiled_forward* op, u32 threshold, u32 i
     lw.max_blocks = std::max(lw.max_items / 8u, 16u) & ~3u;   // (four per long tile; a tile of `threshold` > 128 entries takes more than 8 items per block)
     lw.max_rows = std::max(rows, 64u);
     const u32 tiles = std::max(op->tile_info.total_tiles, 1u);
-    int r = wdgs_alloc((void**)&lw.hdr, sizeof(u32) * LL_HDR_WORDS, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.sync, sizeof(LongSync) * (size_t)lw.max_blocks, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.flags, sizeof(u32) * (size_t)tiles, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.blocks, sizeof(LongBlock) * (size_t)lw.max_blocks, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.item_block, sizeof(u32) * (size_t)lw.max_items, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.nlist, sizeof(u32) * (size_t)lw.max_items, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.cnt, sizeof(u32) * 64u * (size_t)lw.max_items, false, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.off, sizeof(u32) * 64u * (size_t)lw.max_items, false, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.total, sizeof(u32) * 64u * (size_t)lw.max_blocks, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.jlast, sizeof(u32) * 64u * (size_t)lw.max_blocks, true, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.records, sizeof(float4) * 192u * (size_t)lw.max_items, false, d->stream);
-    if (r == WDGS_OK) r = wdgs_alloc((void**)&lw.rows, sizeof(u32) * 256u * (size_t)lw.max_rows, false, d->stream);
+    const size_t I = lw.max_items, B = lw.max_blocks, R = lw.max_rows;
+    // the small tables first (they are zeroed), the three large ones behind them (written before they are read)
+    const size_t sizes[12] = {256, sizeof(LongBlock) * B, sizeof(LongSync) * B, sizeof(u32) * I, sizeof(u32) * I, sizeof(u32) * 64 * B, sizeof(u32) * 64 * B,
+                              sizeof(u32) * 64 * I, sizeof(u32) * 64 * I, sizeof(float4) * 192 * I, sizeof(u32) * 256 * R, 0};
+    size_t at[12], total = 0, zeroed = 0;
+    for (int i = 0; i < 11; i++) { at[i] = total; total += align_up(sizes[i], 256); if (i == 6) zeroed = total; }
+    char* base = nullptr;
+    WDGS_TRY(wdgs_alloc((void**)&base, total, false, d->stream));
+    if (hipMemsetAsync(base, 0, zeroed, d->stream) != hipSuccess) { free_dev(base); wdgs_set_error("hipMemsetAsync failed"); return WDGS_E_HIP; }
+    lw.hdr = (u32*)(base + at[0]); lw.blocks = (LongBlock*)(base + at[1]); lw.sync = (LongSync*)(base + at[2]); lw.item_block = (u32*)(base + at[3]); lw.nlist = (u32*)(base + at[4]);
+    lw.total = (u32*)(base + at[5]); lw.jlast = (u32*)(base + at[6]); lw.cnt = (u32*)(base + at[7]); lw.off = (u32*)(base + at[8]); lw.records = (float4*)(base + at[9]);
+    lw.rows = (u32*)(base + at[10]);
     lw.nf_stamp = op->nf_stamp;
     lw.nf_frame = op->stats + FRAME_WORD;
     op->long_lists = lw;   // (what has been allocated is freed with the pass, also after a failure)
+    const int r = wdgs_alloc((void**)&op->long_lists.flags, sizeof(u32) * (size_t)tiles, true, d->stream);
     if (r != WDGS_OK) { forward_free_long_lists(op); return r; }
     op->long_flags_capacity = tiles;
     return WDGS_OK;
 }
-constexpr u32 LONG_LIST_THRESHOLD = 2048u, LONG_LIST_ITEMS = 4096u, LONG_LIST_ROWS = 32768u;   // defaults (include/webdgs.h: wdgs_tiled_forward_set_long_lists)
+constexpr u32 LONG_LIST_THRESHOLD = 2048u, LONG_LIST_ITEMS = 1024u, LONG_LIST_ROWS = 8192u;   // defaults (include/webdgs.h: wdgs_tiled_forward_set_long_lists)
 
 int wdgs_tiled_forward_create(wdgs_device* d, const wdgs_tiled_forward_config* cfg, wdgs_tiled_forward** out) {
     WDGS_REQUIRE(d && cfg && out, WDGS_E_INVALID, "wdgs_tiled_forward_create: null argument");

@@ -349,7 +349,7 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
 __device__ __attribute__((always_inline)) void long_backward_help(const RenderSettings& settings, u32 num_tiles_x, const float* __restrict__ final_T,
                                                                   const u32* __restrict__ n_contrib, const float4* __restrict__ loss_grad, int* __restrict__ acc, const LongWork lw) {
     const u32 lane = threadIdx.x & 63u;
-    const u32 n_blocks = min(lw.hdr[LL_BLOCKS], lw.max_blocks);
+    const u32 n_blocks = lw.hdr[LL_BLOCKS];   // (ll_frame_on: all of them exist)
     const u32 W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
     __builtin_amdgcn_s_setprio(3);
     // block records are dealt to the launch's waves in turn (wave w takes records w, w + waves, ...: the first waves of the grid start at once; no
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
     __shared__ float4 s_con_all[WPW][64];  // conic.x, conic.y, conic.z, opacity
     __shared__ float4 s_col_all[WPW][64];  // r, g, b, gaussian index (bits)
     __shared__ int s_sum_all[LDS_SUMS ? WPW : 1u][LDS_SUMS ? 8u * 64u : 1u];  // [slot 0..7][pixel lane]: one iteration's contributions
-    const u32 long_blocks = HELP ? lw.hdr[LL_BLOCKS] : 0u;   // (requested now, looked at when the wave's own block is done)
+    const u32 blocks_wanted = HELP ? lw.hdr[LL_BLOCKS] : 0u, items_wanted = HELP ? lw.hdr[LL_ITEMS] : 0u;   // (requested now, looked at below)
     // four independent waves per workgroup (one tile): no barrier is ever taken, the grouping only keeps the tile's waves on one
     // CU (shared L1/L2 lines for the entry list) and the workgroup count within the per-CU slot limit.
     u32 tile_id, sub;
@@ -455,12 +455,13 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         sub = j & 3u;
         mine = tile_id < num_tiles;
     }
-    if (HELP && mine && long_blocks != 0u && ((lw.flags[tile_id] >> (4u + sub)) & 1u)) mine = false;
+    const bool long_on = HELP && ll_frame_on(lw, blocks_wanted, items_wanted);
+    if (long_on && mine && ((lw.flags[tile_id] >> (4u + sub)) & 1u)) mine = false;
     const u32 slot = (WPW == 4u) ? sub : 0u;
     if (mine)
         backward_rasterize_body<WPW, LDS_SUMS, TIMELINE, PRIO>(settings, num_tiles_x, ranges, instances, splats, final_T, n_contrib, loss_grad, acc, timeline, tile_id, sub, s_geo_all[slot],
                                                                s_con_all[slot], s_col_all[slot], s_sum_all[LDS_SUMS ? slot : 0u]);
-    if (HELP && long_blocks != 0u) long_backward_help(settings, num_tiles_x, final_T, n_contrib, loss_grad, acc, lw);
+    if (long_on) long_backward_help(settings, num_tiles_x, final_T, n_contrib, loss_grad, acc, lw);
 }
 
 // clearBuffer x4 (tiled-backward-pass.ts:624-627) as a kernel that first looks at the accumulators' state word: the Trainer's forms of

@@ -7,7 +7,8 @@
 // the case by truncating the list at 8 192 entries (tiled-rasterizer.wgsl:59-60, 125); here it is bounded by giving every pixel its own list:
 //
 //   build   (sort.hip: segment_sort, which knows every tile's length)  tiles with more than `threshold` entries get four block records and
-//           4 * ceil(n / 64) item slots; flags[tile] tells the main waves to leave those blocks alone;
+//           4 * ceil(n / 64) item slots; flags[tile] tells the main waves to leave those blocks alone -- if the frame's long tiles ALL found room
+//           (ll_frame_on below: all or none);
 //   count   per (block, chunk of 64 entries), in parallel: the chunk's records as the main kernel builds them (tile-level record table), and per
 //           pixel the number of records whose extent box holds it;
 //   scan    per block: per-pixel offsets of the chunks, rows needed = the longest per-pixel list; rows come out of a pool;
@@ -99,11 +100,22 @@ WD_DEV void ll_signal(u32* p, u32 lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __hip_atomic_fetch_add(p, lane == 0u ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Next task of a queue (uniform), or 0xFFFFFFFF when it is exhausted.
-WD_DEV u32 ll_pull(u32* head, u32 n_tasks, u32 lane) {
+// The first of the next `batch` tasks of a queue (uniform), or 0xFFFFFFFF when it is exhausted.  A wave works its tasks off in order, so a task still
+// waits only for tasks that running waves hold.
+WD_DEV u32 ll_pull(u32* head, u32 n_tasks, u32 batch, u32 lane) {
     // (a look before the ticket: every wave of the launch comes here once its own block is done, and 32 000 read-modify-writes of ONE word take a
     // millisecond between them -- profiles/r08p_*; once the queue has run out the word is only read)
     if ((u32)__builtin_amdgcn_readfirstlane((int)ll_ld(head)) >= n_tasks) return 0xFFFFFFFFu;
-    const u32 t = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_fetch_add(head, lane == 0u ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (lane 0: the value before its own 1)
+    const u32 t = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_fetch_add(head, lane == 0u ? batch : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (lane 0: the value before its own addition)
     return t < n_tasks ? t : 0xFFFFFFFFu;
 }
+// Tickets cost ~28 ns each whoever draws them (one word, read-modify-written at the memory side: r08p).  A queue of a thousand tasks -- one long tile --
+// is drawn one by one, so that every task has its own wave; longer queues are drawn in batches of up to 8: there are only ~2 000 waves to deal them to.
+WD_DEV u32 ll_batch(u32 n_tasks) { return min(max(n_tasks >> 11, 1u), 8u); }
+// The per-pixel lists are a remedy for a FEW long tiles in a frame: their lists are chains that one wave each walks while the rest of the chip has run
+// out of work.  A frame FULL of long tiles (a dense cloud seen at a small viewport: the densify events' half-resolution metric views of config c3 want
+// 81 000 chunk slots) keeps every CU busy with the wave-per-block walk, which does a third of the work the count / fill / walk tasks do between them:
+// given room for all of it, such a view took 5.7 ms instead of 0.29 (profiles/r08s_event_timing.txt).  So the path is taken by ALL long tiles of a
+// frame or by none: when the frame wants more block records or chunk slots than the scratch holds -- and the host does not let the scratch grow past a
+// few thousand slots (Trainer: longLists.maxItemsCap) -- every tile stays with the main waves.
+WD_DEV bool ll_frame_on(const LongWork& lw, u32 blocks_wanted, u32 items_wanted) { return blocks_wanted != 0u && blocks_wanted <= lw.max_blocks && items_wanted <= lw.max_items; }

@@ -451,14 +451,17 @@ WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lan
 // One wave works the forward queue off: [count tasks][scan tasks][fill tasks][walk tasks] (longlist.h).  s_geo / s_con / s_col: the wave's own record set.
 __device__ __attribute__((always_inline)) void long_forward_help(const LongCtx c, const LongWork lw, float4* s_geo, float4* s_con, float4* s_col) {
     const u32 lane = threadIdx.x & 63u;
-    const u32 n_items = min(lw.hdr[LL_ITEMS], lw.max_items), n_blocks = min(lw.hdr[LL_BLOCKS], lw.max_blocks);
-    const u32 n_tasks = 2u * (n_items + n_blocks);
+    const u32 n_items = lw.hdr[LL_ITEMS], n_blocks = lw.hdr[LL_BLOCKS];   // (ll_frame_on: all of them exist)
+    const u32 n_tasks = 2u * (n_items + n_blocks), batch = ll_batch(n_tasks);
     __builtin_amdgcn_s_setprio(3);   // the long lists are the frame's longest chains: first in line for the issue slots
-    for (u32 t = ll_pull(&lw.hdr[LL_FWD_HEAD], n_tasks, lane); t != 0xFFFFFFFFu; t = ll_pull(&lw.hdr[LL_FWD_HEAD], n_tasks, lane)) {
-        if (t < n_items) long_task_item(c, lw, t, false, lane, s_geo, s_con, s_col);
-        else if (t < n_items + n_blocks) long_task_scan(lw, t - n_items, lane);
-        else if (t < 2u * n_items + n_blocks) long_task_item(c, lw, t - n_items - n_blocks, true, lane, s_geo, s_con, s_col);
-        else long_task_walk(c, lw, t - 2u * n_items - n_blocks, lane, s_geo, s_con, s_col);
+    for (u32 t0 = ll_pull(&lw.hdr[LL_FWD_HEAD], n_tasks, batch, lane); t0 != 0xFFFFFFFFu; t0 = ll_pull(&lw.hdr[LL_FWD_HEAD], n_tasks, batch, lane)) {
+        const u32 t1 = min(t0 + batch, n_tasks);
+        for (u32 t = t0; t < t1; t++) {
+            if (t < n_items) long_task_item(c, lw, t, false, lane, s_geo, s_con, s_col);
+            else if (t < n_items + n_blocks) long_task_scan(lw, t - n_items, lane);
+            else if (t < 2u * n_items + n_blocks) long_task_item(c, lw, t - n_items - n_blocks, true, lane, s_geo, s_con, s_col);
+            else long_task_walk(c, lw, t - 2u * n_items - n_blocks, lane, s_geo, s_con, s_col);
+        }
     }
     __builtin_amdgcn_s_setprio(0);
 }
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
     float4* const s_geo = s_geo_all[slot];  // wave-private record sets
     float4* const s_con = s_con_all[slot];
     float4* const s_col = s_col_all[slot];
-    const u32 long_blocks = HELP ? lw.hdr[LL_BLOCKS] : 0u;   // (requested now, looked at when the wave's own block is done)
+    const u32 blocks_wanted = HELP ? lw.hdr[LL_BLOCKS] : 0u, items_wanted = HELP ? lw.hdr[LL_ITEMS] : 0u;   // (requested now, looked at below)
     // independent waves (no barrier is ever taken): one per 8x8 block
     u32 tile_id, sub;
     bool mine = true;
@@ -494,7 +497,8 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
         sub = j & 3u;
         mine = tile_id < ti.total_tiles;
     }
-    if (HELP && mine && long_blocks != 0u && ((lw.flags[tile_id] >> sub) & 1u)) mine = false;   // (a long list: the tasks composite and write this block)
+    const bool long_on = HELP && ll_frame_on(lw, blocks_wanted, items_wanted);
+    if (long_on && mine && ((lw.flags[tile_id] >> sub) & 1u)) mine = false;   // (a long list: the tasks composite and write this block)
     if (mine) {
         const bool exact = nf_stamp == nullptr || nf_stamp[tile_id] == *nf_frame;   // (uniform per workgroup)
         if (exact)
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
             rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, false>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
                                                                 out_ncontrib, issue_priority, timeline, tile_id, sub, s_geo, s_con, s_col);
     }
-    if (HELP && long_blocks != 0u)
+    if (long_on)
         long_forward_help(LongCtx{settings, ti, splats, ranges, sorted_keys, sorted_vals, count_ptr, num_splats, out_rgba8, out_alpha, out_ncontrib, nf_stamp, nf_frame}, lw, s_geo, s_con, s_col);
 }
 

@@ -270,6 +270,11 @@ class Trainer:
         self.stepItersPerSec = 0.0
         self.stepMs = 0.0
         self.lastDensifyPruneIteration = None
+        # the lanes this trainer will use come into being now (the library creates a lane's stream and event at its first use, ~5 ms each:
+        # otherwise the first densify event, which is the first to touch the metric lanes, pays for them -- profiles/r08t_event_timing.txt)
+        for k in range(1, max(self._lanes, self.metric_lanes)):
+            self.device.laneOrder(k, 0)
+            self.device.laneOrder(0, k)
 
     def stop(self) -> None:
         self.isTraining = False
@@ -316,25 +321,33 @@ class Trainer:
     def _new_forward_pass(self, cameraBuffer, w: int, h: int) -> ops.TiledForwardPass:
         fw = ops.TiledForwardPass(self.device, self.pointCloud, cameraBuffer, dict(viewportWidth=w, viewportHeight=h, renderMode="gaussian", maxTileEntries=self._tile_entries()))
         fw.setDcSource(self._dc_words)
-        if self.longLists is not None:   # (None: the library's defaults -- threshold 2048, room for 4096 chunk slots and 32768 rows)
+        if self.longLists is not None:   # (None: the library's defaults -- threshold 2048, room for 1024 chunk slots and 8192 rows)
             fw.setLongLists(int(self.longLists.get("threshold", 2048)), int(self.longLists.get("maxItems", 0)), int(self.longLists.get("maxRows", 0)))
         return fw
 
     def _grow_long_lists(self) -> None:
-        """Long tile lists (csrc/longlist.h) work in scratch of a fixed size; a tile that finds no room is composited the ordinary way -- correct, but as
-        slow as its list is long.  The work's header says what the last frame wanted: looked at where the host waits anyway (a densify event), and every
-        pass is given room for 1.5 x that (command buffers recorded against the old scratch are dropped)."""
+        """Long tile lists (csrc/longlist.h) work in scratch of a fixed size; a frame whose long tiles find no room is composited the ordinary way --
+        correct, but as slow as its longest list.  The work's header says what the last frame wanted: looked at where the host waits anyway (a densify
+        event), and every pass is given room for 1.5 x that -- up to ``longLists.maxItemsCap`` / ``maxRowsCap`` (8 192 chunk slots: 33 000 entries of
+        long tiles; 65 536 rows).  A frame that wants more than the caps is FULL of long tiles (a dense cloud at a small viewport): the path is not for
+        it (longlist.h: ll_frame_on) and the scratch is left alone.  (Command buffers recorded against the old scratch are dropped.)"""
         import warnings
-        need_items = need_rows = 0
+        cap_items, cap_rows = int((self.longLists or {}).get("maxItemsCap", 8192)), int((self.longLists or {}).get("maxRowsCap", 65536))
+        have_items = have_rows = need_items = need_rows = 0
         for fw in self._forward_passes():
             st = fw.longListStats()
-            if st["threshold"] and st["stalled"]:
+            if not st["threshold"]:
+                continue
+            if st["stalled"]:
                 warnings.warn(f"a long-list task gave up waiting (code {st['stalled']:#x}): the frame's long tiles are not to be trusted", RuntimeWarning, stacklevel=3)
-            if st["threshold"] and (st["itemsWanted"] > st["maxItems"] or st["rowsWanted"] > st["maxRows"]):
-                need_items, need_rows = max(need_items, st["itemsWanted"], st["maxItems"]), max(need_rows, st["rowsWanted"], st["maxRows"])
-        if not need_items:
+            have_items, have_rows = max(have_items, st["maxItems"]), max(have_rows, st["maxRows"])
+            if st["itemsWanted"] <= cap_items:
+                need_items, need_rows = max(need_items, st["itemsWanted"]), max(need_rows, st["rowsWanted"])
+        items = max(have_items, min(int(need_items * 1.5), cap_items)) if need_items > have_items else have_items
+        rows = max(have_rows, min(int(need_rows * 1.5), cap_rows)) if need_rows > have_rows else have_rows
+        if (items, rows) == (have_items, have_rows):
             return
-        self.longLists = dict(self.longLists or {}, maxItems=int(need_items * 1.5), maxRows=int(need_rows * 1.5))
+        self.longLists = dict(self.longLists or {}, maxItems=items, maxRows=rows)
         warnings.warn(f"long-list scratch enlarged to {self.longLists['maxItems']} chunk slots and {self.longLists['maxRows']} rows", RuntimeWarning, stacklevel=3)
         self._invalidate_command_buffers()
         for fw in self._forward_passes():
