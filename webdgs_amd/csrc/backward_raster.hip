@@ -96,8 +96,9 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
                                                                  const u32* __restrict__ instances, const u32* __restrict__ splats,
                                                                  const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                                                                  const float4* __restrict__ loss_grad, int* __restrict__ acc,
-                                                                 unsigned long long* __restrict__ timeline, u32 tile_id, u32 sub, float4* s_geo, float4* s_con, float4* s_col,
-                                                                 int* s_sum) {
+                                                                 unsigned long long* __restrict__ timeline, u32 tile_id, u32 sub, u32 range_start /* ranges[tile_id] */,
+                                                                 u32 range_end /* ranges[tile_id + 1] */, u32 n_val /* n_contrib of the lane's pixel, 0 outside the image */,
+                                                                 float4* s_geo, float4* s_con, float4* s_col, int* s_sum) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
     auto leave_timeline = [&]() {
@@ -114,9 +115,8 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
-    const u32 W = wd_to_u32(vx), H = wd_to_u32(vy);
-    const bool in_bounds = pixel_x < W && pixel_y < H;
-    const size_t p = (size_t)pixel_y * W + pixel_x;
+    const u32 W = wd_to_u32(vx);
+    const size_t p = (size_t)pixel_y * W + pixel_x;   // (inside the image wherever n_val != 0)
     const float cap = (settings.max_splat_radius_px > 0.0f) ? settings.max_splat_radius_px : 1e9f;
     const float blk_x0 = (float)bx + 0.5f, blk_x1 = (float)bx + 7.5f, blk_y0 = (float)by + 0.5f, blk_y1 = (float)by + 7.5f;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -130,10 +130,7 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
     const bool atomic_lane = LDS_SUMS ? ((lane & 7u) == 0u || (lane & 15u) == 1u) : ((lane & 15u) < 3u);
     const u32 atomic_slot = LDS_SUMS ? (sum_lane ? sum_q : 8u + (lane >> 4)) : ((quad_lane == 2u) ? 8u + (lane >> 4) : 2u * (lane >> 4) + quad_lane);
 
-    const u32 range_start = ranges[tile_id];
-    const u32 range_end = ranges[tile_id + 1u];
     const u32 tile_entries = (range_end > range_start) ? range_end - range_start : 0u;
-    const u32 n_val = in_bounds ? n_contrib[p] : 0u;
     float T = 0.0f;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (min(n_val, tile_entries) > 0u) { T = final_T[p]; g = loss_grad[p]; }
@@ -348,7 +345,9 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
 // per-pixel list has elements in front of its last contributor -- not as the tile list has entries.
 __device__ __attribute__((always_inline)) void long_backward_help(const RenderSettings& settings, u32 num_tiles_x, const float* __restrict__ final_T,
                                                                   const u32* __restrict__ n_contrib, const float4* __restrict__ loss_grad, int* __restrict__ acc, const LongWork lw) {
-    const u32 lane = threadIdx.x & 63u;
+    // (the lane number derived again, not taken from the walk above: a vector register kept alive across that walk for this function's sake costs it --
+    // raster.hip's kernel says how much)
+    const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const u32 n_blocks = lw.hdr[LL_BLOCKS];   // (ll_frame_on: all of them exist)
     const u32 W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
     __builtin_amdgcn_s_setprio(3);
@@ -455,11 +454,24 @@ __global__ __launch_bounds__(64 * WPW, 8) void backward_rasterize_kernel(RenderS
         sub = j & 3u;
         mine = tile_id < num_tiles;
     }
+    // (the walk's first two words, requested together with the words that decide whose walk it is: one round trip, not two in a row)
+    const u32 range_start = mine ? ranges[tile_id] : 0u, range_end = mine ? ranges[tile_id + 1u] : 0u;
+    u32 n_val = 0u;
+    if (mine) {   // (the pixel of backward_rasterize_body)
+        const u32 lane = threadIdx.x & 63u, W = wd_to_u32(settings.viewport_x), H = wd_to_u32(settings.viewport_y);
+        const u32 pixel_x = (tile_id % num_tiles_x) * 16u + (sub & 1u) * 8u + (lane & 7u), pixel_y = (tile_id / num_tiles_x) * 16u + (sub >> 1) * 8u + (lane >> 3);
+        if (pixel_x < W && pixel_y < H) n_val = n_contrib[(size_t)pixel_y * W + pixel_x];
+    }
     const bool long_on = HELP && ll_frame_on(lw, blocks_wanted, items_wanted);
     if (long_on && mine && ((lw.flags[tile_id] >> (4u + sub)) & 1u)) mine = false;
     const u32 slot = (WPW == 4u) ? sub : 0u;
+    // HELP: the walk's pointer arguments are made to sit in scalar registers HERE.  With the help's 38 more argument words in the kernel the compiler fetches
+    // arguments where they are first used, some inside the walk behind branches -- and a scalar load that MAY be in flight (they return out of order)
+    // turns every partial wait of the walk's inner loop (three record reads, "wait for the first") into a full one: +1.2 % on the kernel, same box
+    // (profiles/r08z_kernels_same_box.txt; the loop's code is otherwise identical).
+    if (HELP) asm volatile("" ::"s"(ranges), "s"(instances), "s"(splats), "s"(final_T), "s"(n_contrib), "s"(loss_grad), "s"(acc));
     if (mine)
-        backward_rasterize_body<WPW, LDS_SUMS, TIMELINE, PRIO>(settings, num_tiles_x, ranges, instances, splats, final_T, n_contrib, loss_grad, acc, timeline, tile_id, sub, s_geo_all[slot],
+        backward_rasterize_body<WPW, LDS_SUMS, TIMELINE, PRIO>(settings, num_tiles_x, ranges, instances, splats, final_T, n_contrib, loss_grad, acc, timeline, tile_id, sub, range_start, range_end, n_val, s_geo_all[slot],
                                                                s_con_all[slot], s_col_all[slot], s_sum_all[LDS_SUMS ? slot : 0u]);
     if (long_on) long_backward_help(settings, num_tiles_x, final_T, n_contrib, loss_grad, acc, lw);
 }

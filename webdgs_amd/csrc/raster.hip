@@ -42,11 +42,11 @@ __device__ __attribute__((always_inline)) void rasterize_body(const RenderSettin
                            const u32* __restrict__ ranges, const u32* __restrict__ sorted_keys,
                            const u32* __restrict__ sorted_vals, const u32* __restrict__ count_ptr, u32 max_entries,
                            u32* __restrict__ out_rgba8, float* __restrict__ out_alpha, u32* __restrict__ out_ncontrib, u32 issue_priority,
-                           unsigned long long* __restrict__ timeline, u32 tile_id, u32 sub, float4* s_geo, float4* s_con, float4* s_col) {
+                           unsigned long long* __restrict__ timeline, u32 tile_id, u32 sub, u32 lane, u32 total /* *count_ptr */, u32 start /* ranges[tile_id] */,
+                           float4* s_geo, float4* s_con, float4* s_col) {
     const unsigned long long t_start = TIMELINE ? wall_clock64() : 0ull;
     u32 iterations = 0u;
     const u32 tile_x = tile_id % ti.num_tiles_x, tile_y = tile_id / ti.num_tiles_x;
-    const u32 lane = threadIdx.x & 63u;
     const u32 bx = tile_x * 16u + (sub & 1u) * 8u, by = tile_y * 16u + (sub >> 1) * 8u;  // block origin
     const u32 pixel_x = bx + (lane & 7u), pixel_y = by + (lane >> 3);
     const float vx = settings.viewport_x, vy = settings.viewport_y;
@@ -60,8 +60,6 @@ __device__ __attribute__((always_inline)) void rasterize_body(const RenderSettin
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, A = 0.0f;
     u32 last_contributor = 0u;
 
-    const u32 total = *count_ptr;
-    const u32 start = ranges[tile_id];
     if (__any(in_bounds) && start < total) {  // 0xFFFFFFFF (empty tile) fails the second test too
         const u32 want_key = tile_id + 1u;
         auto fetch_kv = [&](u32 c, u32& key, u32& val) {
@@ -390,10 +388,10 @@ WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lan
     if (row_base == LL_NO_ROWS) {   // no rows: the wave-per-block walk, here (the block's main wave has left it alone)
         if (c.nf_stamp == nullptr || c.nf_stamp[blk.tile] == *c.nf_frame)
             rasterize_body<true, 4u, false, true>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
-                                                  c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, s_geo, s_con, s_col);
+                                                  c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, lane, *c.count_ptr, c.ranges[blk.tile], s_geo, s_con, s_col);
         else
             rasterize_body<true, 4u, false, false>(c.settings, c.ti, c.splats, c.num_splats, c.ranges, c.sorted_keys, c.sorted_vals, c.count_ptr, 0u, c.out_rgba8, c.out_alpha,
-                                                   c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, s_geo, s_con, s_col);
+                                                   c.out_ncontrib, 0u, nullptr, blk.tile, blk.sub, lane, *c.count_ptr, c.ranges[blk.tile], s_geo, s_con, s_col);
         return;
     }
     const u32 W = wd_to_u32(c.settings.viewport_x), H = wd_to_u32(c.settings.viewport_y);
@@ -449,8 +447,7 @@ WD_DEV void long_task_walk(const LongCtx& c, const LongWork& lw, u32 lb, u32 lan
 }
 
 // One wave works the forward queue off: [count tasks][scan tasks][fill tasks][walk tasks] (longlist.h).  s_geo / s_con / s_col: the wave's own record set.
-__device__ __attribute__((always_inline)) void long_forward_help(const LongCtx c, const LongWork lw, float4* s_geo, float4* s_con, float4* s_col) {
-    const u32 lane = threadIdx.x & 63u;
+__device__ __attribute__((always_inline)) void long_forward_help(const LongCtx c, const LongWork lw, u32 lane, float4* s_geo, float4* s_con, float4* s_col) {
     const u32 n_items = lw.hdr[LL_ITEMS], n_blocks = lw.hdr[LL_BLOCKS];   // (ll_frame_on: all of them exist)
     const u32 n_tasks = 2u * (n_items + n_blocks), batch = ll_batch(n_tasks);
     __builtin_amdgcn_s_setprio(3);   // the long lists are the frame's longest chains: first in line for the issue slots
@@ -485,6 +482,9 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
     float4* const s_con = s_con_all[slot];
     float4* const s_col = s_col_all[slot];
     const u32 blocks_wanted = HELP ? lw.hdr[LL_BLOCKS] : 0u, items_wanted = HELP ? lw.hdr[LL_ITEMS] : 0u;   // (requested now, looked at below)
+    // (HELP: the wave's number in a scalar register for the help below, which derives everything it needs from it -- a vector register kept alive across
+    // the walk for the help's sake costs the walk a spill per chunk: +3.5 us at c3, profiles/r08w_kernels_same_box.txt)
+    const u32 wave_s = (HELP && WPW == 4u) ? (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
     // independent waves (no barrier is ever taken): one per 8x8 block
     u32 tile_id, sub;
     bool mine = true;
@@ -497,19 +497,23 @@ __global__ __launch_bounds__(64 * WPW, 8) void rasterize_kernel(RenderSettings s
         sub = j & 3u;
         mine = tile_id < ti.total_tiles;
     }
+    // (the walk's first two words, requested together with the words that decide which walk it is: one round trip, not two in a row)
+    const u32 total = *count_ptr;
+    const u32 start = mine ? ranges[tile_id] : 0xFFFFFFFFu;
+    const bool exact = nf_stamp == nullptr || (mine && nf_stamp[tile_id] == *nf_frame);   // (uniform per workgroup)
     const bool long_on = HELP && ll_frame_on(lw, blocks_wanted, items_wanted);
     if (long_on && mine && ((lw.flags[tile_id] >> sub) & 1u)) mine = false;   // (a long list: the tasks composite and write this block)
     if (mine) {
-        const bool exact = nf_stamp == nullptr || nf_stamp[tile_id] == *nf_frame;   // (uniform per workgroup)
         if (exact)
             rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, true>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
-                                                               out_ncontrib, issue_priority, timeline, tile_id, sub, s_geo, s_con, s_col);
+                                                               out_ncontrib, issue_priority, timeline, tile_id, sub, threadIdx.x & 63u, total, start, s_geo, s_con, s_col);
         else
             rasterize_body<GAUSSIAN_MODE, WPW, TIMELINE, false>(settings, ti, splats, num_splats, ranges, sorted_keys, sorted_vals, count_ptr, max_entries, out_rgba8, out_alpha,
-                                                                out_ncontrib, issue_priority, timeline, tile_id, sub, s_geo, s_con, s_col);
+                                                                out_ncontrib, issue_priority, timeline, tile_id, sub, threadIdx.x & 63u, total, start, s_geo, s_con, s_col);
     }
     if (long_on)
-        long_forward_help(LongCtx{settings, ti, splats, ranges, sorted_keys, sorted_vals, count_ptr, num_splats, out_rgba8, out_alpha, out_ncontrib, nf_stamp, nf_frame}, lw, s_geo, s_con, s_col);
+        long_forward_help(LongCtx{settings, ti, splats, ranges, sorted_keys, sorted_vals, count_ptr, num_splats, out_rgba8, out_alpha, out_ncontrib, nf_stamp, nf_frame}, lw,
+                          __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), s_geo_all[wave_s], s_con_all[wave_s], s_col_all[wave_s]);
 }
 
 }  // namespace

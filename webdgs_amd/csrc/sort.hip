@@ -49,7 +49,7 @@ struct DigitOf {
 template <u32 ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __restrict__ keys, const u32* __restrict__ count_ptr, DigitOf digit_of,
                                                                  u32 num_parts, u32* __restrict__ counts /*[RADIX][num_parts]*/, u32* __restrict__ ranges_init,
-                                                                 u32 total_tiles) {
+                                                                 u32 total_tiles, u32* __restrict__ marks_init) {
     WD_STREAM_PRIO();
     constexpr u32 TILE = SORT_THREADS * ITEMS;  // keys per partition
     __shared__ u32 lh[SORT_THREADS / 64][RADIX];
@@ -63,6 +63,13 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u32* __re
         const u32 active = max((count + TILE - 1u) / TILE, 1u);
         if (part < active)
             for (u32 t = part * SORT_THREADS + threadIdx.x; t <= total_tiles; t += active * SORT_THREADS) ranges_init[t] = (t == total_tiles) ? count : 0xFFFFFFFFu;
+    }
+    // marks_init (nullable): the per-tile marks of the long tile lists (longlist.h: flags) start the frame cleared -- here, among stores that are not on
+    // anybody's way, rather than one store per tile in the middle of segment_sort's workgroups; that kernel then marks its long tiles only
+    if (marks_init) {
+        const u32 active = max((count + TILE - 1u) / TILE, 1u);
+        if (part < active)
+            for (u32 t = part * SORT_THREADS + threadIdx.x; t < total_tiles; t += active * SORT_THREADS) marks_init[t] = 0u;
     }
     if (base >= count) return;
     const u32 wave = threadIdx.x >> 6;
@@ -480,10 +487,7 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 __device__ void long_list_build(const LongWork& lw, u32 t, u32 n) {
     __shared__ u32 s_first, s_lb;
     const bool want = lw.threshold != 0u && n > lw.threshold && !(lw.nf_stamp && lw.nf_stamp[t] == *lw.nf_frame);
-    if (!want) {   // (uniform per workgroup)
-        if (threadIdx.x == 0u) lw.flags[t] = 0u;
-        return;
-    }
+    if (!want) return;   // (uniform per workgroup; the marks were cleared by the frame's first sort_hist)
     const u32 chunks = (n + 63u) >> 6, need = 4u * chunks;
     if (threadIdx.x == 0u) {
         s_first = atomicAdd(&lw.hdr[LL_ITEMS], need);
@@ -500,7 +504,7 @@ __device__ void long_list_build(const LongWork& lw, u32 t, u32 n) {
         lw.blocks[b] = LongBlock{t, threadIdx.x, first + threadIdx.x * chunks, ok ? chunks : 0u};
         lw.sync[b] = LongSync{0u, LL_NO_ROWS, 0u, 0u, 0u, 0u, 0u, 0u};
     }
-    if (threadIdx.x == 0u) lw.flags[t] = ok ? 0xFu : 0u;
+    if (threadIdx.x == 0u && ok) lw.flags[t] = 0xFu;
 }
 
 __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
@@ -514,10 +518,7 @@ __global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restri
     const u32 t = blockIdx.x;
     const u32 start = ranges[t];
     u32 end = ranges[t + 1u];          // (requested together with `start`: one round trip)
-    if (start == 0xFFFFFFFFu) {  // empty tile (uniform per workgroup)
-        if (lw.flags && threadIdx.x == 0u) lw.flags[t] = 0u;
-        return;
-    }
+    if (start == 0xFFFFFFFFu) return;  // empty tile (uniform per workgroup)
     // end of the segment = start of the next non-empty tile (ranges[T] = E ends the walk): the successor itself unless it is empty, in
     // which case every thread walks on (uniform addresses: the same few loads for the whole workgroup, no barrier)
     for (u32 nx = t + 1u; end == 0xFFFFFFFFu && nx < total_tiles;) { nx++; end = ranges[nx]; }
@@ -656,12 +657,13 @@ int sorter_sort_segmented(wdgs_sorter* s, u32 segment_bits, u32 num_segments, u3
         const u32 width = left / (passes - p);
         left -= width;
         const u32 dmask = (1u << width) - 1u;
+        u32* const marks = (p == 0u && lw) ? lw->flags : nullptr;   // (the long-list marks are cleared by the frame's first histogram kernel)
         if (s->items == 4u) {
             WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts,
-                        s->counts, (u32*)nullptr, 0u);
+                        s->counts, (u32*)nullptr, num_segments, marks);
         } else {
             WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, dmask, 0u}), s->num_parts,
-                        s->counts, (u32*)nullptr, 0u);
+                        s->counts, (u32*)nullptr, num_segments, marks);
         }
         if (s->items == 4u) {
             WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<4u>, dim3(dmask + 1u), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
@@ -699,9 +701,9 @@ int sorter_sort_rows(wdgs_sorter* s, u32 num_tiles_x, u32 num_tiles_y, u32* rang
     const u32 tiles = num_tiles_x * num_tiles_y;
     const DigitOf rows{0u, num_tiles_y - 1u, 0xFFFFFFFFu / num_tiles_x + 1u};  // (num_tiles_x >= 2)
     if (s->items == 4u) {
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles);
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles, lw ? lw->flags : (u32*)nullptr);
     } else {
-        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles);
+        WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[0], s->count_ptr, rows, s->num_parts, s->counts, ranges, tiles, lw ? lw->flags : (u32*)nullptr);
     }
     if (s->items == 4u) {
         WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<4u>, dim3(num_tiles_y), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
@@ -733,10 +735,10 @@ int wdgs_sorter_sort(wdgs_sorter* s, uint32_t key_bits) {
         const u32 shift = p * 8u;
         if (s->items == 4u) {
             WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<4u>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts,
-                        s->counts, (u32*)nullptr, 0u);
+                        s->counts, (u32*)nullptr, 0u, (u32*)nullptr);
         } else {
             WDGS_LAUNCH(dev, "sort_hist", sort_hist_kernel<SORT_ITEMS_MAX>, dim3(s->num_parts), dim3(SORT_THREADS), 0, s->keys[src], s->count_ptr, (DigitOf{shift, RADIX - 1u, 0u}), s->num_parts,
-                        s->counts, (u32*)nullptr, 0u);
+                        s->counts, (u32*)nullptr, 0u, (u32*)nullptr);
         }
         if (s->items == 4u) {
             WDGS_LAUNCH(dev, "sort_scan_rows", sort_scan_rows_kernel<4u>, dim3(RADIX), dim3(256), 0, s->counts, s->count_ptr, s->num_parts, s->totals);
