@@ -453,12 +453,19 @@ class Trainer {
     if (!(error && error.code === 'WDGS_E_CAPACITY')) return false;
     const mine = this.ownOverflow(error);
     if (mine === null || mine.length) return false;
+    this.device.capacityReports.post(error);   // (for the passes' owner: it looks there at its own next wait)
     if (!this.foreignOverflowWarned) console.warn(`a forward pass that is not this trainer's overflowed its tile-entry lists (${error.message}); its owner has to enlarge them`);
     this.foreignOverflowWarned = true;
     return true;
   }
-  wait(ticket) { try { this.device.queue.wait(ticket); } catch (e) { if (!this.notOurs(e)) throw e; } }
-  synchronize() { try { this.device.synchronize(); } catch (e) { if (!this.notOurs(e)) throw e; } }
+  wait(ticket) { try { this.device.queue.wait(ticket); } catch (e) { if (!this.notOurs(e)) throw e; } this.reportsLeftForUs(); }
+  synchronize() { try { this.device.synchronize(); } catch (e) { if (!this.notOurs(e)) throw e; } this.reportsLeftForUs(); }
+  /** A report about THIS trainer's passes that another owner's wait consumed (a Viewer reading its frame): raised here, as if this wait had got it. */
+  reportsLeftForUs() {
+    if (!this.device.capacityReports.pending.length) return;
+    const e = this.device.capacityReports.take(this.forwardPasses().map((fw) => fw.handle));
+    if (e) throw e;
+  }
 
   /** `await onSubmittedWorkDone()` (trainer.ts:639-645) + the deferred capacity check.  Depth 1: this step's own completion, through the
    *  Promise, as the reference awaits it.  Depth d > 1: a ticket for this step is kept and the step d - 1 submissions ago is awaited. */

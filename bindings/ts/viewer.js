@@ -78,8 +78,16 @@ class Viewer {
     // If the frame's tile-entry list outran what the library sized for the cloud (the reference would show the truncated picture; the library reports it),
     // the viewer's passes are rebuilt around larger lists and the frame is rendered again -- other owners' reports on the same device are left to them.
     for (let attempt = 0; attempt < 4 && this.forwardPass; attempt++) {   // this viewer's own pass: its word is consumed by its own check
-      try { this.forwardPass.check(); break; } catch (e) {
-        const m = e && e.code === 'WDGS_E_CAPACITY' && /(\d+) entries needed, max_tile_entries = (\d+)/.exec(String(e.message));
+      try {
+        this.forwardPass.check();
+        const left = this.device.capacityReports.take([this.forwardPass.handle]);   // (consumed by another owner's wait, left for us)
+        if (left) throw left;
+        break;
+      } catch (e) {
+        // (a report names up to four passes: this viewer's line)
+        const own = BigInt(this.forwardPass.handle), re = /(\d+) entries needed, max_tile_entries = (\d+) \(forward pass (0x[0-9a-fA-F]+)\)/g, text = String(e && e.message);
+        let m = null;
+        if (e && e.code === 'WDGS_E_CAPACITY') for (let x = re.exec(text); x && !m; x = re.exec(text)) if (BigInt(x[3]) === own) m = x;
         if (!m) throw e;
         this.tileEntries = Math.min(Math.max(2 * Number(m[2]), Math.floor(Number(m[1]) * 1.5)), 0xFFFFF000);
         this.buildPasses();

@@ -17,8 +17,17 @@ export class HipEncoder {
   finish(): HipCommandBuffer;
   abort(): void;
 }
+/** Capacity reports that reached the wrong owner (a Trainer and a Viewer sharing a device): left here for the owner of the passes they name. */
+export class CapacityReports {
+  constructor(keep?: number);
+  pending: Error[];
+  static passesNamed(error: Error): bigint[];
+  post(error: Error): void;
+  take(ownHandles: Array<bigint | number>): Error | null;
+}
 export class HipDevice {
   constructor(ordinal?: number);
+  readonly capacityReports: CapacityReports;
   readonly queue: {
     submit(cmds: HipCommandBuffer[]): void;
     onSubmittedWorkDone(): Promise<void>;

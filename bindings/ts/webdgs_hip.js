@@ -60,9 +60,31 @@ class HipEncoder {
   abort() { if (this.open) { this.open = false; addon.encoderAbort(this.device.handle); } }
 }
 
+/** Capacity reports that reached the wrong owner.  The library reports a truncated tile-entry list at the next host wait on the DEVICE, to whoever waits
+ *  (csrc/api.hip: deferred_checks consumes every pass's word and names the passes); a Trainer and a Viewer that share a device each handle the reports
+ *  that name their own passes -- and leave the others here, where the passes' owner looks at its own next wait. */
+class CapacityReports {
+  constructor(keep) { this.pending = []; this.keep = keep || 16; }
+  static passesNamed(error) {
+    const out = [], re = /\(forward pass (0x[0-9a-fA-F]+)\)/g, text = String(error && error.message);
+    for (let m = re.exec(text); m; m = re.exec(text)) out.push(BigInt(m[1]));
+    return out;
+  }
+  post(error) { this.pending.push(error); if (this.pending.length > this.keep) this.pending.splice(0, this.pending.length - this.keep); }
+  /** The oldest pending report that names one of `ownHandles` (removed), or null. */
+  take(ownHandles) {
+    const own = ownHandles.map((h) => BigInt(h));
+    for (let i = 0; i < this.pending.length; i++) {
+      if (CapacityReports.passesNamed(this.pending[i]).some((h) => own.some((o) => o === h))) return this.pending.splice(i, 1)[0];
+    }
+    return null;
+  }
+}
+
 class HipDevice {                        // GPUDevice + GPUQueue
   constructor(ordinal) {
     this.handle = addon.deviceCreate(ordinal || 0);
+    this.capacityReports = new CapacityReports();
     const self = this;
     this.queue = {
       submit(cmds) { for (const c of cmds) if (c.handle !== null) addon.queueSubmit(self.handle, c.handle); },
@@ -447,6 +469,6 @@ class Communicator {
 const MAX_LANES = 4;         // WDGS_MAX_LANES
 const MAX_BATCH_VIEWS = 16;  // WDGS_MAX_BATCH_VIEWS
 
-module.exports = { addon, MAX_LANES, MAX_BATCH_VIEWS, projectViews, geometryViews, imageSSE, imagePSNR, Communicator, HipBuffer, HipCommandBuffer, HipEncoder, HipDevice, allocatePointCloudLike, PrefixScanner, get_prefix_scanner, DynamicSortStuff,
+module.exports = { addon, MAX_LANES, MAX_BATCH_VIEWS, projectViews, geometryViews, imageSSE, imagePSNR, Communicator, HipBuffer, HipCommandBuffer, HipEncoder, HipDevice, CapacityReports, allocatePointCloudLike, PrefixScanner, get_prefix_scanner, DynamicSortStuff,
   get_dynamic_sorter, TiledForwardPass, TiledRasterizer, TiledBackwardPass, DEFAULT_ADAM_HYPERPARAMETERS, allocateOptimizerStateBuffers, Optimizer,
   DensifyPrunePass, downsampleRGBA8 };

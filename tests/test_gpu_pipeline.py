@@ -161,6 +161,11 @@ def test_another_owners_overflow_is_not_the_trainers_to_answer(hip_device):
         assert (1 << 20) < cap <= (4 << 20), cap
         assert int(v.getForwardPass().getResources()["maxTileEntries"]) <= (1 << 20) + 4096, "the viewer's lists are its owner's business"
         assert t.getIteration() >= 9
+        # ... and the owner gets to answer: the reports the trainer's waits consumed were left for it (ops.CapacityReports), its next read finds one
+        assert dev.capacityReports.pending, "reports about the viewer's pass wait for the viewer"
+        v.readFrame()
+        assert int(v.getForwardPass().getResources()["maxTileEntries"]) > (1 << 20) + 4096, "the viewer enlarged its lists at its own read"
+        dev.capacityReports.pending.clear()
     finally:
         t.pointCloud = None  # (the cloud is shared: destroyed below, once)
         t.destroy()

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import re
 from typing import Optional
 
 import numpy as np
@@ -164,6 +165,35 @@ class _Queue:
         buf.write(data, offset)
 
 
+class CapacityReports:
+    """Capacity reports that reached the wrong owner.  The library reports a truncated tile-entry list at the next host wait on the DEVICE, to whoever
+    waits (csrc/api.hip: deferred_checks consumes every pass's word and names the passes); a Trainer and a Viewer that share a device each handle the
+    reports that name their own passes -- and leave the others HERE, where the passes' owner looks at its own next wait (dropped instead, a
+    report consumed by the wrong owner was lost to the right one)."""
+
+    _NAMED = re.compile(r"\(forward pass (0x[0-9a-fA-F]+)\)")
+
+    def __init__(self, keep: int = 16):
+        self.pending: list = []
+        self.keep = keep
+
+    @classmethod
+    def passes_named(cls, error) -> set:
+        return {int(h, 16) for h in cls._NAMED.findall(str(error))}
+
+    def post(self, error) -> None:
+        self.pending.append(error)
+        del self.pending[:-self.keep]
+
+    def take(self, own_handles) -> Optional[Exception]:
+        """The oldest pending report that names one of ``own_handles`` (removed), or None."""
+        own = {int(h) for h in own_handles}
+        for i, e in enumerate(self.pending):
+            if self.passes_named(e) & own:
+                return self.pending.pop(i)
+        return None
+
+
 class HipDevice:
     """``GPUDevice`` + ``GPUQueue`` on one MI355X: a HIP ordinal and torch's current stream on it."""
 
@@ -185,6 +215,7 @@ class HipDevice:
         check(self.lib.wdgs_device_create(ordinal, C.c_void_p(stream), C.byref(h)))
         self.handle = h
         self.queue = _Queue(self)
+        self.capacityReports = CapacityReports()
         self._keepalive: list = []
 
     def createCommandEncoder(self, label: str = "", record: bool = False) -> HipEncoder:

@@ -777,6 +777,7 @@ class Trainer:
         device: the report is device-wide, whoever waits first gets it, and it is the pass's owner who has to enlarge its lists."""
         if self._own_overflow(error) != []:
             return False
+        self.device.capacityReports.post(error)   # (for the passes' owner: it looks there at its own next wait)
         if not self._foreign_overflow_warned:
             import warnings
             warnings.warn(f"a forward pass that is not this trainer's overflowed its tile-entry lists ({error}); its owner has to enlarge them", RuntimeWarning, stacklevel=4)
@@ -789,6 +790,7 @@ class Trainer:
         except ops.CapacityError as e:
             if not self._not_ours(e):
                 raise
+        self._reports_left_for_us()
 
     def _synchronize(self) -> None:
         try:
@@ -796,6 +798,14 @@ class Trainer:
         except ops.CapacityError as e:
             if not self._not_ours(e):
                 raise
+        self._reports_left_for_us()
+
+    def _reports_left_for_us(self) -> None:
+        """A report about THIS trainer's passes that another owner's wait consumed (a Viewer reading its frame): raised here, as if this wait had got it."""
+        if self.device.capacityReports.pending:
+            e = self.device.capacityReports.take(int(fw.handle.value or 0) for fw in self._forward_passes())
+            if e is not None:
+                raise e
 
     def _finish_step(self, n_views: int) -> None:
         """``await onSubmittedWorkDone()`` (trainer.ts:639-645) + the deferred capacity check, for the step ``pipeline_depth - 1``

@@ -154,28 +154,26 @@ class Viewer:
     def readFrame(self) -> np.ndarray:
         """The presented image as ``[H, W, 4]`` uint8 (synchronises).  If the frame's tile-entry list outran what the library sized for the cloud
         (the reference would show the truncated picture; the library reports it), the viewer's passes are rebuilt around larger lists and the
-        frame is rendered again -- other owners' reports on the same device are left to them."""
+        frame is rendered again.  (A report about this viewer's pass may have been consumed by another owner's wait -- a Trainer on the same device:
+        it was left in ``device.capacityReports``, and is answered here.)"""
         import re
         for _ in range(4):  # this viewer's own pass: its word is consumed by its own check
             if self.forwardPass is None:
                 break
             try:
                 self.forwardPass.check()
+                left = self.device.capacityReports.take([int(self.forwardPass.handle.value or 0)])   # (consumed by another owner's wait, left for us)
+                if left is not None:
+                    raise left
                 break
             except CapacityError as e:
-                m = re.search(r"(\d+) entries needed, max_tile_entries = (\d+)", str(e))
-                if not m:
+                own = int(self.forwardPass.handle.value or 0)   # (a report names up to four passes: this viewer's line)
+                named = [(int(n), int(c)) for n, c, h in re.findall(r"(\d+) entries needed, max_tile_entries = (\d+) \(forward pass (0x[0-9a-fA-F]+)\)", str(e)) if int(h, 16) == own]
+                if not named:
                     raise
-                self._tile_entries = min(max(2 * int(m.group(2)), int(int(m.group(1)) * 1.5)), 0xFFFFF000)
+                self._tile_entries = min(max(2 * named[0][1], int(named[0][0] * 1.5)), 0xFFFFF000)
                 self._build_passes()
                 self.render(None)
-        for _ in range(4):  # the read synchronises the device: a report about someone else's pass may surface here -- consumed, and not this viewer's
-            try:
-                return self.frameBuffer.read(np.uint8, 4 * self.width * self.height).reshape(self.height, self.width, 4)
-            except CapacityError as e:
-                own = hex(int(self.forwardPass.handle.value or 0)) if self.forwardPass is not None else ""
-                if own and own in str(e).lower():
-                    raise
         return self.frameBuffer.read(np.uint8, 4 * self.width * self.height).reshape(self.height, self.width, 4)
 
     def savePNG(self, path: str) -> None:
