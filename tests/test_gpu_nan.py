@@ -102,6 +102,21 @@ def test_step_with_non_finite_gaussians(hip_device, orc, field, value):
     assert not diffs, "\n".join(diffs)
 
 
+@pytest.mark.parametrize("field,value,every", [("position", NAN16, 2), ("x", NAN16, 2), ("z", 0xFE00, 3), ("position", INF16, 2), ("opacity", NAN16, 2), ("z", NAN16, 1)],
+                         ids=["nan-positions", "nan-x", "-nan-z", "inf-positions", "nan-opacity", "all-nan-z"])
+def test_a_pile_of_non_finite_gaussians_behind_a_dead_block(hip_device, orc, field, value, every):
+    """The late regime's tile 0 in small: 1 300-4 000 Gaussians with a NaN (or infinite) field behind the real ones of their tile -- dozens of chunks whose
+    records a dead block drops (raster.hip: EXACT, `dead`), and a tile list that `segment_sort` sorts through global memory (more than 2 048 entries:
+    sort.hip, seg_pass_global).  A NaN position gives a NaN depth, which sorts last; a NaN opacity leaves the depth a number; an infinite position makes
+    it an infinity or a NaN by the camera's row.  Either way: two steps equal to the oracle's."""
+    cfg = harness.small_config("c1", num_points=4000, width=64, height=48)
+    g, sh, cam = poisoned(cfg, field, value, every=every)
+    rng = np.random.default_rng(6)
+    target = rng.integers(0, 255, (cfg.height, cfg.width, 4), dtype=np.uint8)
+    diffs = step_differences(orc, hip_device, cfg, g, sh, cam, target, steps=2)
+    assert not diffs, "\n".join(diffs)
+
+
 def _rows(rows):
     """(x, y, z, opacity_raw, log_sigma) -> packed Gaussians and SH (DC only)."""
     g = np.zeros((len(rows), 12), np.uint16)
