@@ -21,16 +21,20 @@ python3 scripts/pmc_to_json.py $O/pmc_${TAG} $O/${TAG}_pmc.json c3
 cp $O/${TAG}_pmc.json $R/profiles/${TAG}_pmc.json
 python3 scripts/hbm_table.py $O/${TAG}_pmc.json $O/${TAG}_c3_kernel_stats.csv ${TAG} > $O/${TAG}_hbm_by_kernel.md
 cat $O/${TAG}_hbm_by_kernel.md
-echo "== bench c3 (headline, full)"; timeout -k 10 600 python3 bench.py > $O/${TAG}_bench_c3.json 2> $O/${TAG}_bench_c3.err
+echo "== bench c3 (headline, full: the driver's command)"; T0=$(date +%s.%N); timeout -k 10 600 python3 bench.py > $O/${TAG}_bench_c3.json 2> $O/${TAG}_bench_c3.err; echo "default bench.py wall: $(python3 -c "import time,sys; print(round(time.time() - float(sys.argv[1]), 1))" $T0) s" | tee $O/${TAG}_bench_c3_wall.txt
 echo "== bench c2"; timeout -k 10 300 python3 bench.py --config c2 > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
 echo "== bench c5"; timeout -k 10 400 python3 bench.py --config c5 --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c5.json 2> $O/${TAG}_bench_c5.err
 echo "== bench c3, 8 views per step"; for L in 3 1; do timeout -k 10 500 python3 bench.py --views-per-rank 8 --lanes $L --steps 10 --warmup 2 --sustained-steps 0 --no-cpu-baseline > $O/${TAG}_bench_c3_vpr8_lanes${L}.json 2> $O/${TAG}_bench_vpr8.err; done
 echo "== the same measurement through the TypeScript-side host (node + N-API addon)"
 timeout -k 10 400 node bindings/napi/bench.js --config c3 --sustained-steps 608 > $O/${TAG}_benchjs_c3.json 2> $O/${TAG}_benchjs_c3.err
 timeout -k 10 500 node bindings/napi/bench.js --config c3 --views-per-step 8 --steps 10 --warmup 2 > $O/${TAG}_benchjs_c3_vpr8.json 2> $O/${TAG}_benchjs_c3_vpr8.err
-echo "== c2 counters"
+echo "== c2 kernel trace + counters"
+rm -rf $O/prof_${TAG}c2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}c2 -- python3 bench.py --config c2 --sustained-steps 0 --no-cpu-baseline --no-batched-step --min-seconds 0.3 > $O/${TAG}_bench_c2_under_rocprof.json 2>> $O/${TAG}_rocprof.err || true
+cp $(find $O/prof_${TAG}c2 -name "*kernel_stats.csv" | head -1) $O/${TAG}_c2_kernel_stats.csv || true
 timeout -k 10 600 bash scripts/pmc.sh ${TAG}c2 c2 3 > $O/${TAG}_c2_pmc.log 2>&1 || tail -5 $O/${TAG}_c2_pmc.log
 python3 scripts/pmc_to_json.py $O/pmc_${TAG}c2 $O/${TAG}_c2_pmc.json c2 || true
+python3 scripts/hbm_table.py $O/${TAG}_c2_pmc.json $O/${TAG}_c2_kernel_stats.csv ${TAG}c2 > $O/${TAG}_c2_hbm_by_kernel.md || true
 python3 -c "
 import json
 for f in ('bench_c3','bench_c2','bench_c5','bench_c3_vpr8_lanes3','bench_c3_vpr8_lanes1'):
