@@ -34,6 +34,7 @@ async function main() {
   const t = new Trainer(dev, undefined, { random, viewsPerStep: meta.views_per_step || 1, lanes: meta.lanes || 0, pipelineDepth: meta.pipeline_depth || 1,
     keepGradients: !!meta.keep_gradients, exchange });
   t.setDensifyPruneConfig(meta.densify);
+  if (meta.long_lists) t.longLists = meta.long_lists;   // long tile lists (csrc/longlist.h) with the test's threshold and scratch sizes
   t.setPointCloud(pc);
   t.setDataset(cameras, images);
   t.start();
@@ -47,6 +48,7 @@ async function main() {
   if (drawn !== draws.length) throw new Error(`drew ${drawn} views, schedule has ${draws.length}`);
   dev.synchronize();
   const n = t.getPointCount();
+  const longLists = { settings: t.longLists, stats: t.forwardPass.longListStats() };
   // deferred SH writes: a raw device copy of the rows (no hook) is stale, a host read through the buffer is current -- no flushPointCloud() call here
   if (t.deferredSH) {
     const raw = new Uint32Array(hip.addon.copyToHost(dev.handle, t.pointCloud.sh_buffer.ptr, n * 96));
@@ -69,7 +71,7 @@ async function main() {
   if (meta.skip_probes) {   // (full-size runs: the scanner / sorter / overflow probes below belong to the small cases)
     fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ hashes, num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
       last_densify: t.getLastDensifyPruneIteration(), next_densify: t.getNextDensifyPruneIteration(), iters_per_s: t.getItersPerSec(), recorded_views: t.commandBuffers.size,
-      stale_rows_seen: staleRowsSeen, exchange: exchange.name }));
+      stale_rows_seen: staleRowsSeen, exchange: exchange.name, long_lists: longLists }));
     const lastCloud = t.pointCloud;
     t.destroy(); exchange.destroy();
     lastCloud.gaussian_3d_buffer.destroy(); lastCloud.sh_buffer.destroy();
@@ -130,7 +132,7 @@ async function main() {
   fs.writeFileSync(path.join(dir, 'out_meta.json'), JSON.stringify({ overflow, hashes, num_points: n, iteration: t.getIteration(), optimizer_iteration: t.optimizer.getIteration(), sizes,
     last_densify: t.getLastDensifyPruneIteration(), next_densify: t.getNextDensifyPruneIteration(), iters_per_s: t.getItersPerSec(), scan_ok: scanOk, sort_ok: sortOk,
     recorded_views: t.commandBuffers.size, recorded_keys: Array.from(t.commandBuffers.keys()), lanes: t.lanes, op_sets: t.opSets, stale_rows_seen: staleRowsSeen,
-    exchange: exchange.name }));
+    exchange: exchange.name, long_lists: longLists }));
   const last = t.pointCloud;
   t.destroy();
   exchange.destroy();

@@ -29,6 +29,9 @@ FORMS = {
     "batched_two_lanes_depth2": dict(views_per_step=2, lanes=2, pipeline_depth=2),
     "batched_sliced_over_rccl": dict(views_per_step=2, lanes=2, comm="capi"),
     "one_view_gradients_kept": dict(keep_gradients=True),
+    # long tile lists (csrc/longlist.h) for every tile above 40 entries, from scratch too small for them: no tile takes them until the densify event at
+    # iteration 6 has enlarged it (growLongLists / _grow_long_lists), every long tile from then on -- the same frames in both hosts, the same bits either way
+    "one_view_long_lists_grown_at_the_event": dict(pipeline_depth=2, long_lists=dict(threshold=40, maxItems=64, maxRows=65536)),
 }
 
 
@@ -83,6 +86,8 @@ def test_node_trainer_equals_python_trainer(hip_device, orc, tmp_path, form):
     exchange = parallel.CapiExchange(dev) if opts.get("comm") == "capi" else None
     t = Trainer(dev, seed=0, views_per_rank=vps, overlap_views=opts.get("lanes"), pipeline_depth=opts.get("pipeline_depth", 1), exchange=exchange)
     t.keep_gradients = bool(opts.get("keep_gradients"))
+    if opts.get("long_lists"):
+        t.longLists = dict(opts["long_lists"])
     t.setDensifyPruneConfig(dens)
     t.setPointCloud(ops.createPointCloud(dev, g, sh, cfg.sh_deg))
     t.setDataset([dict(camera=cams[i], width=cfg.width, height=cfg.height) for i in range(4)],
@@ -104,6 +109,12 @@ def test_node_trainer_equals_python_trainer(hip_device, orc, tmp_path, form):
         words = dict(optPosBuffer=12, optRotBuffer=12, optScaleBuffer=12, optOpacityBuffer=3, paramSH=48, stateSH=96)
         for k, b in t.optimizer.getStateBuffers().items():
             assert_bits_equal(np.fromfile(tmp_path / f"out_state_{k}.bin", np.uint32), b.read(np.uint32)[: n * words[k]], f"node vs python: state {k}")
+        if opts.get("long_lists"):
+            mine, theirs = t.forwardPass.longListStats(), out["long_lists"]["stats"]
+            assert {k: theirs.get(k) for k in mine} == mine, ("the last frame's long-list work, node vs python", theirs, mine)
+            assert mine["maxItems"] > 64 and mine["itemsWanted"] <= mine["maxItems"] and mine["blocksWanted"] >= 4 and not mine["stalled"], mine
+            assert mine["forwardQueue"] >= 2 * (mine["itemsWanted"] + mine["blocksWanted"]), ("the tasks of the last frame were all drawn", mine)
+            assert out["long_lists"]["settings"]["maxItems"] == t.longLists["maxItems"] and out["long_lists"]["settings"]["maxRows"] == t.longLists["maxRows"]
         if opts.get("keep_gradients"):
             grads = np.fromfile(tmp_path / "out_gradients.bin", np.uint32)
             assert_bits_equal(grads, t.backwardPass.getGradientsBuffer().read(np.uint32)[: n * 8], "node vs python: packed gradients of the last step")
