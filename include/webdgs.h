@@ -230,10 +230,12 @@ int wdgs_tiled_forward_check(wdgs_tiled_forward* op, uint32_t* stats_out);
  * library composites every entry, and gives the blocks of a tile with more than `threshold` entries per-PIXEL lists, built and walked by tasks that the
  * waves of the rasterization kernels work off themselves (csrc/longlist.h) -- no launch, no host decision: the path is part of every recording and taken
  * on the device.  Results do not depend on it.  A pass is created with threshold 2048, room for 1024 (block, 64-entry chunk) slots and 8192 list rows (13 MB);
- * a tile that finds no room is composited the ordinary way (correct, slow).  set_long_lists re-sizes the work (threshold 0: off; items / rows 0: keep);
+ * the path is taken by ALL long tiles of a frame or by none: a frame whose long tiles want more slots than there are is composited the ordinary way
+ * (correct; slow if its long tiles are few, right if they are many: a frame full of long tiles keeps the chip busy without it).  set_long_lists re-sizes the work (threshold 0: off; items / rows 0: keep);
  * synchronises, not allowed while recording, command buffers recorded against the pass must be dropped.  long_list_stats (synchronises) returns
  * {block records wanted, item slots wanted, forward queue position, backward queue position, rows handed out, rows wanted, stall code (0 = none), 0,
- *  max_items, max_blocks, max_rows, threshold} of the last frame: a host compares wanted with the capacities and enlarges them. */
+ *  max_items, max_blocks, max_rows, threshold} of the last frame: a host compares wanted with the capacities and enlarges them -- up to a cap of its
+ * choosing (the Trainers: 8 192 slots, 65 536 rows). */
 int wdgs_tiled_forward_set_long_lists(wdgs_tiled_forward* op, uint32_t threshold, uint32_t max_items, uint32_t max_rows);
 int wdgs_tiled_forward_long_list_stats(wdgs_tiled_forward* op, uint32_t stats_out[12]);
 

@@ -286,12 +286,6 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
                 // as a column of an [8][64] array, lane (q, part) reads back eight consecutive entries of row q and adds them with plain
                 // integer adds, and three DPP steps inside the eight lanes of a row's group finish the sum.  LDS operations of one wave
                 // execute in order, so the stores, the transposed reads and the next iteration's stores need no barrier between them.
-#ifdef WDGS_EXPERIMENT_NO_LDS_SUMS  // timing experiment only (results are wrong): no transposition through LDS, no DPP steps
-                m = (f_mx + f_my) + (f_cx + f_cy) + ((f_cz + f_op) + (f_r + f_g)) + f_b;
-                if (false) {
-#else
-                {
-#endif
                 s_sum[0u * 64u + lane] = f_mx; s_sum[1u * 64u + lane] = f_my; s_sum[2u * 64u + lane] = f_cx; s_sum[3u * 64u + lane] = f_cy;
                 s_sum[4u * 64u + lane] = f_cz; s_sum[5u * 64u + lane] = f_op; s_sum[6u * 64u + lane] = f_r; s_sum[7u * 64u + lane] = f_g;
                 const int4 h0 = *sum_rd0, h1 = *sum_rd1;
@@ -304,7 +298,6 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
                 b += (unsigned)dpp_ror4((int)b);
                 b += (unsigned)dpp_ror8((int)b);
                 m = sum_lane ? (int)x : (int)b;
-                }
             } else {
             // ---- nine wave sums by a halving butterfly.  Accumulator slots: 0 mx 1 my 2 cx 3 cy 4 cz 5 op 6 r 7 g 8 b.
             // fold32 pairs slot j with slot j+4: lanes < 32 then carry slot j, lanes >= 32 slot j+4.
@@ -323,13 +316,9 @@ __device__ __attribute__((always_inline)) void backward_rasterize_body(const Ren
             if (atomic_lane) {
                 const u32 slot = atomic_slot;
                 const u32 gidx = __float_as_uint(col.w);
-#ifdef WDGS_EXPERIMENT_NO_ATOMICS  // timing experiment only (results are wrong): what the kernel costs without its global atomics
-                asm volatile("" ::"v"(m), "v"(gidx), "v"(slot));
-#else
-                // (no test for m == 0: the atomics cost this kernel nothing -- built without them it takes the same time -- while the
+                // (no test for m == 0: the atomics cost this kernel nothing -- built without them it took the same time, round 3 -- while the
                 // test is a VALU compare in every iteration)
                 atomicAdd(&acc[(size_t)gidx * ACC_STRIDE + slot], m);
-#endif
             }
         }
         __builtin_amdgcn_wave_barrier();  // all lanes are done reading the records before the next chunk overwrites them

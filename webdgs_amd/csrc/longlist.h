@@ -20,7 +20,7 @@
 // None of this is a launch.  The tasks sit in one queue in the order above and are pulled, one atomic each, by the waves of the rasterization
 // kernel itself as they finish their own blocks (the waves of the long tiles at once); a task waits only for tasks in front of it in the queue,
 // which waves that are already running have taken -- so nothing can wait for a wave that has not started.  With no long tile in the frame a wave
-// reads one word (requested when it starts) and leaves: the path is always recorded and decided on the device.  Every operation keeps the operands it has
+// reads two header words (requested when it starts) and leaves: the path is always recorded and decided on the device.  Every operation keeps the operands it has
 // in the wave-per-block walk and the parity oracle's own forms (raster.hip: EXACT), so results are bit-identical whichever path a block takes.
 #pragma once
 #include "common.h"

@@ -482,7 +482,7 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
 // One workgroup per segment (= tile): stable sort of [start, end) by the low 16 key bits.  keys/vals `cur` hold the data (and receive
 // the result); `alt` is the other ping-pong pair, used as scratch by oversized segments only.
 // Long tile lists (longlist.h): the workgroup of a tile with more than lw.threshold entries reserves the tile's four block records and
-// 4 * ceil(n / 64) item slots and marks the tile; every other tile's mark is cleared.  (When a tile finds no room, the header's counts say so and ALL
+// 4 * ceil(n / 64) item slots and marks the tile (the marks were cleared by the frame's first sort_hist).  (When a tile finds no room, the header's counts say so and ALL
 // long tiles of the frame stay with the main waves: longlist.h, ll_frame_on.)
 __device__ void long_list_build(const LongWork& lw, u32 t, u32 n) {
     __shared__ u32 s_first, s_lb;
