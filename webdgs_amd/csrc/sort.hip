@@ -416,15 +416,36 @@ __device__ __forceinline__ void seg_pass_regs(const u32 (&kk)[SEG_ROUNDS], const
     __syncthreads();
 }
 
-// Segments longer than SEG_CAP: the same two stable passes, through global memory.  pass: histogram of the whole segment, exclusive
-// scan, then the chunks of 256 in index order, each ranked stably (wave ballots + earlier waves' counts) on top of running digit bases.
+// A workgroup barrier that orders LDS accesses only (s_barrier behind a wait for the wave's own LDS operations): global loads and stores stay in flight.
+WD_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Segments longer than SEG_CAP: the same two stable passes, through global memory.  pass: histogram of the whole segment, exclusive scan, then the
+// segment in trips of 1 024 entries -- thread t holds entries c0 + j * 256 + t, j = 0..3 (index order = (j, wave, lane)) -- each ranked stably on top
+// of running digit bases.
+//
+// The first form of this pass ranked ONE chunk of 256 per trip: four waves, one per SIMD, each a chain of a dozen dependent LDS round trips and four
+// __syncthreads (which also wait for the trip's global stores), 0.75 us per chunk -- 92 us for the 15 000 entries of the tile in which a long run of the
+// reference's schedule collects its non-finite Gaussians (profiles/r08p_late_regime.txt), 293 us for a 40 000-entry tile.  What was tried on the way
+// and did not matter by itself is in profiles/r09i_*, r09j_*: loads requested ahead, LDS-only barriers, a histogram free of same-address atomics.  What
+// matters is the number of LDS round trips one after the other per entry.  Now: the four chunks' ballot matches are four independent chains; the
+// counts of the trip's sixteen (chunk, wave) groups of a digit lie side by side, [digit][16] of 16 bits, so that thread d turns digit d's counts into
+// positions with two 16-byte reads, a prefix sum in registers and two 16-byte writes; a trip has four barriers, which wait for LDS only; the next
+// trip's pairs are requested at the top of this one.  (15 000 entries: 92 -> 71 us; 40 000: 293 -> 208, profiles/r10c_*.  A trip of 1 024 entries still takes 2.7 us, of which the counted instructions and LDS
+// round trips explain one: the rest has not been found -- requesting the pairs one trip ahead or within the trip makes no difference.)
 __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __restrict__ src_v, u32* __restrict__ dst_k, u32* __restrict__ dst_v, u32 n,
                                 u32 shift, seg_hist_t (*whist)[SEG_BINS], u32* s_base /*[RADIX]*/, u32* s_wsum) {
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     s_base[threadIdx.x] = 0u;
     __syncthreads();
-    for (u32 i = threadIdx.x; i < n; i += SEG_THREADS) atomicAdd(&s_base[(src_k[i] >> shift) & (RADIX - 1u)], 1u);
+    for (u32 i0 = threadIdx.x; i0 < n; i0 += 4u * SEG_THREADS) {   // (four keys per thread and trip, requested together)
+        u32 kh[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) kh[j] = (i0 + j * SEG_THREADS < n) ? src_k[i0 + j * SEG_THREADS] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 4; j++)
+            if (i0 + j * SEG_THREADS < n) atomicAdd(&s_base[(kh[j] >> shift) & (RADIX - 1u)], 1u);
+    }
     __syncthreads();
     {
         const u32 cnt_d = s_base[threadIdx.x];
@@ -442,41 +463,74 @@ __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __rest
         s_base[threadIdx.x] = woff + inc - cnt_d;  // start of digit d in the sorted segment
     }
     __syncthreads();
-    for (u32 c0 = 0; c0 < n; c0 += SEG_THREADS) {
-        const u32 i = c0 + threadIdx.x;  // index order = (wave, lane)
-        const bool valid = i < n;
-        const u32 k = valid ? src_k[i] : 0xFFFFFFFFu;
-        const u32 v = valid ? src_v[i] : 0u;
-        const u32 digit = (k >> shift) & (RADIX - 1u);
-        unsigned long long m = __ballot(valid);
+    seg_hist_t* const cnt16 = &whist[0][0];                                           // [256 digits][16 groups (chunk j, wave)], 8 KB
+    uint4* const my_counts = reinterpret_cast<uint4*>(cnt16 + threadIdx.x * 16u);    // digit d = threadIdx.x: its sixteen counts, 32 bytes
+    u32 kq[4], vq[4];
 #pragma unroll
-        for (u32 b = 0; b < 8; b++) {
-            const bool bit = (digit >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
-        const u32 below = (u32)__popcll(m & lt_mask);
-#pragma unroll
-        for (u32 w = 0; w < SEG_THREADS / 64; w++) whist[w][threadIdx.x] = 0u;
-        __syncthreads();
-        if (valid && below == 0u) whist[wave][digit] = (seg_hist_t)__popcll(m);  // this wave's count of the digit in this chunk
-        __syncthreads();
-        u32 earlier = 0;
-#pragma unroll
-        for (u32 w = 0; w < SEG_THREADS / 64; w++) if (w < wave) earlier += whist[w][digit];
-        if (valid) {
-            const u32 pos = s_base[digit] + earlier + below;
-            dst_k[pos] = k;
-            dst_v[pos] = v;
-        }
-        __syncthreads();
-        {   // advance the running bases by this chunk's totals
-            const u32 d = threadIdx.x;
-            s_base[d] += whist[0][d] + whist[1][d] + whist[2][d] + whist[3][d];
-        }
-        __syncthreads();
+    for (u32 j = 0; j < 4u; j++) {
+        const u32 i = j * SEG_THREADS + threadIdx.x;
+        kq[j] = (i < n) ? src_k[i] : 0xFFFFFFFFu;
+        vq[j] = (i < n) ? src_v[i] : 0u;
     }
-    __threadfence_block();
+    for (u32 c0 = 0; c0 < n; c0 += 4u * SEG_THREADS) {
+        u32 kn[4], vn[4];
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) {
+            const u32 i_next = c0 + (4u + j) * SEG_THREADS + threadIdx.x;
+            kn[j] = (i_next < n) ? src_k[i_next] : 0xFFFFFFFFu;
+            vn[j] = (i_next < n) ? src_v[i_next] : 0u;
+        }
+        my_counts[0] = make_uint4(0u, 0u, 0u, 0u);
+        my_counts[1] = make_uint4(0u, 0u, 0u, 0u);
+        u32 below[4], group[4];   // lanes of this wave with the same digit in chunk j: those in front of this one; all of them (0: this lane is not their first)
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) {
+            const bool valid = c0 + j * SEG_THREADS + threadIdx.x < n;
+            const u32 digit = (kq[j] >> shift) & (RADIX - 1u);
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (u32 b = 0; b < 8; b++) {
+                const bool bit = (digit >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            below[j] = (u32)__popcll(m & lt_mask);
+            group[j] = (valid && below[j] == 0u) ? (u32)__popcll(m) : 0u;
+        }
+        lds_barrier();   // the counts are cleared
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++)
+            if (group[j] != 0u) cnt16[((kq[j] >> shift) & (RADIX - 1u)) * 16u + j * 4u + wave] = (seg_hist_t)group[j];
+        lds_barrier();   // the counts are there
+        u32 trip_total = 0u;
+        {   // digit d's sixteen counts -> where each group's entries of the digit start inside the trip's run of that digit (<= 1 024: 16 bits hold it)
+            uint4 q[2] = {my_counts[0], my_counts[1]};
+            u32* const w = reinterpret_cast<u32*>(q);
+#pragma unroll
+            for (u32 x = 0; x < 8u; x++) {
+                const u32 lo = w[x] & 0xFFFFu, hi = w[x] >> 16u;
+                w[x] = trip_total | ((trip_total + lo) << 16u);
+                trip_total += lo + hi;
+            }
+            my_counts[0] = q[0];
+            my_counts[1] = q[1];
+        }
+        lds_barrier();   // the positions are there
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) {
+            if (c0 + j * SEG_THREADS + threadIdx.x < n) {
+                const u32 digit = (kq[j] >> shift) & (RADIX - 1u);
+                const u32 pos = s_base[digit] + cnt16[digit * 16u + j * 4u + wave] + below[j];
+                dst_k[pos] = kq[j];
+                dst_v[pos] = vq[j];
+            }
+        }
+        lds_barrier();   // everybody has read the bases and the positions
+        s_base[threadIdx.x] += trip_total;   // (read again behind the next trip's three barriers)
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) { kq[j] = kn[j]; vq[j] = vn[j]; }
+    }
+    __syncthreads();   // (the pass's stores are complete: the caller's next pass reads them)
 }
 
 // One workgroup per segment (= tile): stable sort of [start, end) by the low 16 key bits.  keys/vals `cur` hold the data (and receive
@@ -507,7 +561,7 @@ __device__ void long_list_build(const LongWork& lw, u32 t, u32 n) {
     if (threadIdx.x == 0u && ok) lw.flags[t] = 0xFu;
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
+__global__ __launch_bounds__(SEG_THREADS, 6) void segment_sort_kernel(u32* __restrict__ cur_k, u32* __restrict__ cur_v, u32* __restrict__ alt_k,
                                                                     u32* __restrict__ alt_v, const u32* __restrict__ ranges, u32 total_tiles, LongWork lw) {
     WD_STREAM_PRIO();
     __shared__ u32 a_k[SEG_CAP], a_v[SEG_CAP];  // one pair: every pass reads its input into registers before anyone scatters
