@@ -248,6 +248,46 @@ def _pipeline_with_long_lists(threshold, items=0, rows=0, seen=None):
     return make
 
 
+def test_long_lists_follow_a_growing_viewport_and_a_change_of_render_mode(hip_device, orc):
+    """The per-tile marks of the long lists and the stamps of non-finite tiles are sized by the tile grid: a viewport that grows past what the pass was
+    built for re-allocates both (csrc/api.hip: set_viewport).  With every tile above 48 entries a long one: the image and n_contrib after the change
+    equal the oracle's, and so does a frame in point-cloud mode in between (that kernel knows nothing of the lists: the marks must not keep its blocks
+    from being drawn) and the Gaussian frame after it."""
+    from harness import assert_bits_equal
+    cfg = harness.small_config("c1", num_points=6000, width=64, height=48, s0=0.004, fy=140.0)
+    g, sh, cam = harness.scene(cfg)
+    pipe = harness.HipPipeline(hip_device, cfg, g, sh, cam)
+    try:
+        pipe.fwd.setLongLists(48, 8192, 65536)
+        pipe.forward()
+        st = pipe.fwd.longListStats()
+        assert st["blocksWanted"] >= 4 and st["itemsWanted"] <= st["maxItems"] and not st["stalled"], st
+        big = harness.small_config("c1", num_points=6000, width=208, height=112, s0=0.004, fy=140.0)
+        cam2 = synth.identity_camera(big)
+        pipe.camera.write(cam2)
+        pipe.fwd.setViewport(big.width, big.height)
+        pipe.cfg = big
+        rs, ti = synth.render_settings(big), synth.tile_info(big.width, big.height, 0)
+        ref = orc.forward(g, sh, cam2, rs, ti)
+        for what in ("after the viewport change", "again, after a frame in point-cloud mode"):
+            pipe.forward()
+            got = pipe.collect_forward()
+            st = pipe.fwd.longListStats()
+            assert st["blocksWanted"] >= 4 and st["itemsWanted"] <= st["maxItems"] and st["forwardQueue"] >= 2 * (st["itemsWanted"] + st["blocksWanted"]) and not st["stalled"], st
+            assert_bits_equal(got["rgba8"], ref["rgba8"], "image " + what)
+            assert_bits_equal(got["n_contrib"], ref["n_contrib"], "n_contrib " + what)
+            assert not differences(got["final_T"], ref["final_T"], "final T " + what, np.float32)
+            if what.startswith("after"):
+                pipe.fwd.setRenderMode("pointcloud")
+                pipe.forward()
+                points = pipe.collect_forward()["rgba8"]
+                ps = synth.render_settings(big, gaussian_mode=0.0)   # (point size: the pass's default, 3 px)
+                assert_bits_equal(points, orc.forward(g, sh, cam2, ps, ti)["rgba8"], "point-cloud frame between two Gaussian frames with long lists")
+                pipe.fwd.setRenderMode("gaussian")
+    finally:
+        pipe.destroy()
+
+
 @pytest.mark.parametrize("case", ["every-tile", "no-item-slots", "no-rows", "off"])
 def test_long_list_tasks_and_their_fallbacks(hip_device, orc, case):
     """The per-pixel lists of long tiles (csrc/longlist.h) at a threshold of 48 entries, so that most tiles of an ordinary scene take them: built by the
