@@ -430,8 +430,9 @@ WD_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :::
 // matters is the number of LDS round trips one after the other per entry.  Now: the four chunks' ballot matches are four independent chains; the
 // counts of the trip's sixteen (chunk, wave) groups of a digit lie side by side, [digit][16] of 16 bits, so that thread d turns digit d's counts into
 // positions with two 16-byte reads, a prefix sum in registers and two 16-byte writes; a trip has four barriers, which wait for LDS only; the next
-// trip's pairs are requested at the top of this one.  (15 000 entries: 92 -> 71 us; 40 000: 293 -> 208, profiles/r10c_*.  A trip of 1 024 entries still takes 2.7 us, of which the counted instructions and LDS
-// round trips explain one: the rest has not been found -- requesting the pairs one trip ahead or within the trip makes no difference.)
+// trip's pairs are requested at the top of this one.  (15 000 entries: 92 -> 71 us; 40 000: 293 -> 208, profiles/r10c_*.  A trip of 1 024 entries still takes 2.4-2.7 us, and 2.0 of them with every global
+// access taken out (scripts/microbench/seg_pass_phases.hip, profiles/r11c_seg_pass_phases.txt): the trip is ~450 instructions of a wave that is alone
+// on its SIMD, and such a wave issues one every 5-10 cycles.  More entries per second from here means more waves: several workgroups per segment.)
 __device__ void seg_pass_global(const u32* __restrict__ src_k, const u32* __restrict__ src_v, u32* __restrict__ dst_k, u32* __restrict__ dst_v, u32 n,
                                 u32 shift, seg_hist_t (*whist)[SEG_BINS], u32* s_base /*[RADIX]*/, u32* s_wsum) {
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
